@@ -1,0 +1,452 @@
+// Projection head pieces and the InfoNCE / SupCon loss.
+//   contrastyou/projectors/heads.py:14-22,81-96 + projectors/nn.py:47-54
+//     AdaptiveAvgPool2d(1) -> Linear -> LeakyReLU(0.01) -> Linear -> L2 normalise
+//   contrastyou/losses/contrastive.py:14-20,31-100  (exp_sim_temperature, SupConLoss1)
+// Everything here is f32: the embedding x embedding similarity and the
+// G*P products run on the exact f32 MFMA (v_mfma_f32_32x32x2_f32).
+#include "cy_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- sgemm (f32 MFMA)
+// C[M][N] = alpha * A[M][K] * op(B).  64x64 block tile, 4 waves each a 32x32
+// MFMA accumulator, K staged 16 at a time through LDS.
+template <bool BT>
+__global__ void __launch_bounds__(256)
+    sgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                 int M, int N, int K, float alpha) {
+  __shared__ float sA[64][17];
+  __shared__ float sB[16][65];  // [k][n]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int i = lane & 31, kk = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    __syncthreads();
+    // A tile: 64 rows x 16 k
+    for (int e = tid; e < 64 * 16; e += 256) {
+      const int rr = e >> 4, kc = e & 15;
+      const int gm = m0 + rr, gk = k0 + kc;
+      sA[rr][kc] = (gm < M && gk < K) ? A[(size_t)gm * K + gk] : 0.f;
+    }
+    if (BT) {
+      for (int e = tid; e < 64 * 16; e += 256) {
+        const int nn = e >> 4, kc = e & 15;
+        const int gn = n0 + nn, gk = k0 + kc;
+        sB[kc][nn] = (gn < N && gk < K) ? B[(size_t)gn * K + gk] : 0.f;
+      }
+    } else {
+      for (int e = tid; e < 64 * 16; e += 256) {
+        const int kc = e >> 6, nn = e & 63;
+        const int gn = n0 + nn, gk = k0 + kc;
+        sB[kc][nn] = (gn < N && gk < K) ? B[(size_t)gk * N + gn] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 2) {
+      const float av = sA[wm * 32 + i][ks + kk];
+      const float bv = sB[ks + kk][wn * 32 + i];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+    const int gm = m0 + wm * 32 + row, gn = n0 + wn * 32 + i;
+    if (gm < M && gn < N) C[(size_t)gm * N + gn] = alpha * acc[reg];
+  }
+}
+
+int launch_sgemm(const float* A, const float* B, float* C, int M, int N, int K, float alpha,
+                 int b_trans, hipStream_t st) {
+  dim3 grid(cy_cdiv(N, 64), cy_cdiv(M, 64));
+  if (b_trans)
+    hipLaunchKernelGGL(sgemm_kernel<true>, grid, dim3(256), 0, st, A, B, C, M, N, K, alpha);
+  else
+    hipLaunchKernelGGL(sgemm_kernel<false>, grid, dim3(256), 0, st, A, B, C, M, N, K, alpha);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+// ---------------------------------------------------------------- SupCon
+__device__ __forceinline__ bool is_pos(const int32_t* labels, const uint8_t* pm, int n, int i,
+                                       int j) {
+  const int a = i % n, b = j % n;
+  if (labels) return labels[a] == labels[b];
+  return pm[(size_t)a * n + b] != 0;
+}
+
+// one wave per row: row max (incl. diagonal), sum_{k!=i} exp(s-m), sum over positives, count
+__global__ void __launch_bounds__(256)
+    supcon_rowstats_kernel(const float* __restrict__ S, const int32_t* __restrict__ labels,
+                           const uint8_t* __restrict__ pm, float* __restrict__ tmp, int n) {
+  const int R = 2 * n;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float* sr = S + (size_t)row * R;
+  float m = -INFINITY;
+  for (int j = lane; j < R; j += 64) m = fmaxf(m, sr[j]);
+  m = wave_max(m);
+  float l = 0.f, ps = 0.f, cnt = 0.f;
+  for (int j = lane; j < R; j += 64) {
+    if (j == row) continue;
+    const float s = sr[j];
+    l += expf(s - m);
+    if (is_pos(labels, pm, n, row, j)) {
+      ps += s;
+      cnt += 1.f;
+    }
+  }
+  l = wave_sum(l);
+  ps = wave_sum(ps);
+  cnt = wave_sum(cnt);
+  if (lane == 0) {
+    tmp[row * 4 + 0] = m;
+    tmp[row * 4 + 1] = l;
+    tmp[row * 4 + 2] = ps;
+    tmp[row * 4 + 3] = cnt;
+  }
+}
+
+// single block: global max, per-row denominators, mean loss
+__global__ void __launch_bounds__(256)
+    supcon_finalize_kernel(float* __restrict__ row_stats, float* __restrict__ loss, int R) {
+  __shared__ float smax[256];
+  __shared__ double ssum[256];
+  const int tid = threadIdx.x;
+  float m = -INFINITY;
+  for (int i = tid; i < R; i += 256) m = fmaxf(m, row_stats[i * 4 + 0]);
+  smax[tid] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) smax[tid] = fmaxf(smax[tid], smax[tid + o]);
+    __syncthreads();
+  }
+  const float M = smax[0];
+  double acc = 0.0;
+  for (int i = tid; i < R; i += 256) {
+    const float mi = row_stats[i * 4 + 0], li = row_stats[i * 4 + 1];
+    const float ps = row_stats[i * 4 + 2], cnt = row_stats[i * 4 + 3];
+    const float Di = li * expf(mi - M) + 1e-16f;
+    const float li_loss = ps / cnt - M - logf(Di);  // cnt==0 -> NaN like the reference
+    acc += (double)li_loss;
+    row_stats[i * 4 + 0] = Di;
+    row_stats[i * 4 + 1] = cnt;
+    row_stats[i * 4 + 2] = ps;
+    row_stats[i * 4 + 3] = M;
+  }
+  ssum[tid] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) ssum[tid] += ssum[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) loss[0] = (float)(-ssum[0] / (double)R);
+}
+
+// G + G^T with G_ij = -(g/R) [pos_ij/cnt_i - e_ij/D_i], zero diagonal
+__global__ void __launch_bounds__(256)
+    supcon_gsym_kernel(const float* __restrict__ S, const float* __restrict__ rs,
+                       const int32_t* __restrict__ labels, const uint8_t* __restrict__ pm,
+                       const float* __restrict__ gscale, float* __restrict__ G, int n) {
+  const int R = 2 * n;
+  const long total = (long)R * R;
+  const float gs = gscale[0] / (float)R;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const int i = (int)(e / R), j = (int)(e % R);
+    float v = 0.f;
+    if (i != j) {
+      const float M = rs[3];
+      const float eij = expf(S[e] - M);
+      const float Di = rs[i * 4 + 0], Dj = rs[j * 4 + 0];
+      const float ci = rs[i * 4 + 1], cj = rs[j * 4 + 1];
+      const float pos = is_pos(labels, pm, n, i, j) ? 1.f : 0.f;
+      v = -gs * (pos * (1.f / ci + 1.f / cj) - eij * (1.f / Di + 1.f / Dj));
+    }
+    G[e] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    supcon_matrices_kernel(const float* __restrict__ S, const float* __restrict__ rs,
+                           const int32_t* __restrict__ labels, const uint8_t* __restrict__ pm,
+                           float* sl, float* se, float* po, float* ne, int n) {
+  const int R = 2 * n;
+  const long total = (long)R * R;
+  const float M = rs[3];
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const int i = (int)(e / R), j = (int)(e % R);
+    const float s = S[e] - M;
+    if (sl) sl[e] = s;
+    if (se) se[e] = expf(s);
+    const bool pos = is_pos(labels, pm, n, i, j);
+    if (po) po[e] = (i != j && pos) ? 1.f : 0.f;
+    if (ne) ne[e] = (i != j && !pos) ? 1.f : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------- avg pool
+template <typename T>
+__global__ void __launch_bounds__(256)
+    avgpool_fwd_kernel(const T* __restrict__ x, float* __restrict__ pooled, int HW, int C) {
+  // grid: (N, ceil(C/256)); thread = channel; loops over pixels (coalesced across channels)
+  const int n = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const T* xp = x + (size_t)n * HW * C + c;
+  float s = 0.f;
+  for (int p = 0; p < HW; ++p) s += to_f32<T>(xp[(size_t)p * C]);
+  pooled[(size_t)n * C + c] = s / (float)HW;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+    avgpool_bwd_kernel(const float* __restrict__ dpooled, T* __restrict__ dx, int N, int HW,
+                       int C) {
+  const long total = (long)N * HW * C;
+  const float inv = 1.f / (float)HW;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const int c = (int)(e % C);
+    const int n = (int)(e / ((long)HW * C));
+    dx[e] = from_f32<T>(dpooled[(size_t)n * C + c] * inv);
+  }
+}
+
+// ---------------------------------------------------------------- linear
+// one wave per output element y[m][o]
+__global__ void __launch_bounds__(256)
+    linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                      const float* __restrict__ b, float* __restrict__ y, int M, int I, int O,
+                      int act, float slope) {
+  const int lane = threadIdx.x & 63;
+  const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= (long)M * O) return;
+  const int m = (int)(e / O), o = (int)(e % O);
+  const float* xr = x + (size_t)m * I;
+  const float* wr = w + (size_t)o * I;
+  float s = 0.f;
+  for (int i = lane; i < I; i += 64) s = fmaf(xr[i], wr[i], s);
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (b) s += b[o];
+    if (act == 1) s = s > 0.f ? s : s * slope;
+    y[e] = s;
+  }
+}
+
+// dz = dy * act'(y) is formed on the fly
+__device__ __forceinline__ float act_grad(float y, float dy, int act, float slope) {
+  return act == 1 ? (y > 0.f ? dy : dy * slope) : dy;
+}
+
+__global__ void __launch_bounds__(256)
+    linear_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ y,
+                         const float* __restrict__ dy, float* __restrict__ dx, int M, int I, int O,
+                         int act, float slope) {
+  const long e = blockIdx.x * 256L + threadIdx.x;
+  if (e >= (long)M * I) return;
+  const int m = (int)(e / I), i = (int)(e % I);
+  float s = 0.f;
+  for (int o = 0; o < O; ++o)
+    s = fmaf(act_grad(y[(size_t)m * O + o], dy[(size_t)m * O + o], act, slope),
+             w[(size_t)o * I + i], s);
+  dx[e] = s;
+}
+
+__global__ void __launch_bounds__(256)
+    linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                         const float* __restrict__ dy, float* __restrict__ dw,
+                         float* __restrict__ db, int M, int I, int O, int act, float slope) {
+  const long e = blockIdx.x * 256L + threadIdx.x;
+  if (e >= (long)O * I) return;
+  const int o = (int)(e / I), i = (int)(e % I);
+  float s = 0.f, sb = 0.f;
+  for (int m = 0; m < M; ++m) {
+    const float dz = act_grad(y[(size_t)m * O + o], dy[(size_t)m * O + o], act, slope);
+    s = fmaf(dz, x[(size_t)m * I + i], s);
+    sb += dz;
+  }
+  if (dw) dw[e] = s;
+  if (db && i == 0) db[o] = sb;
+}
+
+// ---------------------------------------------------------------- L2 normalise (wave per row)
+__global__ void __launch_bounds__(256)
+    l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ z,
+                      float* __restrict__ norms, int M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* xr = x + (size_t)m * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s = fmaf(xr[i], xr[i], s);
+  s = wave_sum(s);
+  const float nrm = sqrtf(s);
+  const float den = fmaxf(nrm, eps);
+  for (int i = lane; i < D; i += 64) z[(size_t)m * D + i] = xr[i] / den;
+  if (lane == 0) norms[m] = nrm;
+}
+
+__global__ void __launch_bounds__(256)
+    l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ norms,
+                      const float* __restrict__ dz, float* __restrict__ dx, int M, int D,
+                      float eps) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* xr = x + (size_t)m * D;
+  const float* gr = dz + (size_t)m * D;
+  const float nrm = norms[m];
+  if (nrm > eps) {
+    float dot = 0.f;
+    for (int i = lane; i < D; i += 64) dot = fmaf(xr[i], gr[i], dot);
+    dot = wave_sum(dot);
+    const float inv = 1.f / nrm;
+    const float k = dot * inv * inv * inv;
+    for (int i = lane; i < D; i += 64) dx[(size_t)m * D + i] = gr[i] * inv - xr[i] * k;
+  } else {
+    const float inv = 1.f / eps;
+    for (int i = lane; i < D; i += 64) dx[(size_t)m * D + i] = gr[i] * inv;
+  }
+}
+
+inline int grid_for(long total) {
+  long b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cy_sgemm(const float* A, const float* B, float* C, int M, int N, int K, float alpha,
+             int b_trans, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return CY_ERR_ARG;
+  return launch_sgemm(A, B, C, M, N, K, alpha, b_trans, (hipStream_t)stream);
+}
+
+int cy_supcon_fwd(const float* P, const int32_t* labels, const uint8_t* pos_mask, float* S,
+                  float* loss, float* row_stats, int n, int D, float t, void* stream) {
+  if (!P || (!labels && !pos_mask) || !S || !loss || !row_stats) return CY_ERR_ARG;
+  if (n <= 0 || D <= 0 || !(t > 0.f)) return CY_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int R = 2 * n;
+  int rc = launch_sgemm(P, P, S, R, R, D, 1.f / t, 1, st);
+  if (rc != CY_OK) return rc;
+  hipLaunchKernelGGL(supcon_rowstats_kernel, dim3(cy_cdiv(R, 4)), dim3(256), 0, st, S, labels,
+                     pos_mask, row_stats, n);
+  CY_CHECK_LAUNCH();
+  hipLaunchKernelGGL(supcon_finalize_kernel, dim3(1), dim3(256), 0, st, row_stats, loss, R);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_supcon_bwd(const float* P, const int32_t* labels, const uint8_t* pos_mask, const float* S,
+                  const float* row_stats, const float* gscale, float* G, float* dP, int n, int D,
+                  float t, void* stream) {
+  if (!P || (!labels && !pos_mask) || !S || !row_stats || !gscale || !G || !dP) return CY_ERR_ARG;
+  if (n <= 0 || D <= 0 || !(t > 0.f)) return CY_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int R = 2 * n;
+  hipLaunchKernelGGL(supcon_gsym_kernel, dim3(grid_for((long)R * R)), dim3(256), 0, st, S,
+                     row_stats, labels, pos_mask, gscale, G, n);
+  CY_CHECK_LAUNCH();
+  return launch_sgemm(G, P, dP, R, D, R, 1.f / t, 0, st);
+}
+
+int cy_supcon_matrices(const float* S, const float* row_stats, const int32_t* labels,
+                       const uint8_t* pos_mask, float* sim_logits, float* sim_exp,
+                       float* pos_out, float* neg_out, int n, void* stream) {
+  if (!S || !row_stats || (!labels && !pos_mask) || n <= 0) return CY_ERR_ARG;
+  const int R = 2 * n;
+  hipLaunchKernelGGL(supcon_matrices_kernel, dim3(grid_for((long)R * R)), dim3(256), 0,
+                     (hipStream_t)stream, S, row_stats, labels, pos_mask, sim_logits, sim_exp,
+                     pos_out, neg_out, n);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_avgpool_fwd(const void* x, float* pooled, int N, int HW, int C, int dtype, void* stream) {
+  if (!x || !pooled || N <= 0 || HW <= 0 || C <= 0) return CY_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(N, cy_cdiv(C, 256));
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(avgpool_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, pooled,
+                       HW, C);
+  else if (dtype == CY_F32)
+    hipLaunchKernelGGL(avgpool_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, pooled,
+                       HW, C);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_avgpool_bwd(const float* dpooled, void* dx, int N, int HW, int C, int dtype, void* stream) {
+  if (!dpooled || !dx || N <= 0 || HW <= 0 || C <= 0) return CY_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for((long)N * HW * C);
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(avgpool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, dpooled, (bf16*)dx,
+                       N, HW, C);
+  else if (dtype == CY_F32)
+    hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, dpooled,
+                       (float*)dx, N, HW, C);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int I, int O,
+                  int act, float slope, void* stream) {
+  if (!x || !w || !y || M <= 0 || I <= 0 || O <= 0) return CY_ERR_ARG;
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cy_cdiv((long)M * O, 4)), dim3(256), 0,
+                     (hipStream_t)stream, x, w, b, y, M, I, O, act, slope);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
+                  float* dw, float* db, int M, int I, int O, int act, float slope, void* stream) {
+  if (!x || !w || !y || !dy || M <= 0 || I <= 0 || O <= 0) return CY_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) {
+    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cy_cdiv((long)M * I, 256)), dim3(256), 0, st, w,
+                       y, dy, dx, M, I, O, act, slope);
+    CY_CHECK_LAUNCH();
+  }
+  if (dw || db) {
+    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cy_cdiv((long)O * I, 256)), dim3(256), 0, st, x,
+                       y, dy, dw, db, M, I, O, act, slope);
+    CY_CHECK_LAUNCH();
+  }
+  return CY_OK;
+}
+
+int cy_l2norm_fwd(const float* x, float* z, float* norms, int M, int D, float eps, void* stream) {
+  if (!x || !z || !norms || M <= 0 || D <= 0) return CY_ERR_ARG;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cy_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x,
+                     z, norms, M, D, eps);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_l2norm_bwd(const float* x, const float* norms, const float* dz, float* dx, int M, int D,
+                  float eps, void* stream) {
+  if (!x || !norms || !dz || !dx || M <= 0 || D <= 0) return CY_ERR_ARG;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cy_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x,
+                     norms, dz, dx, M, D, eps);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,555 @@
+// 3x3 convolution (stride 1, pad 1, no bias) as an implicit GEMM on the gfx950
+// matrix cores.  Replaces nn.Conv2d at contrastyou/arch/unet.py:21,24,39 and,
+// through the load-side modes, nn.MaxPool2d (unet.py:67-70), nn.Upsample
+// (unet.py:38), torch.cat (unet.py:142,151,160,169) and the BatchNorm+ReLU of
+// the previous layer (unet.py:22-23).  The same kernel computes the data
+// gradient (run on dy with the flipped/transposed weight image).
+//
+// GEMM view:  out[p][co] = sum_{tap,ci} in[p + tap][ci] * w[tap][co][ci]
+//   M = pixels of a TH x TW spatial tile (rows are flattened n*H+h rows, so a
+//       tile may span images), N = BN output channels, K = 9 taps x Cin.
+// A (activations) is staged once per input-channel chunk as a (TH+2)x(TW+2)
+// halo tile in LDS and re-read by all 9 taps at shifted addresses; B (weights)
+// streams through a double-buffered LDS slice per (chunk, tap).  Four waves per
+// workgroup, each owning M_REP x N_REP 32x32 MFMA accumulators.
+// The epilogue rounds to the storage type, emits per-tile per-channel sum /
+// sum-of-squares partials for the following BatchNorm (deterministic: one
+// partial per tile, fixed-order reduction in cy_bn_finalize) and stores
+// 16-byte NHWC chunks after a wave-private LDS transpose.
+#include "cy_conv_tile.h"
+
+namespace {
+
+template <typename T, typename TO, int TH, int TW, int BN, int WGM, int WGN, int PITCHB>
+struct ConvCfg {
+  static constexpr int EPC = ElemTr<T>::EPC;
+  static constexpr int KC = PITCHB / (int)sizeof(T);
+  static constexpr int CPP = PITCHB / 16;
+  static constexpr int KS = KC / 16;
+  static constexpr int HW2 = TW + 2;
+  static constexpr int ZSLOT = TH + 2;
+  static constexpr int A_BYTES = (TH + 3) * HW2 * PITCHB;
+  static constexpr int B_BYTES = BN * PITCHB;
+  static constexpr int MT = TH * TW / 32;
+  static constexpr int M_REP = MT / WGM;
+  static constexpr int N_REP = BN / (32 * WGN);
+  static constexpr int BREG = (BN * CPP + 255) / 256;
+  static constexpr int TAB_BYTES = (3 * TH + 4) * 4;
+  static constexpr int EPI_BYTES = 4 * 32 * 36 * 4 + WGM * 2 * BN * 4;
+  static constexpr int MAIN_BYTES = A_BYTES + 2 * B_BYTES;
+  static constexpr int SMEM = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) + TAB_BYTES + 16;
+  static_assert(WGM * WGN == 4, "4 waves");
+  static_assert((TH * TW) % 32 == 0 && MT % WGM == 0, "tile/wave split");
+  static_assert(BN % (32 * WGN) == 0, "cout/wave split");
+  static_assert(256 % CPP == 0, "chunk ownership");
+};
+
+template <typename T, typename TO, int TH, int TW, int BN, int WGM, int WGN, int PITCHB>
+__global__ void __launch_bounds__(256, 2)
+    conv3x3_igemm_kernel(const ConvArgs a) {
+  using C = ConvCfg<T, TO, TH, TW, BN, WGM, WGN, PITCHB>;
+  using M = Mma<T>;
+  constexpr int EPC = C::EPC, KC = C::KC, CPP = C::CPP, KS = C::KS, HW2 = C::HW2;
+  constexpr int M_REP = C::M_REP, N_REP = C::N_REP, BREG = C::BREG;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MAINB = (C::MAIN_BYTES > C::EPI_BYTES ? C::MAIN_BYTES : C::EPI_BYTES);
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + C::A_BYTES;
+  int* s_row1 = reinterpret_cast<int*>(smem + ((MAINB + 15) & ~15));
+  int* s_row2 = s_row1 + (TH + 2);
+  int* s_flag = s_row2 + (TH + 2);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int tile = blockIdx.x;
+  const int ct = tile % a.tiles_w;
+  const int rt = tile / a.tiles_w;
+  const int R0 = rt * TH, w0 = ct * TW;
+  const int n0 = blockIdx.y * BN;
+  const int Cin = a.C1 + a.C2;
+  const int ncc = (Cin + KC - 1) / KC;
+
+  // zero slot + row tables
+  for (int idx = tid; idx < HW2 * CPP; idx += 256) {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    st16(sA + (C::ZSLOT * HW2) * PITCHB + idx * 16, z);
+  }
+  conv_row_tables(a, TH, R0, tid, s_row1, s_row2, s_flag, false);
+  __syncthreads();
+
+  // per-lane pixel coordinates of the A rows this lane feeds
+  int pty[M_REP], ptx[M_REP], pfl[M_REP];
+#pragma unroll
+  for (int m = 0; m < M_REP; ++m) {
+    const int i = (wm * M_REP + m) * 32 + r;
+    pty[m] = i / TW;
+    ptx[m] = i - pty[m] * TW;
+    pfl[m] = s_flag[pty[m]];
+  }
+  // per-lane B rows
+  int brow[N_REP], bswz[N_REP];
+#pragma unroll
+  for (int n = 0; n < N_REP; ++n) {
+    brow[n] = (wn * N_REP + n) * 32 + r;
+    bswz[n] = lds_swz<PITCHB>(brow[n]);
+  }
+
+  f32x16 acc[M_REP][N_REP];
+#pragma unroll
+  for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+    for (int n = 0; n < N_REP; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+  const T* wp = reinterpret_cast<const T*>(a.w);
+  u32x4 breg[BREG];
+  auto load_b = [&](int cc, int tap) {
+#pragma unroll
+    for (int i = 0; i < BREG; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < BN * CPP) {
+        const int row = idx / CPP, ch = idx % CPP;
+        breg[i] = ld16(wp + ((size_t)(tap * a.w_co_pad + n0 + row)) * a.w_ci_pad + cc * KC + ch * EPC);
+      }
+    }
+  };
+  auto store_b = [&](unsigned char* dst) {
+#pragma unroll
+    for (int i = 0; i < BREG; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < BN * CPP) {
+        const int row = idx / CPP, ch = idx % CPP;
+        st16(dst + row * PITCHB + ((ch ^ lds_swz<PITCHB>(row)) << 4), breg[i]);
+      }
+    }
+  };
+
+  conv_stage_halo<T, PITCHB, true>(a, sA, s_row1, s_row2, TH, TW, w0, 0, tid);
+  load_b(0, 0);
+  store_b(sB);
+  __syncthreads();
+
+  const int nit = ncc * 9;
+  for (int it = 0; it < nit; ++it) {
+    const int cc = it / 9;
+    const int tap = it - cc * 9;
+    const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+    const bool has_next = it + 1 < nit;
+    if (has_next) {
+      const int it1 = it + 1;
+      load_b(it1 / 9, it1 % 9);
+    }
+    const unsigned char* sBc = sB + (it & 1) * C::B_BYTES;
+
+    const unsigned char* apix[M_REP];
+    int aswz[M_REP];
+#pragma unroll
+    for (int m = 0; m < M_REP; ++m) {
+      int slot = pty[m] + 1 + dh;
+      if ((dh < 0 && (pfl[m] & 1)) || (dh > 0 && (pfl[m] & 2))) slot = C::ZSLOT;
+      const int p = slot * HW2 + ptx[m] + 1 + dw;
+      apix[m] = sA + p * PITCHB;
+      aswz[m] = lds_swz<PITCHB>(p);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int fi = 2 * ks + h;
+      typename M::Frag bf[N_REP];
+#pragma unroll
+      for (int n = 0; n < N_REP; ++n) bf[n] = M::load(sBc + brow[n] * PITCHB, fi, bswz[n]);
+#pragma unroll
+      for (int m = 0; m < M_REP; ++m) {
+        typename M::Frag af = M::load(apix[m], fi, aswz[m]);
+#pragma unroll
+        for (int n = 0; n < N_REP; ++n) M::mma(af, bf[n], acc[m][n]);
+      }
+    }
+
+    if (has_next) store_b(sB + ((it + 1) & 1) * C::B_BYTES);
+    if (tap == 8 && has_next) {
+      __syncthreads();  // every wave is done reading the halo tile
+      conv_stage_halo<T, PITCHB, true>(a, sA, s_row1, s_row2, TH, TW, w0, (cc + 1) * KC, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  constexpr int EPO = 16 / (int)sizeof(TO);  // output elements per 16-byte chunk
+  constexpr int CPO = 32 / EPO;              // chunks per 32-cout row
+  float* scratch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+  float* sstat = reinterpret_cast<float*>(smem) + 4 * (32 * 36);
+  const bool do_stats = a.stats != nullptr;
+  TO* o1 = reinterpret_cast<TO*>(a.out);
+  TO* o2 = reinterpret_cast<TO*>(a.out2);
+
+#pragma unroll
+  for (int n = 0; n < N_REP; ++n) {
+    float s1 = 0.f, s2 = 0.f;
+    const int cobase = n0 + (wn * N_REP + n) * 32;
+#pragma unroll
+    for (int m = 0; m < M_REP; ++m) {
+      const int ibase = (wm * M_REP + m) * 32;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const float v = acc[m][n][reg];
+        scratch[row * 36 + r] = v;
+        if (do_stats) {
+          bool ok = true;
+          if (!a.full_tiles) {
+            const int i = ibase + row;
+            const int ty = i / TW, tx = i - ty * TW;
+            ok = (R0 + ty < a.NH) && (w0 + tx < a.W);
+          }
+          if (ok) {
+            const float q = round_through<TO>(v);
+            s1 += q;
+            s2 += q * q;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int itx = 0; itx < (32 * CPO) / 64; ++itx) {
+        const int idx = lane + itx * 64;
+        const int pix = idx / CPO, cch = idx % CPO;
+        float f[EPO];
+        const f32x4* sp = reinterpret_cast<const f32x4*>(scratch + pix * 36 + cch * EPO);
+#pragma unroll
+        for (int q = 0; q < EPO / 4; ++q) {
+          f32x4 t = sp[q];
+          f[4 * q] = t[0];
+          f[4 * q + 1] = t[1];
+          f[4 * q + 2] = t[2];
+          f[4 * q + 3] = t[3];
+        }
+        const int i = ibase + pix;
+        const int ty = i / TW, tx = i - ty * TW;
+        const int R = R0 + ty, w = w0 + tx;
+        const int co = cobase + cch * EPO;
+        if (R < a.NH && w < a.W && co < a.Cout) {
+          const size_t gp = (size_t)R * a.W + w;
+          u32x4 pk = Chunk<TO>::pack(f);
+          if (a.split_c > 0 && co >= a.split_c)
+            st16(o2 + gp * a.ldo2 + (co - a.split_c), pk);
+          else
+            st16(o1 + gp * a.ldo + co, pk);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (do_stats) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0) {
+        const int col = (wn * N_REP + n) * 32 + r;
+        sstat[(wm * 2 + 0) * BN + col] = s1;
+        sstat[(wm * 2 + 1) * BN + col] = s2;
+      }
+    }
+  }
+  if (do_stats) {
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < WGM; ++q) {
+        t1 += sstat[(q * 2 + 0) * BN + tid];
+        t2 += sstat[(q * 2 + 1) * BN + tid];
+      }
+      a.stats[((size_t)tile * 2 + 0) * a.Cout + n0 + tid] = t1;
+      a.stats[((size_t)tile * 2 + 1) * a.Cout + n0 + tid] = t2;
+    }
+  }
+}
+
+template <typename T, typename TO, int TH, int TW, int BN, int WGM, int WGN, int PITCHB>
+int launch_conv(ConvArgs a, hipStream_t st) {
+  using C = ConvCfg<T, TO, TH, TW, BN, WGM, WGN, PITCHB>;
+  auto kern = conv3x3_igemm_kernel<T, TO, TH, TW, BN, WGM, WGN, PITCHB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM) != hipSuccess)
+      return CY_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int tiles_h = cy_cdiv(a.NH, TH);
+  a.tiles_w = cy_cdiv(a.W, TW);
+  a.full_tiles = (a.NH % TH == 0) && (a.W % TW == 0);
+  dim3 grid(tiles_h * a.tiles_w, cy_cdiv(a.Cout, BN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), C::SMEM, st, a);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+struct TileChoice {
+  int th, tw, bn;
+};
+
+// Tile selection: exact column tilings where the image width allows, a masked
+// 16x16 tile otherwise.  7-MFMA-tile shapes (8x28, 16x14) exist for BN=128.
+TileChoice choose_tile(int W, int Cout) {
+  TileChoice c;
+  c.bn = Cout >= 128 ? 128 : (Cout > 32 ? 64 : 32);
+  if (W % 32 == 0) {
+    c.th = 8, c.tw = 32;
+  } else if (W % 16 == 0) {
+    c.th = 16, c.tw = 16;
+  } else if (W % 8 == 0) {
+    c.th = 32, c.tw = 8;
+  } else if (W == 28 && c.bn == 128) {
+    c.th = 8, c.tw = 28;
+  } else if (W == 14 && c.bn == 128) {
+    c.th = 16, c.tw = 14;
+  } else {
+    c.th = 16, c.tw = 16;
+  }
+  return c;
+}
+
+template <typename T>
+int dispatch_conv(const ConvArgs& a, hipStream_t st) {
+  const TileChoice c = choose_tile(a.W, a.Cout);
+  const int Cin = a.C1 + a.C2;
+  const bool small_k = Cin * (int)sizeof(T) <= 64 && c.bn <= 64;
+#define CY_CONV_CASE(TH_, TW_, BN_, WGM_, WGN_, P_) \
+  return launch_conv<T, T, TH_, TW_, BN_, WGM_, WGN_, P_>(a, st)
+  if (c.th == 8 && c.tw == 32) {
+    if (c.bn == 128) CY_CONV_CASE(8, 32, 128, 2, 2, 128);
+    if (c.bn == 64) { if (small_k) CY_CONV_CASE(8, 32, 64, 4, 1, 64); CY_CONV_CASE(8, 32, 64, 4, 1, 128); }
+    if (small_k) CY_CONV_CASE(8, 32, 32, 4, 1, 64);
+    CY_CONV_CASE(8, 32, 32, 4, 1, 128);
+  }
+  if (c.th == 16 && c.tw == 16) {
+    if (c.bn == 128) CY_CONV_CASE(16, 16, 128, 2, 2, 128);
+    if (c.bn == 64) { if (small_k) CY_CONV_CASE(16, 16, 64, 4, 1, 64); CY_CONV_CASE(16, 16, 64, 4, 1, 128); }
+    if (small_k) CY_CONV_CASE(16, 16, 32, 4, 1, 64);
+    CY_CONV_CASE(16, 16, 32, 4, 1, 128);
+  }
+  if (c.th == 32 && c.tw == 8) {
+    if (c.bn == 128) CY_CONV_CASE(32, 8, 128, 2, 2, 128);
+    if (c.bn == 64) { if (small_k) CY_CONV_CASE(32, 8, 64, 4, 1, 64); CY_CONV_CASE(32, 8, 64, 4, 1, 128); }
+    if (small_k) CY_CONV_CASE(32, 8, 32, 4, 1, 64);
+    CY_CONV_CASE(32, 8, 32, 4, 1, 128);
+  }
+  if (c.th == 8 && c.tw == 28) CY_CONV_CASE(8, 28, 128, 1, 4, 128);
+  if (c.th == 16 && c.tw == 14) CY_CONV_CASE(16, 14, 128, 1, 4, 128);
+#undef CY_CONV_CASE
+  return CY_ERR_SHAPE;
+}
+
+// ---------------------------------------------------------------------------
+// weight repacking:  w[Cout][Cin][3][3] f32  ->  wf[tap][co_pad][ci_pad] (T)
+//                                            ->  wd[tap][ci_pad2][co_pad2] (T), flipped taps
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf,
+                                    T* __restrict__ wd, int Cout, int Cin, int co_pad, int ci_pad,
+                                    int ci_pad2, int co_pad2) {
+  const long nf = 9L * co_pad * ci_pad;
+  const long nd = wd ? 9L * ci_pad2 * co_pad2 : 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nf + nd;
+       i += (long)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      const int ci = (int)(i % ci_pad);
+      const int co = (int)((i / ci_pad) % co_pad);
+      const int tap = (int)(i / ((long)ci_pad * co_pad));
+      float v = 0.f;
+      if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * 9 + tap];
+      wf[i] = from_f32<T>(v);
+    } else {
+      const long j = i - nf;
+      const int co = (int)(j % co_pad2);
+      const int ci = (int)((j / co_pad2) % ci_pad2);
+      const int tap = (int)(j / ((long)co_pad2 * ci_pad2));
+      float v = 0.f;
+      if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * 9 + (8 - tap)];
+      wd[j] = from_f32<T>(v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// First layer: Cin in 1..4, image is f32 NCHW.  HBM-bound on the output write;
+// plain VALU.  Thread = (pixel, group of 8 output channels).
+template <typename TO>
+__global__ void __launch_bounds__(256)
+    conv3x3_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                         TO* __restrict__ out, float* __restrict__ stats, int N, int Cin, int H,
+                         int W, int Cout) {
+  __shared__ float sw[9 * 4 * 64];  // [tap][ci][co], Cout <= 64
+  __shared__ float sred[2 * 256 * 8];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 9 * Cin * Cout; i += 256) {
+    const int co = i % Cout;
+    const int ci = (i / Cout) % Cin;
+    const int tap = i / (Cout * Cin);
+    sw[i] = w[((size_t)co * Cin + ci) * 9 + tap];
+  }
+  __syncthreads();
+  const int CG = Cout / 8;
+  const int ppb = 256 / CG;  // pixels per block
+  const int cg = tid % CG;
+  const long p = (long)blockIdx.x * ppb + tid / CG;
+  const long npix = (long)N * H * W;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const bool valid = p < npix;
+  if (valid) {
+    const int wq = (int)(p % W);
+    const int hq = (int)((p / W) % H);
+    const int n = (int)(p / ((long)W * H));
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* xp = x + ((size_t)n * Cin + ci) * H * W;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int hh = hq + tap / 3 - 1, ww = wq + tap % 3 - 1;
+        float xv = 0.f;
+        if (hh >= 0 && hh < H && ww >= 0 && ww < W) xv = xp[(size_t)hh * W + ww];
+        const float* wr = sw + (tap * Cin + ci) * Cout + cg * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wr[j], acc[j]);
+      }
+    }
+    TO* op = out + (size_t)p * Cout + cg * 8;
+    if constexpr (sizeof(TO) == 2) {
+      st16(op, Chunk<bf16>::pack(acc));
+    } else {
+      st16(op, Chunk<float>::pack(acc));
+      st16(reinterpret_cast<float*>(op) + 4, Chunk<float>::pack(acc + 4));
+    }
+  }
+  if (stats) {
+    // block reduction per channel: sred[which][pixel slot][8]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float q = valid ? round_through<TO>(acc[j]) : 0.f;
+      sred[(0 * 256 + tid) * 8 + j] = q;
+      sred[(1 * 256 + tid) * 8 + j] = q * q;
+    }
+    __syncthreads();
+    if (tid < 2 * Cout) {
+      const int which = tid / Cout, co = tid % Cout;
+      const int g = co / 8, j = co % 8;
+      float s = 0.f;
+      for (int q = 0; q < ppb; ++q) s += sred[(which * 256 + q * CG + g) * 8 + j];
+      stats[((size_t)blockIdx.x * 2 + which) * Cout + co] = s;
+    }
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int cy_abi_version(void) { return 1; }
+const char* cy_build_arch(void) { return "gfx950"; }
+
+int cy_conv3x3_packed_dims(int Cout, int Cin, int* co_pad, int* ci_pad) {
+  if (Cout <= 0 || Cin <= 0) return CY_ERR_ARG;
+  if (co_pad) *co_pad = cy_roundup(Cout, 128);
+  if (ci_pad) *ci_pad = cy_roundup(Cin, 64);
+  return CY_OK;
+}
+
+int cy_conv3x3_pack_weights(const float* w, void* wf, void* wd, int Cout, int Cin, int dtype,
+                            void* stream) {
+  if (!w || !wf) return CY_ERR_ARG;
+  int co_pad, ci_pad, ci_pad2, co_pad2;
+  cy_conv3x3_packed_dims(Cout, Cin, &co_pad, &ci_pad);
+  cy_conv3x3_packed_dims(Cin, Cout, &ci_pad2, &co_pad2);  // dgrad: roles swapped
+  hipStream_t st = (hipStream_t)stream;
+  const long total = 9L * co_pad * ci_pad + (wd ? 9L * ci_pad2 * co_pad2 : 0);
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, (bf16*)wf,
+                       (bf16*)wd, Cout, Cin, co_pad, ci_pad, ci_pad2, co_pad2);
+  else if (dtype == CY_F32)
+    hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, w, (float*)wf,
+                       (float*)wd, Cout, Cin, co_pad, ci_pad, ci_pad2, co_pad2);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+static int conv_check(const cy_conv_desc* d) {
+  if (!d) return CY_ERR_ARG;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C1 <= 0 || d->C2 < 0 || d->Cout <= 0)
+    return CY_ERR_SHAPE;
+  if (d->in_dtype != d->out_dtype) return CY_ERR_DTYPE;
+  if (d->in_dtype != CY_F32 && d->in_dtype != CY_BF16) return CY_ERR_DTYPE;
+  const int epc = d->in_dtype == CY_BF16 ? 8 : 4;
+  if (d->C1 % epc || d->C2 % epc || d->Cout % epc) return CY_ERR_SHAPE;
+  if (d->ld1 % epc || (d->C2 && d->ld2 % epc) || d->ldo % epc) return CY_ERR_SHAPE;
+  if (d->ld1 < d->C1 || (d->C2 && d->ld2 < d->C2)) return CY_ERR_SHAPE;
+  if (d->mode1 == CY_SRC_UP2 && ((d->H & 1) || (d->W & 1))) return CY_ERR_SHAPE;
+  if (d->mode1 < 0 || d->mode1 > 2) return CY_ERR_ARG;
+  if (d->prologue && d->C2) return CY_ERR_ARG;
+  if (d->split_c > 0 && (d->split_c % epc || d->ldo2 % epc)) return CY_ERR_SHAPE;
+  return CY_OK;
+}
+
+int cy_conv3x3_num_partials(const cy_conv_desc* d) {
+  if (conv_check(d) != CY_OK) return CY_ERR_ARG;
+  const TileChoice c = choose_tile(d->W, d->Cout);
+  return cy_cdiv((long)d->N * d->H, c.th) * cy_cdiv(d->W, c.tw);
+}
+
+int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
+                   const float* shift, const void* w_packed, void* out, void* out2, float* stats,
+                   void* stream) {
+  int rc = conv_check(d);
+  if (rc != CY_OK) return rc;
+  if (!src1 || !w_packed || !out) return CY_ERR_ARG;
+  if (d->C2 && !src2) return CY_ERR_ARG;
+  if (d->prologue && (!scale || !shift)) return CY_ERR_ARG;
+  if (d->split_c > 0 && !out2) return CY_ERR_ARG;
+  ConvArgs a;
+  a.src1 = src1, a.src2 = src2, a.scale = scale, a.shift = shift, a.w = w_packed;
+  a.out = out, a.out2 = out2, a.stats = stats;
+  a.N = d->N, a.H = d->H, a.W = d->W, a.NH = d->N * d->H;
+  a.C1 = d->C1, a.C2 = d->C2, a.Cout = d->Cout;
+  a.mode1 = d->mode1, a.prologue = d->prologue;
+  a.ld1 = d->ld1, a.ld2 = d->ld2, a.ldo = d->ldo, a.ldo2 = d->ldo2, a.split_c = d->split_c;
+  a.tiles_w = 0, a.full_tiles = 0;
+  cy_conv3x3_packed_dims(d->Cout, d->C1 + d->C2, &a.w_co_pad, &a.w_ci_pad);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->in_dtype == CY_BF16) return dispatch_conv<bf16>(a, st);
+  return dispatch_conv<float>(a, st);
+}
+
+int cy_conv3x3_first_num_partials(int N, int H, int W, int Cout) {
+  if (Cout % 8 || Cout > 64 || 256 % (Cout / 8)) return CY_ERR_SHAPE;
+  const int ppb = 256 / (Cout / 8);
+  return cy_cdiv((long)N * H * W, ppb);
+}
+
+int cy_conv3x3_first_fwd(const float* x, const float* w, void* out, float* stats, int N, int Cin,
+                         int H, int W, int Cout, int out_dtype, void* stream) {
+  if (!x || !w || !out) return CY_ERR_ARG;
+  if (Cin < 1 || Cin > 4) return CY_ERR_SHAPE;
+  const int np = cy_conv3x3_first_num_partials(N, H, W, Cout);
+  if (np < 0) return np;
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == CY_BF16)
+    hipLaunchKernelGGL(conv3x3_first_kernel<bf16>, dim3(np), dim3(256), 0, st, x, w, (bf16*)out,
+                       stats, N, Cin, H, W, Cout);
+  else if (out_dtype == CY_F32)
+    hipLaunchKernelGGL(conv3x3_first_kernel<float>, dim3(np), dim3(256), 0, st, x, w, (float*)out,
+                       stats, N, Cin, H, W, Cout);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+// In-step affine augmentation, EMA teacher update and the RAdam step.
+//   semi_seg/augment.py:297-311 + semi_seg/epochers/epocher.py:226-238  (rising BaseAffine,
+//       Mirror, GammaCorrection -- third-party, un-vendored; geometry is passed in as theta)
+//   semi_seg/hooks/mt.py:49-82                                         (EMAUpdater)
+//   contrastyou/trainer/base.py:66-75 (torch.optim.RAdam)
+#include "cy_common.h"
+
+namespace {
+
+// output pixel (oy,ox) -> input pixel (iy,ix) under theta (affine_grid/grid_sample
+// conventions, align_corners=False, nearest = round-half-to-even); returns false when
+// the source is outside the image (zero padding).
+__device__ __forceinline__ bool affine_src(const float* th, int oy, int ox, int H, int W, int* iy,
+                                           int* ix) {
+  const float xo = (2.f * ox + 1.f) / (float)W - 1.f;
+  const float yo = (2.f * oy + 1.f) / (float)H - 1.f;
+  const float xi = th[0] * xo + th[1] * yo + th[2];
+  const float yi = th[3] * xo + th[4] * yo + th[5];
+  const float px = ((xi + 1.f) * (float)W - 1.f) * 0.5f;
+  const float py = ((yi + 1.f) * (float)H - 1.f) * 0.5f;
+  const float rx = nearbyintf(px), ry = nearbyintf(py);
+  if (!(rx >= 0.f && rx <= (float)(W - 1) && ry >= 0.f && ry <= (float)(H - 1))) return false;
+  *ix = (int)rx;
+  *iy = (int)ry;
+  return true;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+    affine_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, const float* __restrict__ theta,
+                      const float* __restrict__ gamma, int N, int C, int H, int W) {
+  const long total = (long)N * H * W;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < total; p += (long)gridDim.x * 256L) {
+    const int ox = (int)(p % W);
+    const int oy = (int)((p / W) % H);
+    const int n = (int)(p / ((long)W * H));
+    int iy, ix;
+    const bool ok = affine_src(theta + n * 6, oy, ox, H, W, &iy, &ix);
+    T* op = out + p * C;
+    if (ok) {
+      const T* ip = x + ((long)(n * H + iy) * W + ix) * C;
+      if (gamma) {
+        const float g = gamma[n];
+        for (int c = 0; c < C; ++c) op[c] = from_f32<T>(powf(to_f32<T>(ip[c]), g));
+      } else {
+        for (int c = 0; c < C; ++c) op[c] = ip[c];
+      }
+    } else {
+      for (int c = 0; c < C; ++c) op[c] = from_f32<T>(0.f);
+    }
+  }
+}
+
+// adjoint in gather form: every input pixel scans the output window that can map onto it
+template <typename T>
+__global__ void __launch_bounds__(256)
+    affine_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx,
+                      const float* __restrict__ theta, int N, int C, int H, int W) {
+  const long total = (long)N * H * W;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < total; p += (long)gridDim.x * 256L) {
+    const int ix = (int)(p % W);
+    const int iy = (int)((p / W) % H);
+    const int n = (int)(p / ((long)W * H));
+    const float* th = theta + n * 6;
+    // inverse map of the pixel centre: pixel -> normalised -> theta^-1 -> output pixel
+    const float xi = (2.f * ix + 1.f) / (float)W - 1.f;
+    const float yi = (2.f * iy + 1.f) / (float)H - 1.f;
+    const float det = th[0] * th[4] - th[1] * th[3];
+    T* dp = dx + p * C;
+    int x0 = 0, x1 = -1, y0 = 0, y1 = -1;  // empty window when theta is singular
+    if (fabsf(det) > 1e-12f) {
+      const float i00 = th[4] / det, i01 = -th[1] / det, i10 = -th[3] / det, i11 = th[0] / det;
+      const float bx = xi - th[2], by = yi - th[5];
+      const float xo = i00 * bx + i01 * by, yo = i10 * bx + i11 * by;
+      const float cx = ((xo + 1.f) * (float)W - 1.f) * 0.5f;
+      const float cy = ((yo + 1.f) * (float)H - 1.f) * 0.5f;
+      // half extent (in output pixels) of the pre-image of one input pixel, plus a margin
+      const int rx = (int)ceilf(0.5f * (fabsf(i00) + fabsf(i01) * (float)W / (float)H)) + 1;
+      const int ry = (int)ceilf(0.5f * (fabsf(i10) * (float)H / (float)W + fabsf(i11))) + 1;
+      x0 = (int)floorf(cx) - rx, x1 = (int)ceilf(cx) + rx;
+      y0 = (int)floorf(cy) - ry, y1 = (int)ceilf(cy) + ry;
+      if (x0 < 0) x0 = 0;
+      if (y0 < 0) y0 = 0;
+      if (x1 > W - 1) x1 = W - 1;
+      if (y1 > H - 1) y1 = H - 1;
+    }
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      for (int oy = y0; oy <= y1; ++oy)
+        for (int ox = x0; ox <= x1; ++ox) {
+          int sy2, sx2;
+          if (affine_src(th, oy, ox, H, W, &sy2, &sx2) && sy2 == iy && sx2 == ix) {
+            const T* gp = dout + ((long)(n * H + oy) * W + ox) * C + c0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (c0 + j < C) acc[j] += to_f32<T>(gp[j]);
+          }
+        }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (c0 + j < C) dp[c0 + j] = from_f32<T>(acc[j]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    ema_kernel(float* __restrict__ teacher, const float* __restrict__ student, long n, float alpha,
+               float keep) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L)
+    teacher[i] = (alpha * teacher[i] + (1.f - alpha) * student[i]) * keep;
+}
+
+struct RAdamScalars {
+  float lr, beta1, beta2, eps, wd;
+  float bias_c1;    // 1 - beta1^t
+  float rect;       // rectification term, <0: un-rectified branch
+  float sqrt_bc2;   // sqrt(1 - beta2^t)
+};
+
+__global__ void __launch_bounds__(256)
+    radam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                 float* __restrict__ v, long n, RAdamScalars s) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+    float grad = g[i];
+    const float pv = p[i];
+    if (s.wd != 0.f) grad = fmaf(s.wd, pv, grad);
+    const float mi = m[i] + (grad - m[i]) * (1.f - s.beta1);  // lerp, as torch does
+    const float vi = s.beta2 * v[i] + (1.f - s.beta2) * grad * grad;
+    m[i] = mi;
+    v[i] = vi;
+    const float bc = mi / s.bias_c1;
+    float upd;
+    if (s.rect >= 0.f)
+      upd = bc * s.lr * s.rect * (s.sqrt_bc2 / (sqrtf(vi) + s.eps));
+    else
+      upd = bc * s.lr;
+    p[i] = pv - upd;
+  }
+}
+
+inline int grid_for(long total) {
+  long b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cy_affine_nearest_fwd(const void* x, void* out, const float* theta, const float* gamma, int N,
+                          int C, int H, int W, int dtype, void* stream) {
+  if (!x || !out || !theta || N <= 0 || C <= 0 || H <= 0 || W <= 0) return CY_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for((long)N * H * W);
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(affine_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x,
+                       (bf16*)out, theta, gamma, N, C, H, W);
+  else if (dtype == CY_F32)
+    hipLaunchKernelGGL(affine_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x,
+                       (float*)out, theta, gamma, N, C, H, W);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_affine_nearest_bwd(const void* dout, void* dx, const float* theta, int N, int C, int H,
+                          int W, int dtype, void* stream) {
+  if (!dout || !dx || !theta || N <= 0 || C <= 0 || H <= 0 || W <= 0) return CY_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for((long)N * H * W);
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(affine_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout,
+                       (bf16*)dx, theta, N, C, H, W);
+  else if (dtype == CY_F32)
+    hipLaunchKernelGGL(affine_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout,
+                       (float*)dx, theta, N, C, H, W);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_ema_update(float* teacher, const float* student, long n, float alpha, float weight_decay,
+                  void* stream) {
+  if (!teacher || !student || n <= 0) return CY_ERR_ARG;
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, teacher,
+                     student, n, alpha, 1.f - weight_decay);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_radam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, long step,
+                  void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) return CY_ERR_ARG;
+  RAdamScalars s;
+  s.lr = lr, s.beta1 = beta1, s.beta2 = beta2, s.eps = eps, s.wd = weight_decay;
+  const double b1t = pow((double)beta1, (double)step), b2t = pow((double)beta2, (double)step);
+  const double bc1 = 1.0 - b1t, bc2 = 1.0 - b2t;
+  const double rho_inf = 2.0 / (1.0 - (double)beta2) - 1.0;
+  const double rho_t = rho_inf - 2.0 * (double)step * b2t / bc2;
+  s.bias_c1 = (float)bc1;
+  s.sqrt_bc2 = (float)sqrt(bc2);
+  if (rho_t > 5.0)
+    s.rect = (float)sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf /
+                         ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+  else
+    s.rect = -1.f;
+  hipLaunchKernelGGL(radam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param,
+                     grad, exp_avg, exp_avg_sq, n, s);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,475 @@
+// BatchNorm2d (training statistics) + ReLU forward/backward around the MFMA
+// convolutions, and the backward halves of MaxPool2d(2) / nearest Upsample(x2)
+// whose forward halves live in the conv load path.
+// Reference call sites: contrastyou/arch/unet.py:22-23,25-26,40-41 (BN+ReLU),
+// :67-70 (MaxPool2d), :38 (Upsample).  All kernels are HBM-streaming: 16-byte
+// NHWC chunks per lane, per-channel coefficients from L1/L2, fixed-order
+// (deterministic) reductions through per-block partials.
+#include "cy_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ finalize
+__global__ void __launch_bounds__(256)
+    bn_finalize_kernel(const float* __restrict__ partials, int P, int C, double count,
+                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                       float* running_mean, float* running_var, float momentum, float eps,
+                       int use_batch_stats, int update_running, float* scale, float* shift,
+                       float* mean_out, float* invstd_out) {
+  __shared__ double sred[2][16][16];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C && use_batch_stats) {
+    for (int p = sl; p < P; p += 16) {
+      s1 += (double)partials[((size_t)p * 2 + 0) * C + c];
+      s2 += (double)partials[((size_t)p * 2 + 1) * C + c];
+    }
+  }
+  sred[0][sl][cl] = s1;
+  sred[1][sl][cl] = s2;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double mean, var;
+    if (use_batch_stats) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int q = 0; q < 16; ++q) {
+        t1 += sred[0][q][cl];
+        t2 += sred[1][q][cl];
+      }
+      mean = t1 / count;
+      var = t2 / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      if (update_running) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+      }
+    } else {
+      mean = running_mean[c];
+      var = running_var[c];
+    }
+    const double istd = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[c] : 1.0;
+    const double b = beta ? (double)beta[c] : 0.0;
+    scale[c] = (float)(g * istd);
+    shift[c] = (float)(b - mean * g * istd);
+    mean_out[c] = (float)mean;
+    invstd_out[c] = (float)istd;
+  }
+}
+
+// ------------------------------------------------------------------ apply
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256)
+    bn_relu_apply_kernel(const TI* __restrict__ y, const float* __restrict__ scale,
+                         const float* __restrict__ shift, TO* __restrict__ out, long npix, int C) {
+  // unit of work: 8 channels of one pixel (one 16-byte bf16 chunk / two f32 chunks)
+  const int G = C / 8;
+  const long total = npix * G;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int g = (int)(i % G);
+    const long p = i / G;
+    float f[8];
+    const TI* yp = y + p * C + g * 8;
+    if constexpr (sizeof(TI) == 2) {
+      Chunk<bf16>::unpack(ld16(yp), f);
+    } else {
+      Chunk<float>::unpack(ld16(yp), f);
+      Chunk<float>::unpack(ld16(yp + 4), f + 4);
+    }
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + g * 8);
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(scale + g * 8 + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + g * 8);
+    const f32x4 h1 = *reinterpret_cast<const f32x4*>(shift + g * 8 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[j] = fmaxf(fmaf(s0[j], f[j], h0[j]), 0.f);
+      f[4 + j] = fmaxf(fmaf(s1[j], f[4 + j], h1[j]), 0.f);
+    }
+    TO* op = out + p * C + g * 8;
+    if constexpr (sizeof(TO) == 2) {
+      st16(op, Chunk<bf16>::pack(f));
+    } else {
+      st16(op, Chunk<float>::pack(f));
+      st16(op + 4, Chunk<float>::pack(f + 4));
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* f) {
+  if constexpr (sizeof(T) == 2) {
+    Chunk<bf16>::unpack(ld16(p), f);
+  } else {
+    Chunk<float>::unpack(ld16(p), f);
+    Chunk<float>::unpack(ld16(p + 4), f + 4);
+  }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* f) {
+  if constexpr (sizeof(T) == 2) {
+    st16(p, Chunk<bf16>::pack(f));
+  } else {
+    st16(p, Chunk<float>::pack(f));
+    st16(p + 4, Chunk<float>::pack(f + 4));
+  }
+}
+
+// partial sums of dz and dz*xhat.  thread = (pixel lane, group of 8 channels)
+template <typename T>
+__global__ void __launch_bounds__(256)
+    bn_relu_bwd_reduce_kernel(const T* __restrict__ da, int ld_da, const T* __restrict__ y,
+                              const float* __restrict__ scale, const float* __restrict__ shift,
+                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                              float* __restrict__ partials, long npix, int C) {
+  extern __shared__ float sred[];  // [2][rows][C]
+  const int G = C / 8;
+  const int tid = threadIdx.x;
+  const int nb = gridDim.x;
+  const long per = (npix + nb - 1) / nb;
+  const long p0 = (long)blockIdx.x * per;
+  const long p1 = p0 + per < npix ? p0 + per : npix;
+  float a1[8], a2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
+  // channel groups may exceed the block: loop over group "pages"
+  const int gpp = G < 256 ? G : 256;  // groups per page
+  const int rows = 256 / gpp;
+  const int g_in_page = tid % gpp;
+  const int prow = tid / gpp;
+  const bool active = tid < rows * gpp;
+  for (int page = 0; page * gpp < G; ++page) {
+    const int g = page * gpp + g_in_page;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
+    if (active && g < G) {
+      float sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sc[j] = scale[g * 8 + j];
+        sh[j] = shift[g * 8 + j];
+        mu[j] = mean[g * 8 + j];
+        is[j] = invstd[g * 8 + j];
+      }
+      for (long p = p0 + prow; p < p1; p += rows) {
+        float d[8], v[8];
+        load8<T>(da + p * ld_da + g * 8, d);
+        load8<T>(y + p * C + g * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float z = fmaf(sc[j], v[j], sh[j]);
+          const float dz = z > 0.f ? d[j] : 0.f;
+          a1[j] += dz;
+          a2[j] += dz * ((v[j] - mu[j]) * is[j]);
+        }
+      }
+    }
+    __syncthreads();
+    if (active && g < G) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sred[(0 * rows + prow) * (gpp * 8) + g_in_page * 8 + j] = a1[j];
+        sred[(1 * rows + prow) * (gpp * 8) + g_in_page * 8 + j] = a2[j];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * gpp * 8; i += 256) {
+      const int which = i / (gpp * 8);
+      const int cl = i % (gpp * 8);
+      const int c = page * gpp * 8 + cl;
+      if (c < C) {
+        float s = 0.f;
+        for (int q = 0; q < rows; ++q) s += sred[(which * rows + q) * (gpp * 8) + cl];
+        partials[((size_t)blockIdx.x * 2 + which) * C + c] = s;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    bn_bwd_finalize_kernel(const float* __restrict__ partials, int P, int C, float* dgamma,
+                           float* dbeta) {
+  __shared__ double sred[2][16][16];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int p = sl; p < P; p += 16) {
+      s1 += (double)partials[((size_t)p * 2 + 0) * C + c];
+      s2 += (double)partials[((size_t)p * 2 + 1) * C + c];
+    }
+  }
+  sred[0][sl][cl] = s1;
+  sred[1][sl][cl] = s2;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int q = 0; q < 16; ++q) {
+      t1 += sred[0][q][cl];
+      t2 += sred[1][q][cl];
+    }
+    dbeta[c] = (float)t1;
+    dgamma[c] = (float)t2;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+    bn_relu_bwd_apply_kernel(const T* __restrict__ da, int ld_da, const T* __restrict__ y,
+                             const float* __restrict__ scale, const float* __restrict__ shift,
+                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                             const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                             T* __restrict__ dy, long npix, int C, float inv_count,
+                             int batch_stats) {
+  const int G = C / 8;
+  const long total = npix * G;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int g = (int)(i % G);
+    const long p = i / G;
+    float d[8], v[8], o[8];
+    load8<T>(da + p * ld_da + g * 8, d);
+    load8<T>(y + p * C + g * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = g * 8 + j;
+      const float sc = scale[c];
+      const float z = fmaf(sc, v[j], shift[c]);
+      const float dz = z > 0.f ? d[j] : 0.f;
+      if (batch_stats) {
+        const float xh = (v[j] - mean[c]) * invstd[c];
+        o[j] = sc * (dz - dbeta[c] * inv_count - xh * dgamma[c] * inv_count);
+      } else {
+        o[j] = sc * dz;
+      }
+    }
+    store8<T>(dy + p * C + g * 8, o);
+  }
+}
+
+// ------------------------------------------------------------------ pool / upsample backward
+template <typename T>
+__global__ void __launch_bounds__(256)
+    maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dpool,
+                        const T* __restrict__ add, int ld_add, T* __restrict__ dx, int N, int H,
+                        int W, int C) {
+  // (H,W) are the POOLED dims; x/dx/add are [N,2H,2W,C]
+  const int G = C / 8;
+  const long total = (long)N * H * W * G;
+  const int W2 = 2 * W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int g = (int)(i % G);
+    long p = i / G;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const int n = (int)(p / H);
+    const long base = ((long)(n * 2 * H + 2 * h) * W2 + 2 * w);
+    const long q[4] = {base, base + 1, base + W2, base + W2 + 1};
+    float xv[4][8], g8[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) load8<T>(x + q[k] * C + g * 8, xv[k]);
+    load8<T>(dpool + ((long)(n * H + h) * W + w) * C + g * 8, g8);
+    float o[4][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int best = 0;
+      float bv = xv[0][j];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        if (xv[k][j] > bv) {
+          bv = xv[k][j];
+          best = k;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k][j] = (k == best) ? g8[j] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (add) {
+        float a8[8];
+        load8<T>(add + q[k] * ld_add + g * 8, a8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[k][j] += a8[j];
+      }
+      store8<T>(dx + q[k] * C + g * 8, o[k]);
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+    upsample2_bwd_kernel(const T* __restrict__ dup, int ld_dup, T* __restrict__ dx, int N, int H,
+                         int W, int C) {
+  const int G = C / 8;
+  const long total = (long)N * H * W * G;
+  const int W2 = 2 * W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int g = (int)(i % G);
+    long p = i / G;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const int n = (int)(p / H);
+    const long base = ((long)(n * 2 * H + 2 * h) * W2 + 2 * w);
+    float a[8], b[8], c[8], d[8];
+    load8<T>(dup + base * ld_dup + g * 8, a);
+    load8<T>(dup + (base + 1) * ld_dup + g * 8, b);
+    load8<T>(dup + (base + W2) * ld_dup + g * 8, c);
+    load8<T>(dup + (base + W2 + 1) * ld_dup + g * 8, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (a[j] + b[j]) + (c[j] + d[j]);
+    store8<T>(dx + ((long)(n * H + h) * W + w) * C + g * 8, a);
+  }
+}
+
+inline int stream_grid(long total_threads) {
+  long b = (total_threads + 255) / 256;
+  if (b > 2048 * 4) b = 2048 * 4;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cy_bn_finalize(const float* partials, int num_partials, int C, double count,
+                   const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float momentum, float eps, int use_batch_stats,
+                   int update_running, float* scale, float* shift, float* mean, float* invstd,
+                   void* stream) {
+  if (C <= 0 || !scale || !shift || !mean || !invstd) return CY_ERR_ARG;
+  if (use_batch_stats && (!partials || num_partials <= 0 || count <= 0)) return CY_ERR_ARG;
+  if ((!use_batch_stats || update_running) && (!running_mean || !running_var)) return CY_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cy_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream,
+                     partials, num_partials, C, count, gamma, beta, running_mean, running_var,
+                     momentum, eps, use_batch_stats, update_running, scale, shift, mean, invstd);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_bn_relu_apply(const void* y, const float* scale, const float* shift, void* out, long npix,
+                     int C, int y_dtype, int out_dtype, void* stream) {
+  if (!y || !scale || !shift || !out || npix <= 0) return CY_ERR_ARG;
+  if (C % 8) return CY_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = stream_grid(npix * (C / 8));
+  if (y_dtype == CY_BF16 && out_dtype == CY_BF16)
+    hipLaunchKernelGGL((bn_relu_apply_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, st,
+                       (const bf16*)y, scale, shift, (bf16*)out, npix, C);
+  else if (y_dtype == CY_F32 && out_dtype == CY_F32)
+    hipLaunchKernelGGL((bn_relu_apply_kernel<float, float>), dim3(grid), dim3(256), 0, st,
+                       (const float*)y, scale, shift, (float*)out, npix, C);
+  else if (y_dtype == CY_BF16 && out_dtype == CY_F32)
+    hipLaunchKernelGGL((bn_relu_apply_kernel<bf16, float>), dim3(grid), dim3(256), 0, st,
+                       (const bf16*)y, scale, shift, (float*)out, npix, C);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_bn_bwd_num_partials(long npix, int C) {
+  (void)C;
+  long b = (npix + 127) / 128;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int cy_bn_relu_bwd_reduce(const void* da, int ld_da, const void* y, const float* scale,
+                          const float* shift, const float* mean, const float* invstd,
+                          float* partials, long npix, int C, int dtype, void* stream) {
+  if (!da || !y || !scale || !shift || !mean || !invstd || !partials) return CY_ERR_ARG;
+  if (C % 8 || ld_da % 8 || ld_da < C) return CY_ERR_SHAPE;
+  const int G = C / 8;
+  const int gpp = G < 256 ? G : 256;
+  const int rows = 256 / gpp;
+  const size_t smem = (size_t)2 * rows * gpp * 8 * sizeof(float);
+  const int grid = cy_bn_bwd_num_partials(npix, C);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), smem, st,
+                       (const bf16*)da, ld_da, (const bf16*)y, scale, shift, mean, invstd,
+                       partials, npix, C);
+  else if (dtype == CY_F32)
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<float>, dim3(grid), dim3(256), smem, st,
+                       (const float*)da, ld_da, (const float*)y, scale, shift, mean, invstd,
+                       partials, npix, C);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_bn_bwd_finalize(const float* partials, int num_partials, int C, float* dgamma,
+                       float* dbeta, void* stream) {
+  if (!partials || !dgamma || !dbeta || num_partials <= 0 || C <= 0) return CY_ERR_ARG;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cy_cdiv(C, 16)), dim3(256), 0,
+                     (hipStream_t)stream, partials, num_partials, C, dgamma, dbeta);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_bn_relu_bwd_apply(const void* da, int ld_da, const void* y, const float* scale,
+                         const float* shift, const float* mean, const float* invstd,
+                         const float* dgamma, const float* dbeta, void* dy, long npix, int C,
+                         double count, int batch_stats, int dtype, void* stream) {
+  if (!da || !y || !scale || !shift || !dy) return CY_ERR_ARG;
+  if (batch_stats && (!mean || !invstd || !dgamma || !dbeta || count <= 0)) return CY_ERR_ARG;
+  if (C % 8 || ld_da % 8 || ld_da < C) return CY_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = stream_grid(npix * (C / 8));
+  const float inv_count = batch_stats ? (float)(1.0 / count) : 0.f;
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st,
+                       (const bf16*)da, ld_da, (const bf16*)y, scale, shift, mean, invstd, dgamma,
+                       dbeta, (bf16*)dy, npix, C, inv_count, batch_stats);
+  else if (dtype == CY_F32)
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st,
+                       (const float*)da, ld_da, (const float*)y, scale, shift, mean, invstd,
+                       dgamma, dbeta, (float*)dy, npix, C, inv_count, batch_stats);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_maxpool2_bwd(const void* x, const void* dpool, const void* add, int ld_add, void* dx, int N,
+                    int H, int W, int C, int dtype, void* stream) {
+  if (!x || !dpool || !dx || N <= 0 || H <= 0 || W <= 0) return CY_ERR_ARG;
+  if (C % 8 || (add && (ld_add % 8 || ld_add < C))) return CY_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = stream_grid((long)N * H * W * (C / 8));
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x,
+                       (const bf16*)dpool, (const bf16*)add, ld_add, (bf16*)dx, N, H, W, C);
+  else if (dtype == CY_F32)
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x,
+                       (const float*)dpool, (const float*)add, ld_add, (float*)dx, N, H, W, C);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_upsample2_bwd(const void* dup, int ld_dup, void* dx, int N, int H, int W, int C, int dtype,
+                     void* stream) {
+  if (!dup || !dx || N <= 0 || H <= 0 || W <= 0) return CY_ERR_ARG;
+  if (C % 8 || ld_dup % 8 || ld_dup < C) return CY_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = stream_grid((long)N * H * W * (C / 8));
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(upsample2_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dup,
+                       ld_dup, (bf16*)dx, N, H, W, C);
+  else if (dtype == CY_F32)
+    hipLaunchKernelGGL(upsample2_bwd_kernel<float>, dim3(grid), dim3(256), 0, st,
+                       (const float*)dup, ld_dup, (float*)dx, N, H, W, C);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+}  // extern "C"

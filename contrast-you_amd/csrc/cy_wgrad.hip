@@ -1,0 +1,461 @@
+// Weight gradient of the 3x3 convolution (autograd of nn.Conv2d at
+// contrastyou/arch/unet.py:21,24,39) on the gfx950 matrix cores.
+//
+//   dw[co][ci][tap] = sum_p dy[p][co] * in[p + tap][ci]
+//
+// GEMM view per tap: D[co][ci] += A[co][k] * B[k][ci] with k = pixel.  Both
+// operands are stored pixel-major (NHWC), i.e. with k along LDS rows, so the
+// bf16 path feeds the MFMA through ds_read_b64_tr_b16 (4 rows x 16 columns
+// delivered column-major); the f32 path uses the 32x32x2 f32 MFMA whose
+// operands are one element per lane and needs no transpose.
+//
+// Work split: a workgroup owns a (32*WCO) x (32*WCI) block of (co,ci) for all
+// nine taps and walks a strided subset of the spatial tiles (split-K over
+// pixels, `S` splits); inside the workgroup WK waves split the pixels of a tile.
+// Each split writes its f32 slab ws[s][tap][co][ci]; wgrad_reduce_kernel adds
+// the slabs in split order (bitwise reproducible) into the reference layout
+// dw[Cout][Cin][3][3].
+//
+// The input tile is staged by the same halo stager as the forward kernel, so
+// pool / upsample / concat / BN+ReLU-prologue addressing is identical.
+#include "cy_conv_tile.h"
+
+namespace {
+
+struct WgradArgs {
+  ConvArgs c;      // sources, geometry (out/out2/w/stats unused)
+  const void* dy;  // [N,H,W,Cout], pitch ldy
+  float* ws;       // [S][9][co_pad][ci_pad]
+  int ldy;
+  int TH, TW;  // spatial tile (TH divides H)
+  int tiles_h, tiles_w;
+  int S;
+  int co_pad, ci_pad;
+};
+
+template <typename T> struct WFrag;
+
+// bf16: two transposed reads give k = 8h + {0..3} and 8h + {4..7} for column (lane&31)
+template <> struct WFrag<bf16> {
+  __device__ __forceinline__ static Mma<bf16>::Frag load(const unsigned char* row_lo,
+                                                         const unsigned char* row_hi) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(row_lo));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(row_hi));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    Mma<bf16>::Frag f;
+    f.v = __builtin_bit_cast(bf16x8, v);
+    return f;
+  }
+};
+
+template <typename T, int WCO, int WCI, int WK>
+struct WgCfg {
+  static constexpr int BCO = 32 * WCO, BCI = 32 * WCI;
+  static constexpr int PA = BCO * (int)sizeof(T);  // dy tile pitch (bytes)
+  static constexpr int PB = BCI * (int)sizeof(T);  // halo pitch
+  static constexpr int MAXPIX = 256;               // TH*TW padded to 16 <= 256
+  static constexpr int MAXHALO = 352;              // (TH+2)*(TW+2) upper bound used for sizing
+  static constexpr int A_BYTES = MAXPIX * PA;
+  static constexpr int B_BYTES = MAXHALO * PB;
+  static constexpr int RED_BYTES = WK > 1 ? WCO * WCI * WK * 32 * 32 * 4 : 0;
+  static constexpr int MAIN = A_BYTES + B_BYTES;
+  static constexpr int TAB = 3 * 40 * 4;
+  static constexpr int SMEM = (MAIN > RED_BYTES ? MAIN : RED_BYTES) + TAB + 16;
+  static_assert(WCO * WCI * WK == 4, "4 waves");
+  static_assert(PB == 64 || PB == 128, "halo pitch");
+};
+
+template <typename T, int WCO, int WCI, int WK>
+__global__ void __launch_bounds__(256, 1)
+    wgrad_kernel(const WgradArgs g) {
+  using C = WgCfg<T, WCO, WCI, WK>;
+  constexpr int PA = C::PA, PB = C::PB;
+  constexpr int EPC = ElemTr<T>::EPC;
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  const ConvArgs& a = g.c;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sDy = smem;
+  unsigned char* sIn = smem + C::A_BYTES;
+  constexpr int MAINB = (C::MAIN > C::RED_BYTES ? C::MAIN : C::RED_BYTES);
+  int* s_row1 = reinterpret_cast<int*>(smem + ((MAINB + 15) & ~15));
+  int* s_row2 = s_row1 + 40;
+  int* s_flag = s_row2 + 40;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wave % WK;
+  const int wci = (wave / WK) % WCI;
+  const int wco = wave / (WK * WCI);
+  const int r = lane & 31, h = lane >> 5;
+
+  const int TH = g.TH, TW = g.TW, HW2 = TW + 2;
+  const int npix = TH * TW;
+  const int nsteps = (npix + 15) / 16;
+  const int npix_pad = nsteps * 16;
+  const int ci_tiles = g.ci_pad / C::BCI;
+  const int co_t = blockIdx.x / ci_tiles, ci_t = blockIdx.x % ci_tiles;
+  const int co0 = co_t * C::BCO, ci0 = ci_t * C::BCI;
+  const int split = blockIdx.y;
+  const int ntiles = g.tiles_h * g.tiles_w;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  const T* dyp = reinterpret_cast<const T*>(g.dy);
+
+  for (int tile = split; tile < ntiles; tile += g.S) {
+    const int ct = tile % g.tiles_w, rt = tile / g.tiles_w;
+    const int R0 = rt * TH, w0 = ct * TW;
+    __syncthreads();  // previous tile fully consumed
+    conv_row_tables(a, TH, R0, tid, s_row1, s_row2, s_flag, true);
+    __syncthreads();
+    conv_stage_halo<T, PB, false>(a, sIn, s_row1, s_row2, TH, TW, w0, ci0, tid);
+    // dy tile: rows = pixels k (ty*TW+tx), BCO channels
+    {
+      constexpr int CPA = PA / 16;
+      const int ch = tid % CPA;
+      const int co = co0 + ch * EPC;
+      for (int idx = tid; idx < npix_pad * CPA; idx += 256) {
+        const int k = idx / CPA;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (k < npix && co < a.Cout) {
+          const int ty = k / TW, tx = k - ty * TW;
+          const int R = R0 + ty, w = w0 + tx;
+          if (R < a.NH && w < a.W) v = ld16(dyp + ((size_t)R * a.W + w) * g.ldy + co);
+        }
+        st16(sDy + k * PA + ch * 16, v);
+      }
+    }
+    __syncthreads();
+
+    for (int step = wk; step < nsteps; step += WK) {
+      const int kb = step * 16;
+      if constexpr (IS_BF16) {
+        // this lane supplies row q of the 4x16 blocks of its 16-lane group
+        const int q = (lane & 15) >> 2, p = lane & 3, gsel = (lane >> 4) & 1;
+        const int k1 = kb + 8 * h + q, k2 = k1 + 4;
+        const unsigned char* a_lo = sDy + k1 * PA + (wco * 32 + 16 * gsel + 4 * p) * 2;
+        const unsigned char* a_hi = a_lo + 4 * PA;
+        const Mma<bf16>::Frag af = WFrag<bf16>::load(a_lo, a_hi);
+        int kk1 = k1 < npix ? k1 : 0, kk2 = k2 < npix ? k2 : 0;
+        const int ty1 = kk1 / TW, tx1 = kk1 - ty1 * TW;
+        const int ty2 = kk2 / TW, tx2 = kk2 - ty2 * TW;
+        const int colb = (wci * 32 + 16 * gsel + 4 * p) * 2;
+        const unsigned char* b1 = sIn + ((ty1 + 1) * HW2 + tx1 + 1) * PB + colb;
+        const unsigned char* b2 = sIn + ((ty2 + 1) * HW2 + tx2 + 1) * PB + colb;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int off = ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) * PB;
+          const Mma<bf16>::Frag bf = WFrag<bf16>::load(b1 + off, b2 + off);
+          Mma<bf16>::mma(af, bf, acc[tap]);
+        }
+      } else {
+        // f32: element j of lane (r,h) is pixel kb + 8h + j
+        Mma<float>::Frag af;
+        int hidx[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = kb + 8 * h + j;
+          const float v = *reinterpret_cast<const float*>(sDy + k * PA + (wco * 32 + r) * 4);
+          if (j < 4) af.lo[j] = v; else af.hi[j - 4] = v;
+          const int kk = k < npix ? k : 0;
+          const int ty = kk / TW, tx = kk - ty * TW;
+          hidx[j] = (ty + 1) * HW2 + tx + 1;
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int off = (tap / 3 - 1) * HW2 + (tap % 3 - 1);
+          Mma<float>::Frag bf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float v =
+                *reinterpret_cast<const float*>(sIn + (hidx[j] + off) * PB + (wci * 32 + r) * 4);
+            if (j < 4) bf.lo[j] = v; else bf.hi[j - 4] = v;
+          }
+          Mma<float>::mma(af, bf, acc[tap]);
+        }
+      }
+    }
+  }
+
+  // ---- write the split's slab ----
+  float* slab = g.ws + (size_t)split * 9 * g.co_pad * g.ci_pad;
+  if constexpr (WK == 1) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        slab[((size_t)tap * g.co_pad + co0 + wco * 32 + row) * g.ci_pad + ci0 + wci * 32 + r] =
+            acc[tap][reg];
+      }
+  } else {
+    float* red = reinterpret_cast<float*>(smem);
+    const int grp = wco * WCI + wci;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      __syncthreads();
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        red[((grp * WK + wk) * 32 + row) * 32 + r] = acc[tap][reg];
+      }
+      __syncthreads();
+      // the WK waves of a group share the 1024 outputs
+      for (int e = wk * 64 + lane; e < 1024; e += WK * 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < WK; ++q) s += red[((grp * WK + q) * 32) * 32 + e];
+        const int row = e >> 5, col = e & 31;
+        slab[((size_t)tap * g.co_pad + co0 + wco * 32 + row) * g.ci_pad + ci0 + wci * 32 + col] = s;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int Cout,
+                        int Cin, int co_pad, int ci_pad) {
+  const long total = 9L * Cout * Cin;
+  const size_t slab = (size_t)9 * co_pad * ci_pad;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int ci = (int)(i % Cin);
+    const int co = (int)((i / Cin) % Cout);
+    const int tap = (int)(i / ((long)Cin * Cout));
+    const size_t off = ((size_t)tap * co_pad + co) * ci_pad + ci;
+    float s = 0.f;
+    for (int q = 0; q < S; ++q) s += ws[q * slab + off];
+    dw[((size_t)co * Cin + ci) * 9 + tap] = s;
+  }
+}
+
+struct WgPlan {
+  int wco, wci, wk;
+  int TH, TW, tiles_h, tiles_w, S, co_pad, ci_pad;
+};
+
+WgPlan plan_wgrad(const cy_conv_desc* d) {
+  WgPlan p;
+  const int Cin = d->C1 + d->C2;
+  if (d->in_dtype == CY_F32) {
+    p.wco = 1, p.wci = 1, p.wk = 4;
+  } else if (d->Cout > 32 && Cin > 32) {
+    p.wco = 2, p.wci = 2, p.wk = 1;
+  } else if (d->Cout > 32) {
+    p.wco = 2, p.wci = 1, p.wk = 2;
+  } else if (Cin > 32) {
+    p.wco = 1, p.wci = 2, p.wk = 2;
+  } else {
+    p.wco = 1, p.wci = 1, p.wk = 4;
+  }
+  p.co_pad = cy_roundup(d->Cout, 32 * p.wco);
+  p.ci_pad = cy_roundup(Cin, 32 * p.wci);
+  // spatial tile: TW columns, TH rows with TH | H and TH*TW <= 256, (TH+2)*(TW+2) <= 352
+  p.TW = d->W <= 32 ? d->W : (d->W % 32 == 0 ? 32 : 16);
+  int best = 1;
+  for (int th = 1; th <= d->H && th * p.TW <= 256; ++th)
+    if (d->H % th == 0 && (th + 2) * (p.TW + 2) <= 352 && th + 2 <= 40) best = th;
+  p.TH = best;
+  p.tiles_h = (d->N * d->H) / p.TH;
+  p.tiles_w = cy_cdiv(d->W, p.TW);
+  const int out_tiles = (p.co_pad / (32 * p.wco)) * (p.ci_pad / (32 * p.wci));
+  const int ntiles = p.tiles_h * p.tiles_w;
+  int S = 1024 / out_tiles;
+  if (S < 1) S = 1;
+  if (S > ntiles) S = ntiles;
+  p.S = S;
+  return p;
+}
+
+template <typename T, int WCO, int WCI, int WK>
+int launch_wgrad(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
+  using C = WgCfg<T, WCO, WCI, WK>;
+  auto kern = wgrad_kernel<T, WCO, WCI, WK>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM) != hipSuccess)
+      return CY_ERR_LAUNCH;
+    attr_done = true;
+  }
+  dim3 grid((p.co_pad / C::BCO) * (p.ci_pad / C::BCI), p.S);
+  hipLaunchKernelGGL(kern, grid, dim3(256), C::SMEM, st, g);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+// ---------------------------------------------------------------------------
+// first layer weight gradient (Cin 1..4, f32 NCHW image): plain VALU reduction
+template <typename T>
+__global__ void __launch_bounds__(256)
+    first_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
+                       float* __restrict__ ws, int N, int Cin, int H, int W, int Cout) {
+  // thread = (pixel lane, group of 8 couts); accumulates 9 taps x 8 couts for one ci at a time
+  __shared__ float sred[256 * 8];
+  const int CG = Cout / 8;
+  const int rows = 256 / CG;
+  const int tid = threadIdx.x;
+  const int cg = tid % CG, prow = tid / CG;
+  const long npix = (long)N * H * W;
+  const long per = (npix + gridDim.x - 1) / gridDim.x;
+  const long p0 = (long)blockIdx.x * per;
+  const long p1 = p0 + per < npix ? p0 + per : npix;
+  for (int ci = 0; ci < Cin; ++ci) {
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    for (long p = p0 + prow; p < p1; p += rows) {
+      const int wq = (int)(p % W);
+      const int hq = (int)((p / W) % H);
+      const int n = (int)(p / ((long)W * H));
+      float d[8];
+      if constexpr (sizeof(T) == 2) {
+        Chunk<bf16>::unpack(ld16(dy + p * Cout + cg * 8), d);
+      } else {
+        Chunk<float>::unpack(ld16(dy + p * Cout + cg * 8), d);
+        Chunk<float>::unpack(ld16(dy + p * Cout + cg * 8 + 4), d + 4);
+      }
+      const float* xp = x + ((size_t)n * Cin + ci) * H * W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int hh = hq + t / 3 - 1, ww = wq + t % 3 - 1;
+        float xv = 0.f;
+        if (hh >= 0 && hh < H && ww >= 0 && ww < W) xv = xp[(size_t)hh * W + ww];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = fmaf(xv, d[j], acc[t][j]);
+      }
+    }
+    // block reduction over prow, one tap at a time
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sred[tid * 8 + j] = acc[t][j];
+      __syncthreads();
+      if (tid < Cout) {
+        const int g = tid / 8, j = tid % 8;
+        float s = 0.f;
+        for (int q = 0; q < rows; ++q) s += sred[(q * CG + g) * 8 + j];
+        // ws[block][co][ci][tap]
+        ws[(((size_t)blockIdx.x * Cout + tid) * Cin + ci) * 9 + t] = s;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    first_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nblk,
+                              int total) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < total) {
+    float s = 0.f;
+    for (int q = 0; q < nblk; ++q) s += ws[(size_t)q * total + i];
+    dw[i] = s;
+  }
+}
+
+int first_wgrad_blocks(long npix) {
+  long b = (npix + 511) / 512;
+  if (b > 512) b = 512;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cy_conv3x3_wgrad_ws_bytes(const cy_conv_desc* d) {
+  if (!d || d->Cout <= 0 || d->C1 <= 0 || d->H <= 0 || d->W <= 0 || d->N <= 0) return 0;
+  const WgPlan p = plan_wgrad(d);
+  return (size_t)p.S * 9 * p.co_pad * p.ci_pad * sizeof(float);
+}
+
+int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
+                     const float* shift, const void* dy, float* dw, void* ws, size_t ws_bytes,
+                     void* stream) {
+  if (!d || !src1 || !dy || !dw || !ws) return CY_ERR_ARG;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C1 <= 0 || d->C2 < 0 || d->Cout <= 0)
+    return CY_ERR_SHAPE;
+  if (d->in_dtype != d->out_dtype) return CY_ERR_DTYPE;
+  if (d->in_dtype != CY_F32 && d->in_dtype != CY_BF16) return CY_ERR_DTYPE;
+  const int epc = d->in_dtype == CY_BF16 ? 8 : 4;
+  if (d->C1 % epc || d->C2 % epc || d->Cout % epc || d->ld1 % epc || d->ldo % epc)
+    return CY_ERR_SHAPE;
+  if (d->C2 && (!src2 || d->ld2 % epc)) return CY_ERR_ARG;
+  if (d->prologue && (d->C2 || !scale || !shift)) return CY_ERR_ARG;
+  if (d->mode1 == CY_SRC_UP2 && ((d->H & 1) || (d->W & 1))) return CY_ERR_SHAPE;
+  const WgPlan p = plan_wgrad(d);
+  if (ws_bytes < (size_t)p.S * 9 * p.co_pad * p.ci_pad * sizeof(float)) return CY_ERR_WORKSPACE;
+  WgradArgs g;
+  ConvArgs& a = g.c;
+  a.src1 = src1, a.src2 = src2, a.scale = scale, a.shift = shift, a.w = nullptr;
+  a.out = nullptr, a.out2 = nullptr, a.stats = nullptr;
+  a.N = d->N, a.H = d->H, a.W = d->W, a.NH = d->N * d->H;
+  a.C1 = d->C1, a.C2 = d->C2, a.Cout = d->Cout;
+  a.mode1 = d->mode1, a.prologue = d->prologue;
+  a.ld1 = d->ld1, a.ld2 = d->ld2, a.ldo = 0, a.ldo2 = 0, a.split_c = 0;
+  a.tiles_w = p.tiles_w, a.w_co_pad = 0, a.w_ci_pad = 0, a.full_tiles = 0;
+  g.dy = dy, g.ws = (float*)ws, g.ldy = d->ldo;
+  g.TH = p.TH, g.TW = p.TW, g.tiles_h = p.tiles_h, g.tiles_w = p.tiles_w, g.S = p.S;
+  g.co_pad = p.co_pad, g.ci_pad = p.ci_pad;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (d->in_dtype == CY_F32) {
+    rc = launch_wgrad<float, 1, 1, 4>(g, p, st);
+  } else if (p.wco == 2 && p.wci == 2) {
+    rc = launch_wgrad<bf16, 2, 2, 1>(g, p, st);
+  } else if (p.wco == 2) {
+    rc = launch_wgrad<bf16, 2, 1, 2>(g, p, st);
+  } else if (p.wci == 2) {
+    rc = launch_wgrad<bf16, 1, 2, 2>(g, p, st);
+  } else {
+    rc = launch_wgrad<bf16, 1, 1, 4>(g, p, st);
+  }
+  if (rc != CY_OK) return rc;
+  const int Cin = d->C1 + d->C2;
+  const long total = 9L * d->Cout * Cin;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw,
+                     p.S, d->Cout, Cin, p.co_pad, p.ci_pad);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+size_t cy_conv3x3_first_wgrad_ws_bytes(int N, int Cin, int H, int W, int Cout) {
+  return (size_t)first_wgrad_blocks((long)N * H * W) * Cout * Cin * 9 * sizeof(float);
+}
+
+int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int N, int Cin, int H, int W,
+                           int Cout, int dy_dtype, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !dy || !dw || !ws) return CY_ERR_ARG;
+  if (Cin < 1 || Cin > 4 || Cout % 8 || Cout > 64 || 256 % (Cout / 8)) return CY_ERR_SHAPE;
+  if (ws_bytes < cy_conv3x3_first_wgrad_ws_bytes(N, Cin, H, W, Cout)) return CY_ERR_WORKSPACE;
+  const int nblk = first_wgrad_blocks((long)N * H * W);
+  hipStream_t st = (hipStream_t)stream;
+  if (dy_dtype == CY_BF16)
+    hipLaunchKernelGGL(first_wgrad_kernel<bf16>, dim3(nblk), dim3(256), 0, st, x, (const bf16*)dy,
+                       (float*)ws, N, Cin, H, W, Cout);
+  else if (dy_dtype == CY_F32)
+    hipLaunchKernelGGL(first_wgrad_kernel<float>, dim3(nblk), dim3(256), 0, st, x,
+                       (const float*)dy, (float*)ws, N, Cin, H, W, Cout);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  const int total = Cout * Cin * 9;
+  hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(cy_cdiv(total, 256)), dim3(256), 0, st,
+                     (const float*)ws, dw, nblk, total);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+"""ctypes binding of libcontrastyou_hip.so (C ABI declared in include/contrastyou_hip.h).
+
+The library is the only compute backend of this package: there is no CPU or eager
+fallback.  If it is missing, or a call is made without a GPU tensor, the error is loud.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
+from pathlib import Path
+
+CY_F32, CY_BF16 = 0, 1
+CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2 = 0, 1, 2
+ABI_VERSION = 1
+
+_ERRORS = {-1: "CY_ERR_ARG (bad/NULL argument)", -2: "CY_ERR_SHAPE (unsupported shape)",
+           -3: "CY_ERR_DTYPE (unsupported dtype)", -4: "CY_ERR_LAUNCH (HIP launch failed)",
+           -5: "CY_ERR_WORKSPACE (workspace too small)"}
+
+LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libcontrastyou_hip.so"
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """mirror of cy_conv_desc"""
+    _fields_ = [(n, c_int32) for n in (
+        "N", "H", "W", "C1", "C2", "Cout", "mode1", "prologue", "in_dtype", "out_dtype",
+        "ld1", "ld2", "ldo", "split_c", "ldo2")]
+
+
+_P = c_void_p
+_PCD = POINTER(ConvDesc)
+
+# name -> (restype, argtypes).  restype c_int functions are status-checked.
+_SIGS = {
+    "cy_abi_version": (c_int, []),
+    "cy_build_arch": (c_char_p, []),
+    "cy_conv3x3_packed_dims": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "cy_conv3x3_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "cy_conv3x3_num_partials": (c_int, [_PCD]),
+    "cy_conv3x3_fwd": (c_int, [_PCD, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cy_conv3x3_wgrad_ws_bytes": (c_size_t, [_PCD]),
+    "cy_conv3x3_wgrad": (c_int, [_PCD, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "cy_conv3x3_first_num_partials": (c_int, [c_int, c_int, c_int, c_int]),
+    "cy_conv3x3_first_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cy_conv3x3_first_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "cy_conv3x3_first_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                       c_size_t, _P]),
+    "cy_bn_finalize": (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, c_int,
+                               c_int, _P, _P, _P, _P, _P]),
+    "cy_bn_relu_apply": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, c_int, _P]),
+    "cy_bn_bwd_num_partials": (c_int, [c_long, c_int]),
+    "cy_bn_relu_bwd_reduce": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_long, c_int, c_int, _P]),
+    "cy_bn_bwd_finalize": (c_int, [_P, c_int, c_int, _P, _P, _P]),
+    "cy_bn_relu_bwd_apply": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_long, c_int,
+                                     c_double, c_int, c_int, _P]),
+    "cy_maxpool2_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cy_upsample2_bwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cy_head1x1_fwd": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, c_int, _P]),
+    "cy_head1x1_bwd_ws_bytes": (c_size_t, [c_long, c_int, c_int]),
+    "cy_head1x1_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_int, c_int, c_int, _P, c_size_t,
+                               _P]),
+    "cy_softmax_kl_ws_bytes": (c_size_t, [c_long]),
+    "cy_softmax_kl_fwd": (c_int, [_P, _P, _P, c_long, c_int, c_float, _P, c_size_t, _P]),
+    "cy_softmax_kl_bwd": (c_int, [_P, _P, _P, _P, c_long, c_int, c_float, _P]),
+    "cy_avgpool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cy_avgpool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cy_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "cy_linear_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "cy_l2norm_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P]),
+    "cy_l2norm_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "cy_supcon_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "cy_supcon_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "cy_supcon_matrices": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "cy_sgemm": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
+    "cy_affine_nearest_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cy_affine_nearest_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cy_dice_counts": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "cy_ema_update": (c_int, [_P, _P, c_long, c_float, c_float, _P]),
+    "cy_softmax_mse_ws_bytes": (c_size_t, [c_long]),
+    "cy_softmax_mse_fwd": (c_int, [_P, _P, _P, c_long, c_int, _P, c_size_t, _P]),
+    "cy_softmax_mse_bwd": (c_int, [_P, _P, _P, _P, _P, c_long, c_int, _P]),
+    "cy_radam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_float,
+                              c_long, _P]),
+}
+
+# functions whose int return is a count / size, not a status
+_COUNT_FUNCS = {"cy_abi_version", "cy_conv3x3_num_partials", "cy_conv3x3_first_num_partials",
+                "cy_bn_bwd_num_partials"}
+
+_lib = None
+
+
+def exported_names():
+    return sorted(_SIGS)
+
+
+def load():
+    """Load (once) and return the ctypes library with typed signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise HipExtensionMissing(
+            f"{LIB_PATH} not found: build it with `python contrast-you_amd/build.py` "
+            "(there is no CPU fallback for the hot path)")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.cy_abi_version()
+    if ver != ABI_VERSION:
+        raise HipExtensionMissing(f"ABI mismatch: library {ver}, binding {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, name: str) -> int:
+    if rc < 0:
+        raise HipKernelError(f"{name} failed: {_ERRORS.get(rc, rc)}")
+    return rc
+
+
+def call(name: str, *args) -> int:
+    """Call a status-returning entry point and raise on error."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if name in _COUNT_FUNCS or _SIGS[name][0] is c_int:
+        return check(rc, name)
+    return rc

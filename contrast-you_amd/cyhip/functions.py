@@ -1,0 +1,338 @@
+"""torch.autograd.Function wrappers: the seam between the reference's Python object
+protocol (nn.Module blocks, forward hooks, loss objects) and the HIP kernels.
+
+Granularity follows the reference's named blocks (contrastyou/arch/unet.py:16-46): one
+Function per _ConvBlock / _UpConv so that `get_module(name)` forward hooks still observe a
+block-output tensor with autograd history, while inside a block nothing but raw conv
+outputs is materialised (BN+ReLU of conv 1 is applied in conv 2's load path; max-pool,
+nearest-upsample and channel concat are addressing modes of the consuming conv).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import ops
+
+# bumped by anything that rewrites parameter memory without going through torch
+# (fused optimizer, flat-buffer EMA): invalidates the packed-weight cache.
+_weights_epoch = 0
+_pack_cache = {}
+
+
+def bump_weights_epoch() -> None:
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def packed_weights(w: Tensor, dtype: torch.dtype):
+    """(forward image, dgrad image) of a 3x3 weight, cached until the weight changes."""
+    key = (id(w), dtype)
+    tag = (w._version, _weights_epoch, w.data_ptr())
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1], hit[2]
+    wf, wd = ops.pack_weights(w, dtype, want_dgrad=True)
+    _pack_cache[key] = (tag, wf, wd)
+    return wf, wd
+
+
+def compute_dtype_for(x: Tensor, requested: Optional[torch.dtype]) -> torch.dtype:
+    """bf16 under autocast (AMPScaler.autocast, contrastyou/amp/amp.py:44), else the requested
+    dtype, else f32 (verification mode)."""
+    if requested is not None:
+        return requested
+    if torch.is_autocast_enabled():
+        return torch.bfloat16
+    if x.dtype == torch.bfloat16:
+        return torch.bfloat16
+    return torch.float32
+
+
+class ChainCfg:
+    """Static description of one [conv3x3 -> BN -> ReLU] x {1,2} block."""
+
+    def __init__(self, bns: List[nn.BatchNorm2d], mode: int, first: bool):
+        self.bns = bns
+        self.mode = mode  # ops.CY_SRC_* for the first conv's source 1
+        self.first = first  # first conv reads the f32 image (Cin <= 4)
+        self.dtype: Optional[torch.dtype] = None  # forced compute dtype (None = infer)
+
+
+def _bn_flags(bn: nn.BatchNorm2d):
+    use_batch = bn.training or bn.running_mean is None
+    update = bn.training and bn.track_running_stats and bn.running_mean is not None
+    return use_batch, update
+
+
+class ConvChainFn(torch.autograd.Function):
+    """One reference block: _ConvBlock (2 convs) or _UpConv (upsample + 1 conv)."""
+
+    @staticmethod
+    def forward(ctx, cfg: ChainCfg, x1: Tensor, x2: Optional[Tensor], *params: Tensor):
+        nconv = len(params) // 3
+        ops.require_gpu(x1, x2, *params)
+        dt = compute_dtype_for(x1, cfg.dtype)
+        dev = x1.device
+        saved = []
+        batch_flags = []
+        cur, cur2, mode = x1, x2, cfg.mode
+        if not cfg.first:
+            if cur.dtype != dt:
+                cur = cur.to(dt)
+            cur = ops.to_nhwc(cur)
+            if cur2 is not None:
+                cur2 = ops.to_nhwc(cur2.to(dt) if cur2.dtype != dt else cur2)
+        x1s, x2s = cur, cur2
+        scale = shift = None
+        ys, coefs = [], []
+        for i in range(nconv):
+            w, g, b = params[3 * i: 3 * i + 3]
+            bn = cfg.bns[i]
+            use_batch, update = _bn_flags(bn)
+            Cout = w.shape[0]
+            if i == 0 and cfg.first:
+                y, part = ops.conv_first_fwd(cur, w, dt, want_stats=use_batch)
+            else:
+                wf, _ = packed_weights(w, dt)
+                y, part = ops.conv3x3_fwd(cur, cur2 if i == 0 else None, wf, Cout,
+                                          mode=mode if i == 0 else 0, scale=scale, shift=shift,
+                                          want_stats=use_batch)
+            count = y.shape[0] * y.shape[2] * y.shape[3]
+            scale, shift, mean, invstd = ops.bn_finalize(
+                part, count, g.detach(), b.detach(), bn.running_mean, bn.running_var,
+                bn.momentum if bn.momentum is not None else 0.1, bn.eps, use_batch, update, Cout, dev)
+            if update and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            ys.append(y)
+            coefs.append((scale, shift, mean, invstd))
+            batch_flags.append(use_batch)
+            cur, cur2 = y, None
+        out = ops.bn_relu_apply(ys[-1], scale, shift)
+        ctx.cfg, ctx.nconv, ctx.dt = cfg, nconv, dt
+        ctx.batch_flags = batch_flags
+        ctx.x_shape = tuple(x1.shape)
+        ctx.x_dtype = x1.dtype
+        ctx.has_x2 = x2 is not None
+        tensors = [x1s] + ([x2s] if x2 is not None else []) + list(params) + ys
+        for c in coefs:
+            tensors.extend(c)
+        ctx.save_for_backward(*tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        cfg, nconv, dt = ctx.cfg, ctx.nconv, ctx.dt
+        t = list(ctx.saved_tensors)
+        x1 = t.pop(0)
+        x2 = t.pop(0) if ctx.has_x2 else None
+        params = [t.pop(0) for _ in range(3 * nconv)]
+        ys = [t.pop(0) for _ in range(nconv)]
+        coefs = [tuple(t.pop(0) for _ in range(4)) for _ in range(nconv)]
+        need = ctx.needs_input_grad  # (cfg, x1, x2, *params)
+        grads_p: List[Optional[Tensor]] = [None] * (3 * nconv)
+        da = dout
+        dx1 = dx2 = None
+        for i in reversed(range(nconv)):
+            w = params[3 * i]
+            scale, shift, mean, invstd = coefs[i]
+            dy, dgamma, dbeta = ops.bn_relu_bwd(da, ys[i], scale, shift, mean, invstd,
+                                                ctx.batch_flags[i])
+            if need[3 + 3 * i + 1]:
+                grads_p[3 * i + 1] = dgamma
+            if need[3 + 3 * i + 2]:
+                grads_p[3 * i + 2] = dbeta
+            if i > 0:
+                ps, ph = coefs[i - 1][0], coefs[i - 1][1]
+                if need[3 + 3 * i]:
+                    grads_p[3 * i] = ops.conv3x3_wgrad(ys[i - 1], None, dy, scale=ps, shift=ph)
+                _, wd = packed_weights(w, dt)
+                da, _ = ops.conv3x3_fwd(dy, None, wd, w.shape[1], want_stats=False)
+            else:
+                if need[3]:
+                    if cfg.first:
+                        grads_p[0] = ops.conv_first_wgrad(x1, dy)
+                    else:
+                        grads_p[0] = ops.conv3x3_wgrad(x1, x2, dy, mode=cfg.mode)
+                need_x1 = need[1]
+                need_x2 = ctx.has_x2 and need[2]
+                if need_x1 or need_x2:
+                    if cfg.first:
+                        raise RuntimeError("gradient w.r.t. the input image is not implemented "
+                                           "(the reference never asks for it)")
+                    _, wd = packed_weights(w, dt)
+                    C1 = x1.shape[1]
+                    if ctx.has_x2:
+                        (dl1, dl2), _ = ops.conv3x3_fwd(dy, None, wd, w.shape[1], want_stats=False,
+                                                        split=C1)
+                        dx2 = dl2 if need_x2 else None
+                    else:
+                        dl1, _ = ops.conv3x3_fwd(dy, None, wd, w.shape[1], want_stats=False)
+                    if need_x1:
+                        if cfg.mode == ops.CY_SRC_POOL2:
+                            dx1 = ops.maxpool2_bwd(x1, dl1)
+                        elif cfg.mode == ops.CY_SRC_UP2:
+                            dx1 = ops.upsample2_bwd(dl1)
+                        else:
+                            dx1 = dl1
+                        if dx1.dtype != ctx.x_dtype:
+                            dx1 = dx1.to(ctx.x_dtype)
+        return (None, dx1, dx2, *grads_p)
+
+
+class HeadFn(torch.autograd.Function):
+    """nn.Conv2d(C, K, 1) with bias (contrastyou/arch/unet.py:102); f32 logits."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor]):
+        ops.require_gpu(x, w)
+        x = ops.to_nhwc(x)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return ops.head_fwd(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dlogits: Tensor):
+        x, w = ctx.saved_tensors
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or (
+            ctx.has_bias and ctx.needs_input_grad[2])
+        dx, dw, db = ops.head_bwd(x, w, dlogits, need_dx, need_dw)
+        if dw is not None:
+            dw = dw.to(w.dtype)
+        return dx, dw if ctx.needs_input_grad[1] else None, db if ctx.has_bias else None
+
+
+class SoftmaxKLFn(torch.autograd.Function):
+    """KL_div(softmax(logits,1), one_hot(target)) with mean reduction
+    (semi_seg/epochers/epocher.py:317-318, contrastyou/losses/kl.py:112-125)."""
+
+    @staticmethod
+    def forward(ctx, logits: Tensor, target: Tensor, eps: float):
+        ops.require_gpu(logits, target)
+        logits = ops.to_nhwc(logits.float())
+        target = target.contiguous()
+        ctx.save_for_backward(logits, target)
+        ctx.eps = eps
+        return ops.softmax_kl_fwd(logits, target, eps)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        logits, target = ctx.saved_tensors
+        gs = g.reshape(1).float().contiguous()
+        return ops.softmax_kl_bwd(logits, target, gs, ctx.eps), None, None
+
+
+class SoftmaxMSEFn(torch.autograd.Function):
+    """nn.MSELoss()(a.softmax(1), b.softmax(1)) (semi_seg/hooks/consistency.py:36, mt.py:186)."""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor):
+        ops.require_gpu(a, b)
+        a = ops.to_nhwc(a.float())
+        b = ops.to_nhwc(b.float())
+        ctx.save_for_backward(a, b)
+        return ops.softmax_mse_fwd(a, b)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        a, b = ctx.saved_tensors
+        gs = g.reshape(1).float().contiguous()
+        da, db = ops.softmax_mse_bwd(a, b, gs, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return da, db
+
+
+class AvgPoolFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d((1,1)) + Flatten (contrastyou/projectors/heads.py:15-16)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        ops.require_gpu(x)
+        x = ops.to_nhwc(x)
+        ctx.shape, ctx.dtype = tuple(x.shape), x.dtype
+        return ops.avgpool_fwd(x)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return ops.avgpool_bwd(g.float().contiguous(), ctx.shape, ctx.dtype)
+
+
+class LinearFn(torch.autograd.Function):
+    """nn.Linear (+ optional in-place LeakyReLU), contrastyou/projectors/heads.py:17-19."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor], act: int, slope: float):
+        ops.require_gpu(x, w)
+        x = x.float().contiguous()
+        w32 = w.detach().float().contiguous()
+        y = ops.linear_fwd(x, w32, None if b is None else b.detach().float().contiguous(), act, slope)
+        ctx.save_for_backward(x, w32, y)
+        ctx.act, ctx.slope, ctx.has_bias = act, slope, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, w, y = ctx.saved_tensors
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dx, dw, db = ops.linear_bwd(x, w, y, g.float().contiguous(), ctx.act, ctx.slope, need_dx,
+                                    need_dw)
+        return dx, dw if ctx.needs_input_grad[1] else None, db if ctx.has_bias else None, None, None
+
+
+class L2NormFn(torch.autograd.Function):
+    """F.normalize(x, p=2, dim=1) on [M,D] (contrastyou/projectors/nn.py:47-54)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        ops.require_gpu(x)
+        x = x.float().contiguous()
+        z, norms = ops.l2norm_fwd(x)
+        ctx.save_for_backward(x, norms)
+        return z
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, norms = ctx.saved_tensors
+        return ops.l2norm_bwd(x, norms, g.float().contiguous())
+
+
+class SupConFn(torch.autograd.Function):
+    """SupConLoss1._forward (contrastyou/losses/contrastive.py:52-100) on P = cat(z1, z2)."""
+
+    @staticmethod
+    def forward(ctx, P: Tensor, labels: Optional[Tensor], pos_mask: Optional[Tensor], t: float):
+        ops.require_gpu(P)
+        P = P.float().contiguous()
+        loss, S, stats = ops.supcon_fwd(P, labels, pos_mask, t)
+        ctx.save_for_backward(P, S, stats)
+        ctx.labels, ctx.pos_mask, ctx.t = labels, pos_mask, t
+        ctx.mark_non_differentiable(S, stats)
+        return loss, S, stats
+
+    @staticmethod
+    def backward(ctx, g: Tensor, _gS, _gstats):
+        P, S, stats = ctx.saved_tensors
+        gs = g.reshape(1).float().contiguous()
+        return ops.supcon_bwd(P, ctx.labels, ctx.pos_mask, S, stats, gs, ctx.t), None, None, None
+
+
+class AffineFn(torch.autograd.Function):
+    """Nearest-neighbour affine resampling (+gamma), the in-step augmentation of
+    semi_seg/augment.py:297-311 with the geometry given explicitly as theta."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, theta: Tensor, gamma: Optional[Tensor]):
+        ops.require_gpu(x, theta)
+        ctx.save_for_backward(theta)
+        ctx.has_gamma = gamma is not None
+        return ops.affine_fwd(x, theta, gamma)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        if ctx.has_gamma:
+            raise RuntimeError("backward through the gamma (image-mode) transform is not defined: "
+                               "the reference applies it to input images only")
+        (theta,) = ctx.saved_tensors
+        return ops.affine_bwd(g, theta), None, None

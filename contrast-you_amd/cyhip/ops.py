@@ -1,0 +1,457 @@
+"""Tensor-level wrappers over the C ABI (one Python function per kernel family).
+
+torch is used for device memory (caching allocator), the current HIP stream and nothing
+else: every function below enqueues hand-written gfx950 kernels from libcontrastyou_hip.so.
+Activations are logical [N,C,H,W] tensors in channels_last memory (= NHWC).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import CY_BF16, CY_F32, CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2, ConvDesc  # noqa: F401
+
+_DT = {torch.float32: CY_F32, torch.bfloat16: CY_BF16}
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {dt}: the HIP path computes in float32 or bfloat16") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_gpu(*ts: Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "contrast-you_amd: the hot path only runs as hand-written HIP kernels on a GPU "
+                f"(got a {t.device} tensor); there is no CPU fallback")
+
+
+def is_nhwc(t: Tensor) -> bool:
+    return t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def to_nhwc(t: Tensor) -> Tensor:
+    """Return t with NHWC memory (no copy when it already is)."""
+    if is_nhwc(t):
+        return t
+    return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def empty_nhwc(N: int, Cc: int, H: int, W: int, dtype, device) -> Tensor:
+    return torch.empty((N, H, W, Cc), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def _f32(n, device) -> Tensor:
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def _ws(nbytes: int, device) -> Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# --------------------------------------------------------------------------- conv3x3
+def packed_dims(Cout: int, Cin: int) -> Tuple[int, int]:
+    a, b = C.c_int(), C.c_int()
+    _lib.call("cy_conv3x3_packed_dims", Cout, Cin, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def pack_weights(w: Tensor, dtype: torch.dtype, want_dgrad: bool = True):
+    """w: [Cout,Cin,3,3] f32 -> (wf [9,co_pad,ci_pad], wd [9,ci_pad',co_pad'] or None) of `dtype`."""
+    require_gpu(w)
+    Cout, Cin = w.shape[0], w.shape[1]
+    w = w.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    cop, cip = packed_dims(Cout, Cin)
+    wf = torch.empty((9, cop, cip), dtype=dtype, device=w.device)
+    wd = None
+    if want_dgrad:
+        cip2, cop2 = packed_dims(Cin, Cout)
+        wd = torch.empty((9, cip2, cop2), dtype=dtype, device=w.device)
+    _lib.call("cy_conv3x3_pack_weights", w.data_ptr(), wf.data_ptr(), _ptr(wd), Cout, Cin,
+              dtype_code(dtype), _stream())
+    return wf, wd
+
+
+def _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, ld1, ld2, ldo, split_c=0, ldo2=0) -> ConvDesc:
+    d = ConvDesc()
+    d.N, d.H, d.W, d.C1, d.C2, d.Cout = N, H, W, C1, C2, Cout
+    d.mode1, d.prologue, d.in_dtype, d.out_dtype = mode, prologue, dt, dt
+    d.ld1, d.ld2, d.ldo, d.split_c, d.ldo2 = ld1, ld2, ldo, split_c, ldo2
+    return d
+
+
+def _out_hw(src1: Tensor, mode: int) -> Tuple[int, int]:
+    H, W = src1.shape[2], src1.shape[3]
+    if mode == CY_SRC_POOL2:
+        if H % 2 or W % 2:
+            raise ValueError(f"max-pool 2x2 needs even spatial dims, got {H}x{W}")
+        return H // 2, W // 2
+    if mode == CY_SRC_UP2:
+        return H * 2, W * 2
+    return H, W
+
+
+def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, mode: int = 0,
+                scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
+                want_stats: bool = True, split: Optional[int] = None):
+    """out = conv3x3(cat(src1', src2)).  Returns (out, partials|None) or, with `split`,
+    ((out[:, :split], out[:, split:]), None) as two separate NHWC tensors."""
+    require_gpu(src1, wf)
+    N, C1 = src1.shape[0], src1.shape[1]
+    C2 = 0 if src2 is None else src2.shape[1]
+    H, W = _out_hw(src1, mode)
+    dt = dtype_code(src1.dtype)
+    dev = src1.device
+    prologue = 1 if scale is not None else 0
+    if split:
+        out = empty_nhwc(N, split, H, W, src1.dtype, dev)
+        out2 = empty_nhwc(N, Cout - split, H, W, src1.dtype, dev)
+        d = _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, C1, C2, split, split, Cout - split)
+    else:
+        out = empty_nhwc(N, Cout, H, W, src1.dtype, dev)
+        out2 = None
+        d = _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, C1, C2, Cout)
+    stats = None
+    if want_stats:
+        npart = _lib.call("cy_conv3x3_num_partials", C.byref(d))
+        stats = _f32(npart * 2 * Cout, dev).view(npart, 2, Cout)
+    _lib.call("cy_conv3x3_fwd", C.byref(d), src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
+              wf.data_ptr(), out.data_ptr(), _ptr(out2), _ptr(stats), _stream())
+    if split:
+        return (out, out2), None
+    return out, stats
+
+
+def conv3x3_wgrad(src1: Tensor, src2: Optional[Tensor], dy: Tensor, *, mode: int = 0,
+                  scale: Optional[Tensor] = None, shift: Optional[Tensor] = None) -> Tensor:
+    require_gpu(src1, dy)
+    N, C1 = src1.shape[0], src1.shape[1]
+    C2 = 0 if src2 is None else src2.shape[1]
+    Cout, H, W = dy.shape[1], dy.shape[2], dy.shape[3]
+    dt = dtype_code(src1.dtype)
+    d = _desc(N, H, W, C1, C2, Cout, mode, 1 if scale is not None else 0, dt, C1, C2, Cout)
+    nbytes = _lib.load().cy_conv3x3_wgrad_ws_bytes(C.byref(d))
+    ws = _ws(nbytes, src1.device)
+    dw = torch.empty((Cout, C1 + C2, 3, 3), dtype=torch.float32, device=src1.device)
+    _lib.call("cy_conv3x3_wgrad", C.byref(d), src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
+              dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    return dw
+
+
+def conv_first_fwd(x: Tensor, w: Tensor, out_dtype: torch.dtype, want_stats: bool = True):
+    """x: f32 NCHW image [N,Cin<=4,H,W]; w: f32 [Cout,Cin,3,3]."""
+    require_gpu(x, w)
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    x = x.contiguous() if x.dtype == torch.float32 else x.float().contiguous()
+    w = w.detach().contiguous()
+    out = empty_nhwc(N, Cout, H, W, out_dtype, x.device)
+    stats = None
+    if want_stats:
+        npart = _lib.call("cy_conv3x3_first_num_partials", N, H, W, Cout)
+        stats = _f32(npart * 2 * Cout, x.device).view(npart, 2, Cout)
+    _lib.call("cy_conv3x3_first_fwd", x.data_ptr(), w.data_ptr(), out.data_ptr(), _ptr(stats), N, Cin,
+              H, W, Cout, dtype_code(out_dtype), _stream())
+    return out, stats
+
+
+def conv_first_wgrad(x: Tensor, dy: Tensor) -> Tensor:
+    require_gpu(x, dy)
+    N, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    x = x.contiguous() if x.dtype == torch.float32 else x.float().contiguous()
+    nbytes = _lib.load().cy_conv3x3_first_wgrad_ws_bytes(N, Cin, H, W, Cout)
+    ws = _ws(nbytes, x.device)
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    _lib.call("cy_conv3x3_first_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, Cin, H, W, Cout,
+              dtype_code(dy.dtype), ws.data_ptr(), nbytes, _stream())
+    return dw
+
+
+# --------------------------------------------------------------------------- BN + ReLU
+def bn_finalize(partials: Optional[Tensor], count: int, gamma: Optional[Tensor], beta: Optional[Tensor],
+                running_mean: Optional[Tensor], running_var: Optional[Tensor], momentum: float,
+                eps: float, use_batch_stats: bool, update_running: bool, Cc: int, device):
+    out = _f32(4 * Cc, device).view(4, Cc)
+    npart = 0 if partials is None else partials.shape[0]
+    _lib.call("cy_bn_finalize", _ptr(partials), npart, Cc, float(count), _ptr(gamma), _ptr(beta),
+              _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
+              int(use_batch_stats), int(update_running), out[0].data_ptr(), out[1].data_ptr(),
+              out[2].data_ptr(), out[3].data_ptr(), _stream())
+    return out[0], out[1], out[2], out[3]  # scale, shift, mean, invstd
+
+
+def bn_relu_apply(y: Tensor, scale: Tensor, shift: Tensor, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    N, Cc, H, W = y.shape
+    out_dtype = out_dtype or y.dtype
+    out = empty_nhwc(N, Cc, H, W, out_dtype, y.device)
+    _lib.call("cy_bn_relu_apply", y.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+              N * H * W, Cc, dtype_code(y.dtype), dtype_code(out_dtype), _stream())
+    return out
+
+
+def bn_relu_bwd(da: Tensor, y: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor,
+                batch_stats: bool):
+    """Backward of a = relu(bn(y)): returns (dy, dgamma, dbeta)."""
+    N, Cc, H, W = y.shape
+    npix = N * H * W
+    dev = y.device
+    dt = dtype_code(y.dtype)
+    if da.dtype != y.dtype:
+        da = da.to(y.dtype)
+    da = to_nhwc(da)
+    npart = _lib.call("cy_bn_bwd_num_partials", npix, Cc)
+    part = _f32(npart * 2 * Cc, dev)
+    _lib.call("cy_bn_relu_bwd_reduce", da.data_ptr(), Cc, y.data_ptr(), scale.data_ptr(),
+              shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), part.data_ptr(), npix, Cc, dt,
+              _stream())
+    gb = _f32(2 * Cc, dev).view(2, Cc)
+    _lib.call("cy_bn_bwd_finalize", part.data_ptr(), npart, Cc, gb[0].data_ptr(), gb[1].data_ptr(),
+              _stream())
+    dy = empty_nhwc(N, Cc, H, W, y.dtype, dev)
+    _lib.call("cy_bn_relu_bwd_apply", da.data_ptr(), Cc, y.data_ptr(), scale.data_ptr(),
+              shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gb[0].data_ptr(),
+              gb[1].data_ptr(), dy.data_ptr(), npix, Cc, float(npix), int(batch_stats), dt, _stream())
+    return dy, gb[0], gb[1]
+
+
+def maxpool2_bwd(x: Tensor, dpool: Tensor, add: Optional[Tensor] = None) -> Tensor:
+    N, Cc, H2, W2 = x.shape
+    dx = empty_nhwc(N, Cc, H2, W2, x.dtype, x.device)
+    _lib.call("cy_maxpool2_bwd", x.data_ptr(), dpool.data_ptr(), _ptr(add), Cc, dx.data_ptr(), N,
+              H2 // 2, W2 // 2, Cc, dtype_code(x.dtype), _stream())
+    return dx
+
+
+def upsample2_bwd(dup: Tensor) -> Tensor:
+    N, Cc, H2, W2 = dup.shape
+    dx = empty_nhwc(N, Cc, H2 // 2, W2 // 2, dup.dtype, dup.device)
+    _lib.call("cy_upsample2_bwd", dup.data_ptr(), Cc, dx.data_ptr(), N, H2 // 2, W2 // 2, Cc,
+              dtype_code(dup.dtype), _stream())
+    return dx
+
+
+# --------------------------------------------------------------------------- head + losses
+def head_fwd(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """x [N,C,H,W] NHWC -> f32 logits [N,K,H,W] NHWC."""
+    require_gpu(x, w)
+    N, Cc, H, W = x.shape
+    K = w.shape[0]
+    logits = empty_nhwc(N, K, H, W, torch.float32, x.device)
+    w2 = w.detach().reshape(K, Cc).float().contiguous()
+    _lib.call("cy_head1x1_fwd", x.data_ptr(), w2.data_ptr(), _ptr(None if b is None else b.detach()),
+              logits.data_ptr(), N * H * W, Cc, K, dtype_code(x.dtype), _stream())
+    return logits
+
+
+def head_bwd(x: Tensor, w: Tensor, dlogits: Tensor, need_dx: bool, need_dw: bool):
+    N, Cc, H, W = x.shape
+    K = w.shape[0]
+    npix = N * H * W
+    dlogits = to_nhwc(dlogits.float())
+    w2 = w.detach().reshape(K, Cc).float().contiguous()
+    dx = empty_nhwc(N, Cc, H, W, x.dtype, x.device) if need_dx else None
+    dw = db = None
+    nbytes = 0
+    ws = None
+    if need_dw:
+        dw = _f32(K * Cc, x.device)
+        db = _f32(K, x.device)
+        nbytes = _lib.load().cy_head1x1_bwd_ws_bytes(npix, Cc, K)
+        ws = _ws(nbytes, x.device)
+    _lib.call("cy_head1x1_bwd", x.data_ptr(), w2.data_ptr(), dlogits.data_ptr(), _ptr(dx), _ptr(dw),
+              _ptr(db), npix, Cc, K, dtype_code(x.dtype), _ptr(ws), nbytes, _stream())
+    if dw is not None:
+        dw = dw.view(K, Cc, 1, 1)
+    return dx, dw, db
+
+
+def softmax_kl_fwd(logits: Tensor, target: Tensor, eps: float) -> Tensor:
+    N, K, H, W = logits.shape
+    npix = N * H * W
+    nbytes = _lib.load().cy_softmax_kl_ws_bytes(npix)
+    ws = _ws(nbytes, logits.device)
+    loss = _f32(1, logits.device)
+    _lib.call("cy_softmax_kl_fwd", logits.data_ptr(), target.data_ptr(), loss.data_ptr(), npix, K,
+              float(eps), ws.data_ptr(), nbytes, _stream())
+    return loss.view(())
+
+
+def softmax_kl_bwd(logits: Tensor, target: Tensor, gscale: Tensor, eps: float) -> Tensor:
+    N, K, H, W = logits.shape
+    d = empty_nhwc(N, K, H, W, torch.float32, logits.device)
+    _lib.call("cy_softmax_kl_bwd", logits.data_ptr(), target.data_ptr(), gscale.data_ptr(),
+              d.data_ptr(), N * H * W, K, float(eps), _stream())
+    return d
+
+
+def softmax_mse_fwd(a: Tensor, b: Tensor) -> Tensor:
+    N, K, H, W = a.shape
+    npix = N * H * W
+    nbytes = _lib.load().cy_softmax_mse_ws_bytes(npix)
+    ws = _ws(nbytes, a.device)
+    loss = _f32(1, a.device)
+    _lib.call("cy_softmax_mse_fwd", a.data_ptr(), b.data_ptr(), loss.data_ptr(), npix, K,
+              ws.data_ptr(), nbytes, _stream())
+    return loss.view(())
+
+
+def softmax_mse_bwd(a: Tensor, b: Tensor, gscale: Tensor, need_a: bool, need_b: bool):
+    N, K, H, W = a.shape
+    da = empty_nhwc(N, K, H, W, torch.float32, a.device) if need_a else None
+    db = empty_nhwc(N, K, H, W, torch.float32, a.device) if need_b else None
+    _lib.call("cy_softmax_mse_bwd", a.data_ptr(), b.data_ptr(), gscale.data_ptr(), _ptr(da), _ptr(db),
+              N * H * W, K, _stream())
+    return da, db
+
+
+def dice_counts(logits: Tensor, target: Tensor) -> Tensor:
+    """int64 [N,K,2] = per-sample per-class (intersection, union) of argmax(logits) vs target."""
+    N, K, H, W = logits.shape
+    counts = torch.empty((N, K, 2), dtype=torch.int64, device=logits.device)
+    _lib.call("cy_dice_counts", logits.data_ptr(), target.data_ptr(), counts.data_ptr(), N, H * W, K,
+              _stream())
+    return counts
+
+
+# --------------------------------------------------------------------------- projector pieces
+def avgpool_fwd(x: Tensor) -> Tensor:
+    N, Cc, H, W = x.shape
+    pooled = _f32(N * Cc, x.device).view(N, Cc)
+    _lib.call("cy_avgpool_fwd", x.data_ptr(), pooled.data_ptr(), N, H * W, Cc, dtype_code(x.dtype),
+              _stream())
+    return pooled
+
+
+def avgpool_bwd(dpooled: Tensor, shape, dtype) -> Tensor:
+    N, Cc, H, W = shape
+    dx = empty_nhwc(N, Cc, H, W, dtype, dpooled.device)
+    _lib.call("cy_avgpool_bwd", dpooled.data_ptr(), dx.data_ptr(), N, H * W, Cc, dtype_code(dtype),
+              _stream())
+    return dx
+
+
+def linear_fwd(x: Tensor, w: Tensor, b: Optional[Tensor], act: int = 0, slope: float = 0.01) -> Tensor:
+    M, I = x.shape
+    O = w.shape[0]
+    y = _f32(M * O, x.device).view(M, O)
+    _lib.call("cy_linear_fwd", x.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(), M, I, O, act,
+              float(slope), _stream())
+    return y
+
+
+def linear_bwd(x: Tensor, w: Tensor, y: Tensor, dy: Tensor, act: int, slope: float, need_dx: bool,
+               need_dw: bool):
+    M, I = x.shape
+    O = w.shape[0]
+    dx = _f32(M * I, x.device).view(M, I) if need_dx else None
+    dw = _f32(O * I, x.device).view(O, I) if need_dw else None
+    db = _f32(O, x.device) if need_dw else None
+    _lib.call("cy_linear_bwd", x.data_ptr(), w.data_ptr(), y.data_ptr(), dy.data_ptr(), _ptr(dx),
+              _ptr(dw), _ptr(db), M, I, O, act, float(slope), _stream())
+    return dx, dw, db
+
+
+def l2norm_fwd(x: Tensor, eps: float = 1e-12):
+    M, D = x.shape
+    z = torch.empty_like(x)
+    norms = _f32(M, x.device)
+    _lib.call("cy_l2norm_fwd", x.data_ptr(), z.data_ptr(), norms.data_ptr(), M, D, float(eps), _stream())
+    return z, norms
+
+
+def l2norm_bwd(x: Tensor, norms: Tensor, dz: Tensor, eps: float = 1e-12) -> Tensor:
+    M, D = x.shape
+    dx = torch.empty_like(x)
+    _lib.call("cy_l2norm_bwd", x.data_ptr(), norms.data_ptr(), dz.data_ptr(), dx.data_ptr(), M, D,
+              float(eps), _stream())
+    return dx
+
+
+# --------------------------------------------------------------------------- SupCon / InfoNCE
+def supcon_fwd(P: Tensor, labels: Optional[Tensor], pos_mask: Optional[Tensor], t: float):
+    R, D = P.shape
+    n = R // 2
+    S = _f32(R * R, P.device).view(R, R)
+    stats = _f32(R * 4, P.device).view(R, 4)
+    loss = _f32(1, P.device)
+    _lib.call("cy_supcon_fwd", P.data_ptr(), _ptr(labels), _ptr(pos_mask), S.data_ptr(),
+              loss.data_ptr(), stats.data_ptr(), n, D, float(t), _stream())
+    return loss.view(()), S, stats
+
+
+def supcon_bwd(P: Tensor, labels, pos_mask, S: Tensor, stats: Tensor, gscale: Tensor, t: float) -> Tensor:
+    R, D = P.shape
+    G = _f32(R * R, P.device)
+    dP = torch.empty_like(P)
+    _lib.call("cy_supcon_bwd", P.data_ptr(), _ptr(labels), _ptr(pos_mask), S.data_ptr(),
+              stats.data_ptr(), gscale.data_ptr(), G.data_ptr(), dP.data_ptr(), R // 2, D, float(t),
+              _stream())
+    return dP
+
+
+def supcon_matrices(S: Tensor, stats: Tensor, labels, pos_mask):
+    R = S.shape[0]
+    outs = [_f32(R * R, S.device).view(R, R) for _ in range(4)]
+    _lib.call("cy_supcon_matrices", S.data_ptr(), stats.data_ptr(), _ptr(labels), _ptr(pos_mask),
+              *[o.data_ptr() for o in outs], R // 2, _stream())
+    return outs  # sim_logits, sim_exp, pos_mask, neg_mask
+
+
+def sgemm(A: Tensor, B: Tensor, alpha: float = 1.0, b_trans: bool = False) -> Tensor:
+    M, K = A.shape
+    N = B.shape[0] if b_trans else B.shape[1]
+    Cm = _f32(M * N, A.device).view(M, N)
+    _lib.call("cy_sgemm", A.data_ptr(), B.data_ptr(), Cm.data_ptr(), M, N, K, float(alpha),
+              int(b_trans), _stream())
+    return Cm
+
+
+# --------------------------------------------------------------------------- affine / EMA / RAdam
+def affine_fwd(x: Tensor, theta: Tensor, gamma: Optional[Tensor] = None) -> Tensor:
+    require_gpu(x, theta)
+    x = to_nhwc(x)
+    N, Cc, H, W = x.shape
+    out = empty_nhwc(N, Cc, H, W, x.dtype, x.device)
+    _lib.call("cy_affine_nearest_fwd", x.data_ptr(), out.data_ptr(), theta.data_ptr(), _ptr(gamma), N,
+              Cc, H, W, dtype_code(x.dtype), _stream())
+    return out
+
+
+def affine_bwd(dout: Tensor, theta: Tensor) -> Tensor:
+    dout = to_nhwc(dout)
+    N, Cc, H, W = dout.shape
+    dx = empty_nhwc(N, Cc, H, W, dout.dtype, dout.device)
+    _lib.call("cy_affine_nearest_bwd", dout.data_ptr(), dx.data_ptr(), theta.data_ptr(), N, Cc, H, W,
+              dtype_code(dout.dtype), _stream())
+    return dx
+
+
+def ema_update(teacher: Tensor, student: Tensor, alpha: float, weight_decay: float) -> None:
+    require_gpu(teacher, student)
+    _lib.call("cy_ema_update", teacher.data_ptr(), student.data_ptr(), teacher.numel(), float(alpha),
+              float(weight_decay), _stream())
+
+
+def radam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, beta2: float,
+               eps: float, wd: float, step: int) -> None:
+    require_gpu(p, g)
+    _lib.call("cy_radam_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+              float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step), _stream())

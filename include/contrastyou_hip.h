@@ -1,0 +1,283 @@
+/*
+ * contrastyou_hip.h -- C ABI of libcontrastyou_hip.so, the MI355X (gfx950)
+ * implementation of the Contrast-You SemiSupervisedEpocher hot path.
+ *
+ * The reference (jizongFox/Contrast-You) is 100 % Python on torch: it has no
+ * FFI of its own.  Every entry point below therefore replaces a torch library
+ * call made by a reference leaf; the file:line of that call site is cited per
+ * function.  Conventions:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     the parameter name starts with h_ (host);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it,
+ *     nothing synchronises, nothing allocates (callers pass workspaces);
+ *   - activations are NHWC ("channels_last"): element (n,h,w,c) lives at
+ *     ((n*H + h)*W + w)*ld + c, ld >= C the pixel pitch in elements;
+ *   - dtype codes: CY_F32 (verification mode, f32 MFMA, exact fmaf chains)
+ *     and CY_BF16 (production mode, bf16 MFMA with f32 accumulation);
+ *   - return value 0 = enqueued, <0 = argument/shape error (nothing was
+ *     launched), see CY_ERR_*.
+ */
+#ifndef CONTRASTYOU_HIP_H
+#define CONTRASTYOU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CY_OK 0
+#define CY_ERR_ARG (-1)
+#define CY_ERR_SHAPE (-2)
+#define CY_ERR_DTYPE (-3)
+#define CY_ERR_LAUNCH (-4)
+#define CY_ERR_WORKSPACE (-5)
+
+#define CY_F32 0
+#define CY_BF16 1
+
+/* how source 1 of a 3x3 conv is addressed (arch/unet.py:67-70 MaxPool2d,
+ * :38 Upsample(scale_factor=2) nearest, both folded into the conv's loads) */
+#define CY_SRC_DIRECT 0 /* src1 is [N,H,W,C1] */
+#define CY_SRC_POOL2 1  /* src1 is [N,2H,2W,C1]; 2x2 max taken on load */
+#define CY_SRC_UP2 2    /* src1 is [N,H/2,W/2,C1]; nearest x2 on load */
+
+/* ABI version; bumped whenever a signature changes. */
+int cy_abi_version(void);
+/* name of the offload arch the library was built for ("gfx950"). */
+const char* cy_build_arch(void);
+
+/* ------------------------------------------------------------------------
+ * 3x3 convolution, stride 1, pad 1, no bias  (nn.Conv2d at
+ * contrastyou/arch/unet.py:21,24,39) as an implicit GEMM on MFMA.
+ *
+ * Geometry: output [N,H,W,Cout].  Logical input = channel concat of source 1
+ * (C1 channels, addressed per `mode1`) and optional source 2 (C2 channels,
+ * always direct) -- torch.cat((skip, up), dim=1) at arch/unet.py:142,151,160,
+ * 169 without the copy.  If `prologue` != 0 source 1 is a RAW conv output of
+ * the previous layer and relu(scale[c]*x + shift[c]) (training-mode
+ * BatchNorm2d + ReLU, arch/unet.py:22-23) is applied while loading it.
+ * ------------------------------------------------------------------------ */
+typedef struct cy_conv_desc {
+  int32_t N, H, W;      /* output spatial geometry */
+  int32_t C1, C2, Cout; /* channels of source 1, source 2 (0 = none), output */
+  int32_t mode1;        /* CY_SRC_* for source 1 */
+  int32_t prologue;     /* 1: relu(scale*x+shift) on source 1 while loading */
+  int32_t in_dtype;     /* dtype of sources and packed weights */
+  int32_t out_dtype;    /* dtype of the output tensor */
+  int32_t ld1, ld2;     /* pixel pitch (elements) of source 1 / 2 */
+  int32_t ldo;          /* pixel pitch of `out` */
+  int32_t split_c;      /* >0: couts >= split_c go to out2 (pitch ldo2) */
+  int32_t ldo2;
+} cy_conv_desc;
+
+/* Packed weight geometry for a (Cout,Cin) 3x3 kernel: [9][co_pad][ci_pad]. */
+int cy_conv3x3_packed_dims(int Cout, int Cin, int* co_pad, int* ci_pad);
+
+/* Repack reference-layout weights w[Cout][Cin][3][3] (f32) into the forward
+ * image wf[tap][co_pad][ci_pad] and (if wd != NULL) the data-gradient image
+ * wd[tap][ci_pad'][co_pad'] = w[co][ci][2-kh][2-kw], both of `dtype`. */
+int cy_conv3x3_pack_weights(const float* w, void* wf, void* wd, int Cout, int Cin, int dtype,
+                            void* stream);
+
+/* Number of per-tile statistic partials the forward kernel writes for `d`
+ * (stats buffer is float[num_partials][2][Cout]: sum, sum of squares). */
+int cy_conv3x3_num_partials(const cy_conv_desc* d);
+
+/* out = conv3x3(concat(src1', src2), w).  stats may be NULL. */
+int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
+                   const float* shift, const void* w_packed, void* out, void* out2, float* stats,
+                   void* stream);
+
+/* Weight gradient dw[Cout][Cin][3][3] (f32, reference layout) =
+ *   sum_p dy[p][co] * in[p+tap][ci]  with `in` addressed exactly as in
+ * cy_conv3x3_fwd (same desc; desc.out_dtype/ldo describe dy).  ws is a
+ * workspace of at least cy_conv3x3_wgrad_ws_bytes(d) bytes. */
+size_t cy_conv3x3_wgrad_ws_bytes(const cy_conv_desc* d);
+int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
+                     const float* shift, const void* dy, float* dw, void* ws, size_t ws_bytes,
+                     void* stream);
+
+/* First layer (input_dim 1..4, arch/unet.py:72): x is the f32 NCHW image
+ * [N,Cin,H,W]; w is the reference-layout f32 weight [Cout][Cin][3][3]. */
+int cy_conv3x3_first_num_partials(int N, int H, int W, int Cout);
+int cy_conv3x3_first_fwd(const float* x, const float* w, void* out, float* stats, int N, int Cin,
+                         int H, int W, int Cout, int out_dtype, void* stream);
+size_t cy_conv3x3_first_wgrad_ws_bytes(int N, int Cin, int H, int W, int Cout);
+int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int N, int Cin, int H, int W,
+                           int Cout, int dy_dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * BatchNorm2d (training statistics) + ReLU   (arch/unet.py:22-23,25-26,40-41)
+ * ------------------------------------------------------------------------ */
+/* Reduce conv-epilogue partials to per-channel mean / biased var, fold them
+ * with gamma/beta into scale/shift, and update running stats
+ * (momentum, unbiased var; torch.nn.BatchNorm2d semantics).
+ * use_batch_stats=0 (module.eval()): scale/shift come from running stats.
+ * update_running=0: track_running_stats disabled (utils/utils.py:225-237). */
+int cy_bn_finalize(const float* partials, int num_partials, int C, double count,
+                   const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float momentum, float eps, int use_batch_stats,
+                   int update_running, float* scale, float* shift, float* mean, float* invstd,
+                   void* stream);
+
+/* out = relu(scale[c]*y + shift[c]) over npix pixels of C channels. */
+int cy_bn_relu_apply(const void* y, const float* scale, const float* shift, void* out,
+                     long npix, int C, int y_dtype, int out_dtype, void* stream);
+
+/* Backward of y -> relu(bn(y)).  Step 1: per-channel sums of
+ * dz = da*(scale*y+shift > 0) and dz*xhat into partials
+ * float[num_partials][2][C];  num_partials from cy_bn_bwd_num_partials. */
+int cy_bn_bwd_num_partials(long npix, int C);
+int cy_bn_relu_bwd_reduce(const void* da, int ld_da, const void* y, const float* scale,
+                          const float* shift, const float* mean, const float* invstd,
+                          float* partials, long npix, int C, int dtype, void* stream);
+/* Step 2: dgamma/dbeta from the partials (fixed summation order). */
+int cy_bn_bwd_finalize(const float* partials, int num_partials, int C, float* dgamma,
+                       float* dbeta, void* stream);
+/* Step 3: dy = scale*(dz - dbeta/M - xhat*dgamma/M)  (batch_stats=1) or
+ * dy = scale*dz (batch_stats=0, eval-mode BN). */
+int cy_bn_relu_bwd_apply(const void* da, int ld_da, const void* y, const float* scale,
+                         const float* shift, const float* mean, const float* invstd,
+                         const float* dgamma, const float* dbeta, void* dy, long npix, int C,
+                         double count, int batch_stats, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * MaxPool2d(2,2) backward (arch/unet.py:67-70) and nearest-x2 backward
+ * (arch/unet.py:38): the forward halves are folded into the conv loads.
+ * ------------------------------------------------------------------------ */
+/* dx[N,2H,2W,C] = route(dpool[N,H,W,C]) to the first arg-max of each 2x2
+ * window of x (+ add[N,2H,2W,C] if add != NULL, pitch ld_add). */
+int cy_maxpool2_bwd(const void* x, const void* dpool, const void* add, int ld_add, void* dx, int N,
+                    int H, int W, int C, int dtype, void* stream);
+/* dx[N,H,W,C] = sum of the 2x2 block of dup[N,2H,2W,C] (pitch ld_dup). */
+int cy_upsample2_bwd(const void* dup, int ld_dup, void* dx, int N, int H, int W, int C, int dtype,
+                     void* stream);
+
+/* ------------------------------------------------------------------------
+ * 1x1 classifier head  nn.Conv2d(C, K, 1) + bias  (arch/unet.py:102)
+ * logits are f32 [N,H,W,K].
+ * ------------------------------------------------------------------------ */
+int cy_head1x1_fwd(const void* x, const float* w, const float* b, float* logits, long npix, int C,
+                   int K, int x_dtype, void* stream);
+size_t cy_head1x1_bwd_ws_bytes(long npix, int C, int K);
+int cy_head1x1_bwd(const void* x, const float* w, const float* dlogits, void* dx, float* dw,
+                   float* db, long npix, int C, int K, int x_dtype, void* ws, size_t ws_bytes,
+                   void* stream);
+
+/* ------------------------------------------------------------------------
+ * Supervised loss  KL_div(softmax(logits), one_hot(target))
+ * (semi_seg/epochers/epocher.py:317-318, contrastyou/losses/kl.py:112-125,
+ *  contrastyou/utils/general.py:114-120):
+ *   loss = mean_p -log((softmax(z_p)[t_p] + eps) / (1 + eps))
+ * ------------------------------------------------------------------------ */
+size_t cy_softmax_kl_ws_bytes(long npix);
+int cy_softmax_kl_fwd(const float* logits, const int64_t* target, float* loss, long npix, int K,
+                      float eps, void* ws, size_t ws_bytes, void* stream);
+/* dlogits = gscale[0]/npix * dloss/dz  (gscale: device scalar, upstream grad) */
+int cy_softmax_kl_bwd(const float* logits, const int64_t* target, const float* gscale,
+                      float* dlogits, long npix, int K, float eps, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Encoder projection head (contrastyou/projectors/heads.py:14-22,81-96,
+ * projectors/nn.py:47-54): AdaptiveAvgPool2d(1) -> Linear -> LeakyReLU(0.01)
+ * -> Linear -> x / max(||x||_2, 1e-12).
+ * ------------------------------------------------------------------------ */
+/* pooled[n][c] = mean_{hw} x[n,h,w,c]   (f32 out) */
+int cy_avgpool_fwd(const void* x, float* pooled, int N, int HW, int C, int dtype, void* stream);
+/* dx[n,h,w,c] = dpooled[n][c] / HW */
+int cy_avgpool_bwd(const float* dpooled, void* dx, int N, int HW, int C, int dtype, void* stream);
+/* y[m][o] = act(sum_i x[m][i]*w[o][i] + b[o]);  act: 0 none, 1 LeakyReLU(slope) */
+int cy_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int I, int O,
+                  int act, float slope, void* stream);
+/* given dy (pre-activation gradient is formed inside from y when act=1):
+ * dx[m][i], dw[o][i], db[o].  Any of dx/dw/db may be NULL. */
+int cy_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
+                  float* dw, float* db, int M, int I, int O, int act, float slope, void* stream);
+/* z = x / max(||x||,eps) row-wise; norms[m] saved for backward. */
+int cy_l2norm_fwd(const float* x, float* z, float* norms, int M, int D, float eps, void* stream);
+int cy_l2norm_bwd(const float* x, const float* norms, const float* dz, float* dx, int M, int D,
+                  float eps, void* stream);
+
+/* ------------------------------------------------------------------------
+ * InfoNCE / SupCon loss  (contrastyou/losses/contrastive.py:14-20,31-100)
+ * P = [z1; z2] is [R=2n][D] f32 (unit rows), labels[n] int32 (row i and
+ * i+n share labels[i]); t = temperature.
+ *   S = P P^T / t;  M = max(S) (incl. diagonal);  E = exp(S - M)
+ *   loss = -mean_i [ sum_{j in pos(i)} ((S_ij - M) - log(sum_{k!=i} E_ik + 1e-16)) / |pos(i)| ]
+ * row_stats (f32 [R][4]) keeps {denominator_i, |pos(i)|, sum_pos S_ij, M}
+ * for the backward pass.  Rows with |pos(i)| == 0 give NaN exactly like the
+ * reference (which then raises RuntimeError, contrastive.py:98).
+ * ------------------------------------------------------------------------ */
+/* Either labels (int32 [n]) or pos_mask (uint8 [n][n], 1 = positive pair; the
+ * `mask=` argument of SupConLoss1.forward) must be non-NULL.
+ * S: f32 [R][R] buffer that receives P P^T / t (kept for backward). */
+int cy_supcon_fwd(const float* P, const int32_t* labels, const uint8_t* pos_mask, float* S,
+                  float* loss, float* row_stats, int n, int D, float t, void* stream);
+/* dP[R][D] = gscale[0] * dloss/dP.  G: f32 [R][R] scratch. */
+int cy_supcon_bwd(const float* P, const int32_t* labels, const uint8_t* pos_mask, const float* S,
+                  const float* row_stats, const float* gscale, float* G, float* dP, int n, int D,
+                  float t, void* stream);
+/* materialise sim_logits (S-M), sim_exp, pos_mask, neg_mask, each f32 [R][R]
+ * (contrastive.py:79-82; read only for the TensorBoard figures). any may be NULL */
+int cy_supcon_matrices(const float* S, const float* row_stats, const int32_t* labels,
+                       const uint8_t* pos_mask, float* sim_logits, float* sim_exp,
+                       float* pos_out, float* neg_out, int n, void* stream);
+/* f32 GEMM on the f32 MFMA: C[M][N] = alpha * A[M][K] * op(B); b_trans=1: B is
+ * [N][K] (C = A B^T), b_trans=0: B is [K][N]. */
+int cy_sgemm(const float* A, const float* B, float* C, int M, int N, int K, float alpha,
+             int b_trans, void* stream);
+
+/* ------------------------------------------------------------------------
+ * In-step affine augmentation (semi_seg/augment.py:297-311, configured at
+ * semi_seg/epochers/epocher.py:226-238; third-party `rising`, un-vendored):
+ * nearest-neighbour resampling with a per-sample 2x3 matrix theta (f32 [N][6],
+ * output-normalised -> input-normalised coordinates, align_corners=False,
+ * zero padding) and optional gamma x**g (g f32[N], NULL = none) applied
+ * BEFORE the geometry as the reference does for mode="image".
+ * Tensors are NHWC of `dtype` (an [N,1,H,W] image is its own NHWC view).
+ * ------------------------------------------------------------------------ */
+int cy_affine_nearest_fwd(const void* x, void* out, const float* theta, const float* gamma, int N,
+                          int C, int H, int W, int dtype, void* stream);
+/* dx = gather-form adjoint (deterministic, no atomics). */
+int cy_affine_nearest_bwd(const void* dout, void* dx, const float* theta, int N, int C, int H,
+                          int W, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Segmentation metric helper: per-sample per-class intersection/union counts
+ * of argmax(logits) vs target (contrastyou/meters/general_dice_meter.py:
+ * 37-72,93-110).  counts is int64 [N][K][2] = {intersection, union}.
+ * ------------------------------------------------------------------------ */
+int cy_dice_counts(const float* logits, const int64_t* target, int64_t* counts, int N, int HW,
+                   int K, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Mean-teacher / consistency hooks (semi_seg/hooks/mt.py:49-82,
+ * semi_seg/hooks/consistency.py:22-38)
+ * ------------------------------------------------------------------------ */
+/* teacher = (alpha*teacher + (1-alpha)*student) * (1 - weight_decay) over a
+ * flat f32 buffer of n elements. */
+int cy_ema_update(float* teacher, const float* student, long n, float alpha, float weight_decay,
+                  void* stream);
+/* loss = mean((softmax(a)-softmax(b))^2) over [npix][K] f32 logits */
+size_t cy_softmax_mse_ws_bytes(long npix);
+int cy_softmax_mse_fwd(const float* a, const float* b, float* loss, long npix, int K, void* ws,
+                       size_t ws_bytes, void* stream);
+/* da (and db if not NULL) = gscale[0] * dloss/d{a,b} */
+int cy_softmax_mse_bwd(const float* a, const float* b, const float* gscale, float* da, float* db,
+                       long npix, int K, void* stream);
+
+/* ------------------------------------------------------------------------
+ * RAdam step over a flat f32 parameter buffer (torch.optim.RAdam semantics,
+ * contrastyou/trainer/base.py:66-75, config/base.yaml:10-13).
+ * `step` is the 1-based step count AFTER this update.
+ * ------------------------------------------------------------------------ */
+int cy_radam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, long step,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONTRASTYOU_HIP_H */

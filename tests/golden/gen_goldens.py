@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own leaf modules on CPU.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box):
+
+    python tests/golden/gen_goldens.py
+
+It copies nothing from the reference into the repo: /root/reference is copied to a scratch dir
+under /tmp (its packages mkdir at import), three no-arithmetic import stubs (loguru, termcolor,
+segmentation_models_pytorch, medpy) are written next to it, the reference modules are imported
+from there, fed seeded inputs/weights produced by oracle.* initialisers, and only numeric
+inputs/outputs are saved.
+"""
+import os
+import shutil
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parents[2]
+OUT = Path(__file__).resolve().parent
+REF = Path("/root/reference")
+
+STUBS = {
+    "loguru/__init__.py": (
+        "class _L:\n"
+        "    def __getattr__(self, k):\n"
+        "        return lambda *a, **k2: self\n"
+        "    def catch(self, *a, **k):\n"
+        "        return lambda fn: fn\n"
+        "logger = _L()\n"),
+    "termcolor/__init__.py": "def colored(s, *a, **k):\n    return str(s)\n",
+    "segmentation_models_pytorch/__init__.py": (
+        "import torch.nn as nn\n"
+        "class Unet(nn.Module):\n"
+        "    def __init__(self, *a, **k):\n"
+        "        super().__init__()\n"),
+    "medpy/__init__.py": "",
+    "medpy/metric/__init__.py": "def assd(*a, **k):\n    raise NotImplementedError\n",
+    "medpy/metric/binary.py": "def __surface_distances(*a, **k):\n    raise NotImplementedError\n",
+}
+
+
+def setup_reference():
+    scratch = Path(tempfile.mkdtemp(prefix="cy_ref_"))
+    shutil.copytree(REF, scratch / "ref", ignore=shutil.ignore_patterns(".git"))
+    for rel, text in STUBS.items():
+        p = scratch / "stubs" / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_text(text)
+    sys.path.insert(0, str(scratch / "ref"))
+    sys.path.insert(0, str(scratch / "stubs"))
+    os.chdir(scratch / "ref")
+    return scratch
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def main():
+    sys.path.insert(0, str(REPO))
+    from oracle import losses as ol
+    from oracle import unet as ou
+    scratch = setup_reference()
+    from contrastyou.arch.unet import UNet
+    from contrastyou.losses.contrastive import SupConLoss1
+    from contrastyou.losses.kl import KL_div
+    from contrastyou.meters import UniversalDice
+    from contrastyou.projectors.heads import DenseProjectionHead, ProjectionHead
+    from contrastyou.utils.general import class2one_hot
+
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+
+    # ------------------------------------------------------------------ U-Net
+    sd = ou.init_state_dict(input_dim=1, num_classes=4, max_channel=128, seed=11)
+    net = UNet(input_dim=1, num_classes=4, max_channel=128, momentum=0.01)
+    missing = net.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 1, 32, 32, generator=g)
+    tgt = torch.randint(0, 4, (2, 32, 32), generator=g)
+    net.train()
+    feats = {}
+    hooks = [net.get_module(n).register_forward_hook(lambda m, i, o, n=n: feats.__setitem__(n, o))
+             for n in net.arch_elements]
+    logits = net(x)
+    for h in hooks:
+        h.remove()
+    loss = KL_div()(logits.softmax(1), class2one_hot(tgt, 4))
+    loss.backward()
+    out = {"x": npy(x), "target": npy(tgt), "logits": npy(logits), "loss": npy(loss),
+           "sd_checksum": np.array([float(sum(v.double().sum() for v in sd.values() if v.is_floating_point()))])}
+    for n, f in feats.items():
+        out[f"feat_{n}"] = npy(f)
+    for n, p in net.named_parameters():
+        out[f"grad_{n}"] = npy(p.grad)
+    for n, b in net.named_buffers():
+        out[f"buf_{n}"] = npy(b)
+    net.eval()
+    with torch.no_grad():
+        out["logits_eval"] = npy(net(x))
+        out["conv5_until_eval"] = npy(net(x, until="Conv5"))
+    np.savez_compressed(OUT / "unet_small.npz", **out)
+
+    # ------------------------------------------------------------------ heads + losses
+    out = {}
+    psd = ol.init_projector_sd(128, 256, 256, seed=3)
+    head = ProjectionHead(input_dim=128, hidden_dim=256, output_dim=256, head_type="mlp", normalize=True)
+    head.load_state_dict(psd, strict=True)
+    feat = torch.randn(6, 128, 2, 2, generator=g).requires_grad_(True)
+    z = head(feat)
+    (z * torch.linspace(-1, 1, z.numel()).view_as(z)).sum().backward()
+    out["proj_feat"], out["proj_z"], out["proj_dfeat"] = npy(feat), npy(z), npy(feat.grad)
+    for n, p in head.named_parameters():
+        out[f"proj_grad_{n}"] = npy(p.grad)
+
+    dsd = ol.init_dense_projector_sd(16, 32, 32, seed=4)
+    dhead = DenseProjectionHead(input_dim=16, hidden_dim=32, output_dim=32, head_type="mlp", normalize=True,
+                                spatial_size=(4, 4))
+    dhead.load_state_dict(dsd, strict=True)
+    dfeat = torch.randn(2, 16, 8, 8, generator=g)
+    out["dense_feat"], out["dense_z"] = npy(dfeat), npy(dhead(dfeat))
+
+    crit = SupConLoss1()
+    n = 8
+    z1 = torch.nn.functional.normalize(torch.randn(n, 32, generator=g), dim=1).requires_grad_(True)
+    z2 = torch.nn.functional.normalize(torch.randn(n, 32, generator=g), dim=1).requires_grad_(True)
+    out["sc_z1"], out["sc_z2"] = npy(z1), npy(z2)
+    for tag, target in (("simclr", None), ("partition", [0, 1, 2, 0, 1, 2, 0, 1]),
+                        ("patient", [0, 1, 2, 3, 3, 4, 5, 6])):
+        z1.grad = z2.grad = None
+        l = crit(z1, z2, target=target)
+        l.backward()
+        out[f"sc_{tag}_loss"] = npy(l)
+        out[f"sc_{tag}_dz1"], out[f"sc_{tag}_dz2"] = npy(z1.grad), npy(z2.grad)
+        out[f"sc_{tag}_sim_exp"], out[f"sc_{tag}_sim_logits"] = npy(crit.sim_exp), npy(crit.sim_logits)
+        out[f"sc_{tag}_pos"], out[f"sc_{tag}_neg"] = npy(crit.pos_mask), npy(crit.neg_mask)
+    msk = (torch.rand(n, n, generator=g) > 0.5).float()
+    msk = ((msk + msk.t() + torch.eye(n)) > 0).float()
+    z1.grad = z2.grad = None
+    l = crit(z1, z2, mask=msk)
+    l.backward()
+    out["sc_mask"], out["sc_mask_loss"], out["sc_mask_dz1"] = npy(msk), npy(l), npy(z1.grad)
+
+    lg = torch.randn(2, 4, 16, 16, generator=g).requires_grad_(True)
+    tg = torch.randint(0, 4, (2, 16, 16), generator=g)
+    l = KL_div()(lg.softmax(1), class2one_hot(tg, 4))
+    l.backward()
+    out["kl_logits"], out["kl_target"], out["kl_loss"], out["kl_dlogits"] = npy(lg), npy(tg), npy(l), npy(lg.grad)
+
+    meter = UniversalDice(4, report_axis=[1, 2, 3])
+    preds, tgts, groups = [], [], []
+    for b in range(3):
+        pr = torch.randint(0, 4, (4, 16, 16), generator=g)
+        tt = torch.randint(0, 4, (4, 16, 16), generator=g)
+        gp = [f"patient{(b * 4 + i) // 3:03d}_00" for i in range(4)]
+        meter.add(pr, tt, group_name=gp)
+        preds.append(npy(pr)), tgts.append(npy(tt)), groups.append(gp)
+    summ = meter.summary()
+    out["dice_preds"], out["dice_targets"] = np.stack(preds), np.stack(tgts)
+    out["dice_groups"] = np.array(groups)
+    out["dice_keys"] = np.array(sorted(summ.keys()))
+    out["dice_vals"] = np.array([summ[k] for k in sorted(summ.keys())], dtype=np.float64)
+    np.savez_compressed(OUT / "heads_losses.npz", **out)
+
+    shutil.rmtree(scratch, ignore_errors=True)
+    print("wrote", sorted(p.name for p in OUT.glob("*.npz")))
+
+
+if __name__ == "__main__":
+    main()

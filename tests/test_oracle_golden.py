@@ -1,0 +1,102 @@
+"""The oracle (CPU restatement) against vectors produced by the reference itself
+(tests/golden/gen_goldens.py imported /root/reference in the build container)."""
+import numpy as np
+import torch
+
+from oracle import losses as ol
+from oracle import unet as ou
+
+T = torch.from_numpy
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach() if isinstance(a, torch.Tensor) else torch.as_tensor(a)
+    b = b.detach() if isinstance(b, torch.Tensor) else torch.as_tensor(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a.double() - b.double()).abs().max().item()
+    ref = b.double().abs().max().item()
+    assert err <= atol + rtol * ref, f"max err {err:.3e} vs ref scale {ref:.3e}"
+
+
+def test_unet_forward_backward_matches_reference(golden_dir):
+    g = np.load(golden_dir / "unet_small.npz")
+    sd = ou.init_state_dict(1, 4, 128, seed=11)
+    chk = float(sum(v.double().sum() for v in sd.values() if v.is_floating_point()))
+    assert abs(chk - float(g["sd_checksum"][0])) < 1e-6, "seeded init drifted from the fixture's"
+    sd = ou.clone_state_dict(sd, requires_grad=True)
+    feats = {}
+    logits = ou.unet_forward(sd, T(g["x"]), training=True, momentum=0.01, feats=feats)
+    close(logits, g["logits"])
+    for name, f in feats.items():
+        close(f, g[f"feat_{name}"])
+    loss = ol.sup_loss(logits, T(g["target"]))
+    close(loss, g["loss"], rtol=1e-6)
+    loss.backward()
+    for k, v in sd.items():
+        if v.requires_grad:
+            close(v.grad, g[f"grad_{k}"], rtol=2e-4, atol=1e-7)
+    for k in sd:
+        if "running" in k or "num_batches" in k:
+            close(sd[k].float(), T(g[f"buf_{k}"]).float(), rtol=1e-6)
+    with torch.no_grad():
+        close(ou.unet_forward(sd, T(g["x"]), training=False), g["logits_eval"], rtol=1e-5, atol=1e-5)
+        close(ou.unet_forward(sd, T(g["x"]), training=False, until="Conv5"), g["conv5_until_eval"],
+              rtol=1e-5, atol=1e-5)
+
+
+def test_projection_heads_match_reference(golden_dir):
+    g = np.load(golden_dir / "heads_losses.npz")
+    psd = {k: v.requires_grad_(True) for k, v in ol.init_projector_sd(128, 256, 256, seed=3).items()}
+    feat = T(g["proj_feat"]).requires_grad_(True)
+    z = ol.projection_head(psd, feat)
+    close(z, g["proj_z"])
+    (z * torch.linspace(-1, 1, z.numel()).view_as(z)).sum().backward()
+    close(feat.grad, g["proj_dfeat"], rtol=1e-4)
+    for k, v in psd.items():
+        close(v.grad, g[f"proj_grad_{k}"], rtol=1e-4)
+    dsd = ol.init_dense_projector_sd(16, 32, 32, seed=4)
+    close(ol.dense_projection_head(dsd, T(g["dense_feat"]), (4, 4)), g["dense_z"])
+
+
+def test_supcon_matches_reference(golden_dir):
+    g = np.load(golden_dir / "heads_losses.npz")
+    for tag, target in (("simclr", None), ("partition", [0, 1, 2, 0, 1, 2, 0, 1]),
+                        ("patient", [0, 1, 2, 3, 3, 4, 5, 6])):
+        z1 = T(g["sc_z1"]).requires_grad_(True)
+        z2 = T(g["sc_z2"]).requires_grad_(True)
+        loss, S, E, pos, neg = ol.supcon_loss(z1, z2, target=target, return_all=True)
+        close(loss, g[f"sc_{tag}_loss"], rtol=1e-6)
+        loss.backward()
+        close(z1.grad, g[f"sc_{tag}_dz1"], rtol=1e-4)
+        close(z2.grad, g[f"sc_{tag}_dz2"], rtol=1e-4)
+        close(S, g[f"sc_{tag}_sim_logits"], rtol=1e-5, atol=1e-5)
+        close(E, g[f"sc_{tag}_sim_exp"], rtol=1e-5)
+        close(pos, g[f"sc_{tag}_pos"])
+        close(neg, g[f"sc_{tag}_neg"])
+    z1 = T(g["sc_z1"]).requires_grad_(True)
+    loss = ol.supcon_loss(z1, T(g["sc_z2"]), mask=T(g["sc_mask"]))
+    close(loss, g["sc_mask_loss"], rtol=1e-6)
+    loss.backward()
+    close(z1.grad, g["sc_mask_dz1"], rtol=1e-4)
+
+
+def test_kl_and_dice_match_reference(golden_dir):
+    g = np.load(golden_dir / "heads_losses.npz")
+    lg = T(g["kl_logits"]).requires_grad_(True)
+    loss = ol.sup_loss(lg, T(g["kl_target"]))
+    close(loss, g["kl_loss"], rtol=1e-6)
+    loss.backward()
+    close(lg.grad, g["kl_dlogits"], rtol=1e-5)
+    preds = [T(p) for p in g["dice_preds"]]
+    tgts = [T(p) for p in g["dice_targets"]]
+    groups = [list(x) for x in g["dice_groups"]]
+    summ = ol.dice_summary(preds, tgts, groups, 4, [1, 2, 3])
+    for k, v in zip(g["dice_keys"], g["dice_vals"]):
+        assert abs(summ[str(k)] - float(v)) < 1e-6, (k, summ[str(k)], v)
+
+
+def test_label_generators():
+    assert ol.get_label("partition", "acdc", ["1", "0", "2", "1"], ["p1_00"] * 4) == [1, 0, 2, 1]
+    assert ol.get_label("patient", "acdc", ["0"] * 3, ["patient003_01", "patient001_00", "patient003_00"]) == [1, 0, 1]
+    assert ol.get_label("cycle", "acdc", ["0"] * 2, ["patient003_01", "patient001_00"]) == [1, 0]
+    assert ol.get_label("self", "acdc", ["0"] * 3, ["a_0"] * 3) == [0, 1, 2]
