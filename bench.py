@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: 2D slices/s of the ACDC U-Net + InfoNCE training step.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "C2"): SemiSupervisedEpocher + INFONCEHook@Conv5
+(contrast_on=partition, weight 1), two-stage forward, 16 labeled + 16 unlabeled synthetic
+1x224x224 slices per rank, 4 classes, UNet(max_channel=512, momentum=0.01), bf16 compute,
+RAdam.  One step = forward of 16 + 32 slices, supervised KL loss, InfoNCE loss, backward,
+optimizer step (+ gradient all-reduce over RCCL when N > 1).  Inputs are resident in HBM.
+`value` = (n_l + n_unl) * world / step_time  (dataset slices consumed per second).
+
+Extra JSON objects (see DESIGN.md "Measurement"):
+  roofline     -- dominant conv kernel family: algorithmic FLOP / HIP-event time of its launches,
+                  collected in a separate instrumented pass of the same step AFTER the timed region
+  cpu_baseline -- the oracle's CPU restatement of the same step (kind "port") on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO / "contrast-you_amd"))
+sys.path.insert(0, str(REPO))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+
+
+class _Transforms:
+    _total_freedom = False
+
+
+class _Dataset:
+    transforms = _Transforms()
+
+
+class SyntheticLoader:
+    """infinite iterator over ONE device-resident batch with the reference's collated schema
+    (contrastyou/data/dataset/base.py:139-164): img/gt are [view1, view2] lists."""
+
+    dataset = _Dataset()
+
+    def __init__(self, n: int, hw: int, num_classes: int, device, seed: int, tag: str):
+        g = torch.Generator().manual_seed(seed)
+        img1, img2 = torch.rand(n, 1, hw, hw, generator=g), torch.rand(n, 1, hw, hw, generator=g)
+        gt = torch.randint(0, num_classes, (n, 1, hw, hw), generator=g)
+        self.batch = {
+            "img": [img1.to(device), img2.to(device)], "gt": [gt.to(device), gt.to(device)],
+            "filename": [[f"{tag}_{i:04d}" for i in range(n)]] * 2,
+            "partition": [[str(i % 3) for i in range(n)]] * 2,
+            "scan_num": [[f"patient{i // 3:03d}_{i % 2:02d}" for i in range(n)]] * 2,
+        }
+        self._n = n
+
+    def __len__(self):
+        return 1 << 30
+
+    def __iter__(self):
+        while True:
+            yield self.batch
+
+
+def build_step(device, rank: int, n_l: int, n_unl: int, hw: int, max_channel: int, bf16: bool = True):
+    from contrastyou.amp import BF16Scaler
+    from contrastyou.arch import UNet
+    from contrastyou.hooks.base import TrainerHook
+    from contrastyou.losses.kl import KL_div
+    from contrastyou.optim import RAdam
+    from semi_seg.hooks import create_infonce_hooks
+
+    torch.manual_seed(10)
+    model = UNet(input_dim=1, num_classes=4, max_channel=max_channel, momentum=0.01).to(device)
+    type(TrainerHook).names.clear()  # allow re-building hooks inside one process
+    hook = create_infonce_hooks(model=model, feature_names="Conv5", weights=1.0, contrast_ons="partition",
+                                spatial_size=1, data_name="acdc").to(device)
+    optimizer = RAdam([{"params": list(model.parameters())}, {"params": list(hook.parameters())}],
+                      lr=3e-5, weight_decay=1e-5)
+    labeled = SyntheticLoader(n_l, hw, 4, device, 1234 + rank, "lab")
+    unlabeled = SyntheticLoader(n_unl, hw, 4, device, 4321 + rank, "unl")
+    scaler = BF16Scaler() if bf16 else torch.amp.GradScaler("cuda", enabled=False)
+    return dict(model=model, hook=hook, optimizer=optimizer, labeled=labeled, unlabeled=unlabeled,
+                criterion=KL_div(), scaler=scaler)
+
+
+def run_epoch(ctx, device, num_batches: int, epoch: int):
+    from semi_seg.epochers import SemiSupervisedEpocher
+    ep = SemiSupervisedEpocher(model=ctx["model"], optimizer=ctx["optimizer"], labeled_loader=ctx["labeled"],
+                               unlabeled_loader=ctx["unlabeled"], sup_criterion=ctx["criterion"],
+                               num_batches=num_batches, cur_epoch=epoch, device=device, two_stage=True,
+                               disable_bn=False, scaler=ctx["scaler"], accumulate_iter=1)
+    ep.init()
+    with ep.register_hook(ctx["hook"]()):
+        ep.run()
+    return ep
+
+
+def kernel_roofline(ctx, device, steps: int = 3):
+    """instrumented pass: HIP events around every conv3x3 launch (on the launch stream)"""
+    from cyhip import ops
+    ops.PROFILE = []
+    run_epoch(ctx, device, steps, 99)
+    torch.cuda.synchronize()
+    rec, ops.PROFILE = ops.PROFILE, None
+    fam = {}
+    for kind, flops, e0, e1 in rec:
+        f = fam.setdefault(kind, [0.0, 0.0, 0])
+        f[0] += flops
+        f[1] += e0.elapsed_time(e1) * 1e-3
+        f[2] += 1
+    if not fam:
+        return None, {}
+    dom = max(fam, key=lambda k: fam[k][1])
+    fl, sec, cnt = fam[dom]
+    ach = fl / sec / 1e12
+    roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "launches_per_step": cnt // steps, "avg_launch_ms": round(sec / cnt * 1e3, 4)}
+    detail = {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / steps * 1e3, 3),
+                  "launches_per_step": v[2] // steps} for k, v in fam.items()}
+    return roof, detail
+
+
+def cpu_baseline(hw: int, max_channel: int):
+    """oracle step (CPU restatement, kind=port) on a bounded sample: 2 labeled + 2 unlabeled slices"""
+    from oracle import losses as ol
+    from oracle import step as ostep
+    from oracle import unet as ou
+    n = 2
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    threads = max(1, min(threads, 16))  # a 1-GPU box gives this job a 16-core share
+    torch.set_num_threads(threads)
+    sd = ou.clone_state_dict(ou.init_state_dict(1, 4, max_channel, seed=1), requires_grad=True)
+    psd = {k: v.requires_grad_(True) for k, v in ol.init_projector_sd(max_channel, 256, 256, seed=2).items()}
+    b = ostep.synthetic_batch(n, n, hw, 4)
+    theta = torch.stack([ol.make_theta(1.1, 20.0, 0.05, -0.05, False, i % 2 == 0) for i in range(n)])
+    params = [v for v in list(sd.values()) + list(psd.values()) if v.requires_grad]
+    opt = torch.optim.RAdam(params, lr=3e-5, weight_decay=1e-5)
+    labels = ol.get_label("partition", "acdc", b["partition"], b["scan"])
+
+    def one():
+        opt.zero_grad()
+        out = ostep.semi_step(sd, psd, labeled_image=b["labeled_image"], labeled_target=b["labeled_target"],
+                              unlabeled_image=b["unlabeled_image"],
+                              unlabeled_image_tf=ol.affine_nearest(b["unlabeled_image_cf"], theta), theta=theta,
+                              labels=labels, momentum=0.01)
+        out["total"].backward()
+        opt.step()
+
+    one()
+    t0, k = time.perf_counter(), 0
+    while k < 3 or (time.perf_counter() - t0 < 10.0 and k < 12):
+        one()
+        k += 1
+    dt = (time.perf_counter() - t0) / k
+    return {"value": round(2 * n / dt, 3), "unit": "slices/s", "cores": threads, "kind": "port",
+            "sample": f"{k} steps of the oracle CPU step at {n}+{n} slices {hw}x{hw}, max_channel={max_channel}, "
+                      f"f32, torch {torch.__version__} CPU ops"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n-labeled", type=int, default=16)
+    ap.add_argument("--n-unlabeled", type=int, default=16)
+    ap.add_argument("--hw", type=int, default=224)
+    ap.add_argument("--max-channel", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
+    ctx = build_step(device, rank, a.n_labeled, a.n_unlabeled, a.hw, a.max_channel)
+    note("model / hooks / optimizer built")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_epoch(ctx, device, max(a.warmup, 1), 0)
+    barrier()
+    note(f"warm-up of {max(a.warmup, 1)} steps done")
+    t0 = time.perf_counter()
+    ep = run_epoch(ctx, device, a.steps, 1)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    metrics = ep.get_metric()
+    note(f"timed {a.steps} steps: {dt / a.steps * 1e3:.2f} ms/step")
+
+    roof, detail = (None, {})
+    if rank == 0 and not a.no_roofline:
+        roof, detail = kernel_roofline(ctx, device)
+        note(f"instrumented pass done: {detail}")
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.hw, a.max_channel)
+        note(f"cpu baseline done: {cpu}")
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        per_step = dt / a.steps
+        slices = (a.n_labeled + a.n_unlabeled) * world
+        passes = (a.n_labeled + 2 * a.n_unlabeled)
+        flops_step = passes * 75.04e9 * (a.hw / 224.0) ** 2 if a.max_channel == 512 else None
+        line = {
+            "metric": "2D slices/sec on ACDC U-Net+InfoNCE step", "value": round(slices / per_step, 2),
+            "unit": "slices/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(per_step * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "C2: ACDC SemiSupervisedEpocher + InfoNCE@Conv5 (partition), two-stage, "
+                                   f"{a.n_labeled} labeled + {a.n_unlabeled} unlabeled 1x{a.hw}x{a.hw} per GPU, "
+                                   f"4 classes, UNet max_channel={a.max_channel}, RAdam",
+                       "global_batch": slices, "network_passes_per_step_per_gpu": passes,
+                       "parallelism": f"dp{world}",
+                       "step_tflops_per_gpu": None if flops_step is None else round(flops_step / 1e12, 3),
+                       "achieved_step_tflops_per_gpu": None if flops_step is None else round(
+                           flops_step / per_step / 1e12, 1)},
+            "roofline": roof, "cpu_baseline": cpu,
+            "kernels": detail,
+            "losses": {g: {k: v for k, v in d.items() if not isinstance(v, dict)} for g, d in metrics.items()},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

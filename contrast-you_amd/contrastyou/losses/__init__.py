@@ -1,0 +1,2 @@
+from .contrastive import SupConLoss1, is_normalized  # noqa: F401
+from .kl import KL_div, Entropy  # noqa: F401

@@ -1,0 +1,111 @@
+"""InfoNCE / supervised-contrastive loss with the interface of
+contrastyou/losses/contrastive.py:23-100 (`SupConLoss1`), computed by the HIP SupCon kernels:
+f32-MFMA similarity GEMM, row statistics with the reference's global-max shift, and the
+(G + G^T) P / t backward -- see csrc/cy_contrast.hip.
+
+    criterion(z1, z2, target=list|Tensor|None, mask=None) -> scalar loss
+    criterion.sim_exp / .sim_logits / .pos_mask / .neg_mask   (materialised on first access)
+
+The reference asserts unit-norm inputs (AssertionError) and raises RuntimeError on a NaN loss,
+both through host syncs.  Here the same conditions are evaluated on the device and checked by
+`validate()`; with `defer_checks=False` (default) validate() runs inside forward, exactly like the
+reference; the training hooks switch to deferred mode and validate once per epoch.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+from torch import Tensor, nn
+
+from cyhip import ops
+from cyhip.functions import SupConFn
+
+
+def is_normalized(feature: Tensor, dim=1) -> bool:
+    norms = feature.norm(dim=dim)
+    return torch.allclose(norms, torch.ones_like(norms))
+
+
+def _encode_target(target, n: int, device) -> Tensor:
+    """labels as int32 codes (equality is all that matters: contrastive.py:41)"""
+    if isinstance(target, Tensor):
+        t = target.detach().reshape(-1)
+        if t.is_floating_point():
+            _, t = torch.unique(t, return_inverse=True)
+        t = t.to(device=device, dtype=torch.int32)
+    else:
+        vals = list(target)
+        lut = {}
+        t = torch.tensor([lut.setdefault(v, len(lut)) for v in vals], dtype=torch.int32, device=device)
+    assert t.numel() == n, (t.numel(), n)
+    return t.contiguous()
+
+
+class SupConLoss1(nn.Module):
+    def __init__(self, temperature=0.07, exclude_other_pos=False):
+        super().__init__()
+        if exclude_other_pos:
+            raise NotImplementedError("exclude_other_pos=True is not on the InfoNCE hook path")
+        self._t = temperature
+        self._exclude_pos = exclude_other_pos
+        self.defer_checks = False
+        self._pending = []
+        self._last = None
+
+    def forward(self, proj_feat1: Tensor, proj_feat2: Tensor, target=None, mask: Optional[Tensor] = None, **kwargs):
+        assert proj_feat1.shape == proj_feat2.shape, (proj_feat1.shape, proj_feat2.shape)
+        ops.require_gpu(proj_feat1, proj_feat2)
+        n = proj_feat1.size(0)
+        dev = proj_feat1.device
+        labels = pos = None
+        if mask is not None:
+            assert mask.shape == torch.Size([n, n])
+            pos = (mask == 1).to(device=dev, dtype=torch.uint8).contiguous()
+        elif target is not None:
+            labels = _encode_target(target, n, dev)
+        else:
+            labels = torch.arange(n, dtype=torch.int32, device=dev)  # SimCLR: only the other view
+        P = torch.cat([proj_feat1, proj_feat2], dim=0)
+        loss, S, stats = SupConFn.apply(P, labels, pos, float(self._t))
+        self._last = (S, stats, labels, pos)
+        # device-side evidence for the reference's two checks
+        norm_err = (S.diagonal() * self._t - 1).abs().max()
+        self._pending.append((norm_err, loss.detach()))
+        if not self.defer_checks:
+            self.validate()
+        return loss
+
+    def validate(self):
+        """raise like the reference: AssertionError (inputs not unit norm), RuntimeError (NaN loss)"""
+        pending, self._pending = self._pending, []
+        if not pending:
+            return
+        errs = torch.stack([p[0] for p in pending]).max()
+        losses = torch.stack([p[1] for p in pending])
+        bad_norm, has_nan = (errs > 1e-4).item(), torch.isnan(losses).any().item()
+        assert not bad_norm, "features need to be normalized first"
+        if has_nan:
+            raise RuntimeError(losses)
+
+    def _matrices(self):
+        if self._last is None:
+            raise AttributeError("call the criterion first")
+        S, stats, labels, pos = self._last
+        return ops.supcon_matrices(S, stats, labels, pos)
+
+    @property
+    def sim_logits(self) -> Tensor:
+        return self._matrices()[0]
+
+    @property
+    def sim_exp(self) -> Tensor:
+        return self._matrices()[1]
+
+    @property
+    def pos_mask(self) -> Tensor:
+        return self._matrices()[2]
+
+    @property
+    def neg_mask(self) -> Tensor:
+        return self._matrices()[3]

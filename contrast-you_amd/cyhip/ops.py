@@ -17,6 +17,26 @@ from ._lib import CY_BF16, CY_F32, CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2, Conv
 
 _DT = {torch.float32: CY_F32, torch.bfloat16: CY_BF16}
 
+# bench.py instrumentation: when a list, every conv launch appends (family, algorithmic FLOPs,
+# start event, end event); events are recorded on the launch stream (torch's current stream).
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, kind: str, flops: float):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.append((kind, flops, e0, e1))
+
 
 def dtype_code(dt: torch.dtype) -> int:
     try:
@@ -132,8 +152,10 @@ def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, 
     if want_stats:
         npart = _lib.call("cy_conv3x3_num_partials", C.byref(d))
         stats = _f32(npart * 2 * Cout, dev).view(npart, 2, Cout)
+    ev = _prof_begin()
     _lib.call("cy_conv3x3_fwd", C.byref(d), src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
               wf.data_ptr(), out.data_ptr(), _ptr(out2), _ptr(stats), _stream())
+    _prof_end(ev, "conv3x3_igemm", 2.0 * N * H * W * 9 * (C1 + C2) * Cout)
     if split:
         return (out, out2), None
     return out, stats
@@ -150,8 +172,10 @@ def conv3x3_wgrad(src1: Tensor, src2: Optional[Tensor], dy: Tensor, *, mode: int
     nbytes = _lib.load().cy_conv3x3_wgrad_ws_bytes(C.byref(d))
     ws = _ws(nbytes, src1.device)
     dw = torch.empty((Cout, C1 + C2, 3, 3), dtype=torch.float32, device=src1.device)
+    ev = _prof_begin()
     _lib.call("cy_conv3x3_wgrad", C.byref(d), src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
               dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    _prof_end(ev, "conv3x3_wgrad", 2.0 * N * H * W * 9 * (C1 + C2) * Cout)
     return dw
 
 

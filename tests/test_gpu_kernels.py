@@ -1,0 +1,416 @@
+"""Parity of every HIP kernel family (called through the C ABI via cyhip.ops) against the
+oracle / stock torch CPU ops on the same seeded inputs.  f32 kernels: tight tolerances
+(f32 MFMA = exact fmaf chains); bf16 kernels: inputs are bf16-representable, arithmetic is
+f32-accumulate, so the only differences are accumulation order and the final bf16 rounding
+(tolerance 1e-2 of the tensor's max magnitude, stated per test)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from cyhip import ops
+    return ops
+
+
+def nhwc(t, dtype=None):
+    """CPU NCHW tensor -> GPU tensor with NHWC memory"""
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def cpu(t):
+    return t.detach().float().cpu()
+
+
+def rnd(*shape, gen, scale=1.0):
+    return (torch.rand(*shape, generator=gen) * 2 - 1) * scale
+
+
+def assert_close(a, b, rel, what=""):
+    a, b = cpu(a).double(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = b.abs().max().item() + 1e-30
+    err = (a - b).abs().max().item()
+    assert err <= rel * scale, f"{what}: max err {err:.3e} > {rel:.1e} * {scale:.3e}"
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2}
+
+CONV_CASES = [
+    # N, H, W, C1, C2, Cout, mode, prologue
+    (2, 32, 32, 32, 0, 32, 0, 0),     # 8x32 tile, BN 32, small-K (bf16)
+    (2, 32, 32, 64, 0, 64, 0, 1),     # 8x32 tile, BN 64, prologue
+    (1, 16, 64, 64, 64, 128, 0, 0),   # 8x32 tile, BN 128, concat
+    (2, 16, 16, 16, 0, 8, 0, 0),      # 16x16 tile, tiny channels (padding paths)
+    (2, 16, 16, 32, 0, 64, 1, 0),     # 16x16 tile, pool on load
+    (2, 16, 16, 128, 0, 256, 2, 0),   # 16x16 tile, upsample on load, BN 128 two cout tiles
+    (3, 24, 8, 64, 0, 128, 0, 0),     # 32x8 tile, rows not a multiple of TH, spans images
+    (2, 28, 28, 64, 64, 128, 0, 0),   # 8x28 tile (7 MFMA tiles), concat
+    (3, 14, 14, 128, 0, 256, 0, 1),   # 16x14 tile spanning images, prologue
+    (2, 14, 14, 32, 0, 32, 1, 0),     # generic masked 16x16 tile on 14x14, pool on load
+    (1, 20, 20, 40, 24, 48, 0, 0),    # generic masked tile, odd channel counts, concat
+    (2, 14, 14, 256, 0, 128, 0, 0),   # K = 4 chunks
+]
+
+
+def conv_ref(x1, x2, w, mode, scale, shift):
+    a = x1
+    if scale is not None:
+        a = F.relu(a * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    if mode == 1:
+        a = F.max_pool2d(a, 2, 2)
+    elif mode == 2:
+        a = F.interpolate(a, scale_factor=2, mode="nearest")
+    if x2 is not None:
+        a = torch.cat((a, x2), 1)
+    return F.conv2d(a, w, None, 1, 1), a
+
+
+def make_conv_case(case, dtype, seed):
+    N, H, W, C1, C2, Cout, mode, pro = case
+    g = torch.Generator().manual_seed(seed)
+    sh, sw = (2 * H, 2 * W) if mode == 1 else ((H // 2, W // 2) if mode == 2 else (H, W))
+    x1 = rnd(N, C1, sh, sw, gen=g).to(dtype).float()
+    x2 = rnd(N, C2, H, W, gen=g).to(dtype).float() if C2 else None
+    w = (rnd(Cout, C1 + C2, 3, 3, gen=g) / math.sqrt(9 * (C1 + C2))).to(dtype).float()
+    scale = shift = None
+    if pro:
+        scale = rnd(C1, gen=g) + 0.2
+        shift = rnd(C1, gen=g) * 0.3
+    return x1, x2, w, scale, shift
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3_fwd_and_stats(case, dtype):
+    ops = _ops()
+    N, H, W, C1, C2, Cout, mode, pro = case
+    x1, x2, w, scale, shift = make_conv_case(case, dtype, 1)
+    if pro and dtype == torch.bfloat16:
+        # the kernel rounds relu(scale*x+shift) to bf16 before the MFMA: do the same
+        a = F.relu(x1 * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(dtype).float()
+        ref = F.conv2d(a, w, None, 1, 1)
+    else:
+        ref, _ = conv_ref(x1, x2, w, mode, scale, shift)
+    wf, _ = ops.pack_weights(w.to(DEV), dtype)
+    out, stats = ops.conv3x3_fwd(nhwc(x1, dtype), None if x2 is None else nhwc(x2, dtype), wf, Cout,
+                                 mode=mode, scale=None if scale is None else scale.to(DEV),
+                                 shift=None if shift is None else shift.to(DEV))
+    torch.cuda.synchronize()
+    assert_close(out, ref, TOL[dtype], f"conv {case} {dtype}")
+    # statistics partials: sums of the (rounded) outputs the kernel itself stored
+    o = cpu(out).double()
+    s = cpu(stats).double().sum(0)
+    count = N * H * W
+    assert_close(s[0] / count, o.sum(dim=(0, 2, 3)) / count, 1e-4, "stat sum")
+    assert_close(s[1] / count, (o * o).sum(dim=(0, 2, 3)) / count, 1e-4, "stat sumsq")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3x3_dgrad_with_split(dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    N, H, W, Cin1, Cin2, Cout = 2, 16, 16, 32, 64, 64
+    w = (rnd(Cout, Cin1 + Cin2, 3, 3, gen=g) / 20).to(dtype).float()
+    dy = rnd(N, Cout, H, W, gen=g).to(dtype).float()
+    ref = F.conv_transpose2d(dy, w, None, 1, 1)  # = dgrad of a stride-1 pad-1 conv
+    _, wd = ops.pack_weights(w.to(DEV), dtype)
+    (d1, d2), _ = ops.conv3x3_fwd(nhwc(dy, dtype), None, wd, Cin1 + Cin2, want_stats=False, split=Cin1)
+    assert_close(d1, ref[:, :Cin1], TOL[dtype], "dgrad part 1")
+    assert_close(d2, ref[:, Cin1:], TOL[dtype], "dgrad part 2")
+    full, _ = ops.conv3x3_fwd(nhwc(dy, dtype), None, wd, Cin1 + Cin2, want_stats=False)
+    assert_close(full, ref, TOL[dtype], "dgrad full")
+
+
+WGRAD_CASES = [
+    (2, 32, 32, 32, 0, 32, 0, 0),
+    (2, 16, 16, 64, 0, 64, 0, 1),
+    (1, 16, 32, 64, 64, 32, 0, 0),
+    (2, 16, 16, 32, 0, 64, 1, 0),
+    (2, 16, 16, 64, 0, 32, 2, 0),
+    (3, 14, 14, 128, 0, 64, 0, 0),
+    (2, 28, 28, 16, 0, 8, 0, 0),
+    (1, 20, 20, 40, 24, 48, 0, 0),
+    (2, 56, 56, 32, 0, 32, 0, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv3x3_wgrad(case, dtype):
+    ops = _ops()
+    N, H, W, C1, C2, Cout, mode, pro = case
+    x1, x2, w, scale, shift = make_conv_case(case, dtype, 3)
+    g = torch.Generator().manual_seed(9)
+    dy = rnd(N, Cout, H, W, gen=g).to(dtype).float()
+    wv = w.clone().requires_grad_(True)
+    if pro and dtype == torch.bfloat16:
+        a = F.relu(x1 * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(dtype).float()
+        y = F.conv2d(a, wv, None, 1, 1)
+    else:
+        y, _ = conv_ref(x1, x2, wv, mode, scale, shift)
+    (y * dy).sum().backward()
+    dw = ops.conv3x3_wgrad(nhwc(x1, dtype), None if x2 is None else nhwc(x2, dtype), nhwc(dy, dtype),
+                           mode=mode, scale=None if scale is None else scale.to(DEV),
+                           shift=None if shift is None else shift.to(DEV))
+    assert_close(dw, wv.grad, 2e-5 if dtype == torch.float32 else 2e-3, f"wgrad {case} {dtype}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout", [(1, 32), (3, 8), (1, 16)])
+def test_first_conv_fwd_wgrad(cin, cout, dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(3, cin, 24, 40, generator=g)
+    w = (rnd(cout, cin, 3, 3, gen=g) / 3).requires_grad_(True)
+    ref = F.conv2d(x, w, None, 1, 1)
+    out, stats = ops.conv_first_fwd(x.to(DEV), w.detach().to(DEV), dtype)
+    assert_close(out, ref, TOL[dtype], "first conv")
+    o = cpu(out).double()
+    s = cpu(stats).double().sum(0)
+    assert_close(s[0], o.sum(dim=(0, 2, 3)), 1e-4, "first conv stat sum")
+    assert_close(s[1], (o * o).sum(dim=(0, 2, 3)), 1e-4, "first conv stat sumsq")
+    dy = rnd(3, cout, 24, 40, gen=g).to(dtype).float()
+    (ref * dy).sum().backward()
+    dw = ops.conv_first_wgrad(x.to(DEV), nhwc(dy, dtype))
+    assert_close(dw, w.grad, 2e-5 if dtype == torch.float32 else 2e-3, "first conv wgrad")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,hw", [(32, 24), (8, 12), (512, 6), (40, 10)])
+def test_bn_relu_fwd_bwd(C, hw, dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    N = 3
+    y = (rnd(N, C, hw, hw, gen=g) * 2 + 0.3).to(dtype).float().requires_grad_(True)
+    gamma = (rnd(C, gen=g) + 1.2).requires_grad_(True)
+    beta = (rnd(C, gen=g) * 0.5).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    out_ref = F.relu(F.batch_norm(y, rm, rv, gamma, beta, True, 0.01, 1e-5))
+    da = rnd(N, C, hw, hw, gen=g).to(dtype).float()
+    (out_ref * da).sum().backward()
+    # statistics exactly as the conv epilogue would emit them (one partial here)
+    yd = y.detach().double()
+    part = torch.stack([yd.sum(dim=(0, 2, 3)), (yd * yd).sum(dim=(0, 2, 3))]).float().view(1, 2, C).to(DEV)
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    count = N * hw * hw
+    scale, shift, mean, invstd = ops.bn_finalize(part, count, gamma.detach().to(DEV), beta.detach().to(DEV),
+                                                 rmd, rvd, 0.01, 1e-5, True, True, C, DEV)
+    assert_close(rmd, rm, 1e-5, "running mean")
+    assert_close(rvd, rv, 1e-5, "running var")
+    yg = nhwc(y.detach(), dtype)
+    out = ops.bn_relu_apply(yg, scale, shift)
+    assert_close(out, out_ref, 1e-5 if dtype == torch.float32 else 1e-2, "bn relu apply")
+    dy, dgamma, dbeta = ops.bn_relu_bwd(nhwc(da, dtype), yg, scale, shift, mean, invstd, True)
+    assert_close(dgamma, gamma.grad, 1e-4, "dgamma")
+    assert_close(dbeta, beta.grad, 1e-4, "dbeta")
+    assert_close(dy, y.grad, 1e-4 if dtype == torch.float32 else 1.2e-2, "bn bwd dy")
+    # eval-mode scale/shift from running stats, no update
+    rm2, rv2 = rmd.clone(), rvd.clone()
+    s2, h2, _, _ = ops.bn_finalize(None, count, gamma.detach().to(DEV), beta.detach().to(DEV), rm2, rv2, 0.01,
+                                   1e-5, False, False, C, DEV)
+    ref_eval = F.relu(F.batch_norm(y.detach(), cpu(rmd), cpu(rvd), gamma.detach(), beta.detach(), False, 0.0, 1e-5))
+    assert_close(ops.bn_relu_apply(yg, s2, h2), ref_eval, 1e-5 if dtype == torch.float32 else 1e-2, "bn eval")
+    assert torch.equal(rm2, rmd) and torch.equal(rv2, rvd)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pool_upsample_bwd(dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = F.relu(rnd(2, 16, 12, 20, gen=g)).to(dtype).float().requires_grad_(True)  # zeros -> ties
+    p = F.max_pool2d(x, 2, 2)
+    dp = rnd(2, 16, 6, 10, gen=g).to(dtype).float()
+    (p * dp).sum().backward()
+    dx = ops.maxpool2_bwd(nhwc(x.detach(), dtype), nhwc(dp, dtype))
+    assert_close(dx, x.grad, 1e-6, "maxpool bwd")
+    add = rnd(2, 16, 12, 20, gen=g).to(dtype).float()
+    dx2 = ops.maxpool2_bwd(nhwc(x.detach(), dtype), nhwc(dp, dtype), nhwc(add, dtype))
+    assert_close(dx2, x.grad + add, 1e-6 if dtype == torch.float32 else 1e-2, "maxpool bwd + add")
+    u = rnd(2, 16, 6, 10, gen=g).requires_grad_(True)
+    du = rnd(2, 16, 12, 20, gen=g).to(dtype).float()
+    (F.interpolate(u, scale_factor=2, mode="nearest") * du).sum().backward()
+    assert_close(ops.upsample2_bwd(nhwc(du, dtype)), u.grad, 1e-6 if dtype == torch.float32 else 1e-2, "upsample bwd")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("K", [4, 2, 5, 8])
+def test_head_and_losses(K, dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    N, C, H, W = 2, 32, 16, 24
+    x = rnd(N, C, H, W, gen=g).to(dtype).float().requires_grad_(True)
+    w = (rnd(K, C, 1, 1, gen=g) / 4).requires_grad_(True)
+    b = (rnd(K, gen=g) / 4).requires_grad_(True)
+    tgt = torch.randint(0, K, (N, H, W), generator=g)
+    logits_ref = F.conv2d(x, w, b)
+    from oracle.losses import sup_loss, softmax_mse
+    loss_ref = sup_loss(logits_ref, tgt)
+    loss_ref.backward()
+    xg = nhwc(x.detach(), dtype)
+    logits = ops.head_fwd(xg, w.detach().to(DEV), b.detach().to(DEV))
+    assert_close(logits, logits_ref, 1e-5, "head fwd")
+    loss = ops.softmax_kl_fwd(logits, tgt.to(DEV), 1e-16)
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * max(1.0, abs(loss_ref.item()))
+    gs = torch.ones(1, device=DEV)
+    dl = ops.softmax_kl_bwd(logits, tgt.to(DEV), gs, 1e-16)
+    dx, dw, db = ops.head_bwd(xg, w.detach().to(DEV), dl, True, True)
+    assert_close(dw, w.grad, 1e-4, "head dw")
+    assert_close(db, b.grad, 1e-4, "head db")
+    assert_close(dx, x.grad, 1e-4 if dtype == torch.float32 else 1e-2, "head dx")
+    # softmax-MSE pair
+    a = rnd(N, K, H, W, gen=g).requires_grad_(True)
+    c = rnd(N, K, H, W, gen=g).requires_grad_(True)
+    m_ref = softmax_mse(a, c)
+    m_ref.backward()
+    ag, cg = nhwc(a.detach()), nhwc(c.detach())
+    m = ops.softmax_mse_fwd(ag, cg)
+    assert abs(m.item() - m_ref.item()) < 1e-6
+    da, dc = ops.softmax_mse_bwd(ag, cg, gs, True, True)
+    assert_close(da, a.grad, 1e-4, "mse da")
+    assert_close(dc, c.grad, 1e-4, "mse db")
+    # dice counts
+    counts = cpu(ops.dice_counts(logits, tgt.to(DEV))).long()
+    pred = logits_ref.detach().argmax(1)
+    for n in range(N):
+        for k in range(K):
+            inter = ((pred[n] == k) & (tgt[n] == k)).sum().item()
+            union = (pred[n] == k).sum().item() + (tgt[n] == k).sum().item()
+            assert counts[n, k, 0].item() == inter and counts[n, k, 1].item() == union
+
+
+def test_projector_pieces(golden_dir):
+    ops = _ops()
+    from oracle import losses as ol
+    gld = np.load(golden_dir / "heads_losses.npz")
+    psd = ol.init_projector_sd(128, 256, 256, seed=3)
+    feat = torch.from_numpy(gld["proj_feat"])
+    fg = nhwc(feat)
+    pooled = ops.avgpool_fwd(fg)
+    assert_close(pooled, feat.mean(dim=(2, 3)), 1e-6, "avgpool")
+    h = ops.linear_fwd(pooled, psd["_header.2.weight"].to(DEV), psd["_header.2.bias"].to(DEV), 1, 0.01)
+    o = ops.linear_fwd(h, psd["_header.4.weight"].to(DEV), psd["_header.4.bias"].to(DEV), 0, 0.0)
+    z, norms = ops.l2norm_fwd(o)
+    assert_close(z, torch.from_numpy(gld["proj_z"]), 2e-5, "projection head output (golden)")
+    # backward chain against the golden gradients of the reference module
+    gz = torch.linspace(-1, 1, z.numel()).view_as(z).to(DEV)
+    do = ops.l2norm_bwd(o, norms, gz)
+    dh, dw4, db4 = ops.linear_bwd(h, psd["_header.4.weight"].to(DEV), o, do, 0, 0.0, True, True)
+    dp, dw2, db2 = ops.linear_bwd(pooled, psd["_header.2.weight"].to(DEV), h, dh, 1, 0.01, True, True)
+    dfeat = ops.avgpool_bwd(dp, tuple(feat.shape), torch.float32)
+    assert_close(dw4, torch.from_numpy(gld["proj_grad__header.4.weight"]), 1e-4, "dW4")
+    assert_close(db4, torch.from_numpy(gld["proj_grad__header.4.bias"]), 1e-4, "db4")
+    assert_close(dw2, torch.from_numpy(gld["proj_grad__header.2.weight"]), 1e-4, "dW2")
+    assert_close(db2, torch.from_numpy(gld["proj_grad__header.2.bias"]), 1e-4, "db2")
+    assert_close(dfeat, torch.from_numpy(gld["proj_dfeat"]), 1e-4, "dfeat")
+
+
+def test_sgemm():
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    A, B = rnd(70, 45, gen=g), rnd(100, 45, gen=g)
+    assert_close(ops.sgemm(A.to(DEV), B.to(DEV), 0.5, True), 0.5 * A @ B.t(), 1e-6, "sgemm NT")
+    B2 = rnd(45, 33, gen=g)
+    assert_close(ops.sgemm(A.to(DEV), B2.to(DEV), 2.0, False), 2.0 * A @ B2, 1e-6, "sgemm NN")
+
+
+def test_supcon_against_reference_goldens(golden_dir):
+    ops = _ops()
+    gld = np.load(golden_dir / "heads_losses.npz")
+    z1, z2 = torch.from_numpy(gld["sc_z1"]), torch.from_numpy(gld["sc_z2"])
+    P = torch.cat([z1, z2]).to(DEV)
+    n = z1.shape[0]
+    gs = torch.ones(1, device=DEV)
+    for tag, target in (("simclr", list(range(n))), ("partition", [0, 1, 2, 0, 1, 2, 0, 1]),
+                        ("patient", [0, 1, 2, 3, 3, 4, 5, 6])):
+        lab = torch.tensor(target, dtype=torch.int32, device=DEV)
+        loss, S, stats = ops.supcon_fwd(P, lab, None, 0.07)
+        assert abs(loss.item() - float(gld[f"sc_{tag}_loss"])) < 1e-5 * abs(float(gld[f"sc_{tag}_loss"])), tag
+        dP = ops.supcon_bwd(P, lab, None, S, stats, gs, 0.07)
+        assert_close(dP[:n], torch.from_numpy(gld[f"sc_{tag}_dz1"]), 2e-4, f"{tag} dz1")
+        assert_close(dP[n:], torch.from_numpy(gld[f"sc_{tag}_dz2"]), 2e-4, f"{tag} dz2")
+        sl, se, po, ne = ops.supcon_matrices(S, stats, lab, None)
+        assert_close(sl, torch.from_numpy(gld[f"sc_{tag}_sim_logits"]), 1e-5, "sim_logits")
+        assert_close(se, torch.from_numpy(gld[f"sc_{tag}_sim_exp"]), 1e-5, "sim_exp")
+        assert_close(po, torch.from_numpy(gld[f"sc_{tag}_pos"]), 0, "pos_mask")
+        assert_close(ne, torch.from_numpy(gld[f"sc_{tag}_neg"]), 0, "neg_mask")
+    pm = torch.from_numpy(gld["sc_mask"]).to(torch.uint8).to(DEV)
+    loss, S, stats = ops.supcon_fwd(P, None, pm, 0.07)
+    assert abs(loss.item() - float(gld["sc_mask_loss"])) < 1e-5 * abs(float(gld["sc_mask_loss"]))
+    dP = ops.supcon_bwd(P, None, pm, S, stats, gs, 0.07)
+    assert_close(dP[:n], torch.from_numpy(gld["sc_mask_dz1"]), 2e-4, "mask dz1")
+
+
+def test_supcon_large_against_oracle():
+    """512 rows (C5-style) vs the oracle in f64."""
+    ops = _ops()
+    from oracle.losses import supcon_loss
+    g = torch.Generator().manual_seed(10)
+    n, D = 256, 256
+    z1 = F.normalize(torch.randn(n, D, generator=g), dim=1)
+    z2 = F.normalize(z1 + 0.3 * torch.randn(n, D, generator=g), dim=1)
+    target = [i % 3 for i in range(n)]
+    a, b = z1.double().requires_grad_(True), z2.double().requires_grad_(True)
+    ref = supcon_loss(a, b, target=target)
+    ref.backward()
+    P = torch.cat([z1, z2]).to(DEV)
+    lab = torch.tensor(target, dtype=torch.int32, device=DEV)
+    loss, S, stats = ops.supcon_fwd(P, lab, None, 0.07)
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+    dP = ops.supcon_bwd(P, lab, None, S, stats, torch.ones(1, device=DEV), 0.07)
+    assert_close(dP, torch.cat([a.grad, b.grad]).float(), 1e-4, "large supcon dP")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_affine_fwd_bwd(dtype):
+    ops = _ops()
+    from oracle.losses import affine_nearest, make_theta
+    g = torch.Generator().manual_seed(12)
+    N, C, H, W = 4, 12, 14, 14
+    thetas = torch.stack([make_theta(1.0, 0.0, 0.0, 0.0, False, False),
+                          make_theta(1.25, 30.0, 0.08, -0.05, False, True),
+                          make_theta(0.82, -41.0, -0.1, 0.1, True, False),
+                          make_theta(1.1, 12.0, 0.02, 0.03, True, True)])
+    x = rnd(N, C, H, W, gen=g).to(dtype).float().requires_grad_(True)
+    ref = affine_nearest(x, thetas)
+    dout = rnd(N, C, H, W, gen=g).to(dtype).float()
+    (ref * dout).sum().backward()
+    out = ops.affine_fwd(nhwc(x.detach(), dtype), thetas.to(DEV))
+    assert_close(out, ref, 1e-6, "affine fwd")
+    dx = ops.affine_bwd(nhwc(dout, dtype), thetas.to(DEV))
+    assert_close(dx, x.grad, 1e-6 if dtype == torch.float32 else 1e-2, "affine bwd")
+    if dtype == torch.float32:
+        img = torch.rand(N, 1, 32, 32, generator=g)
+        gam = torch.tensor([0.5, 1.0, 1.7, 2.0])
+        refi = affine_nearest(img, thetas, gam)
+        outi = ops.affine_fwd(img.to(DEV), thetas.to(DEV), gam.to(DEV))
+        assert_close(outi, refi, 1e-5, "affine + gamma image")
+
+
+def test_ema_and_radam():
+    ops = _ops()
+    from oracle.losses import ema_update
+    g = torch.Generator().manual_seed(13)
+    t, s = rnd(5000, gen=g), rnd(5000, gen=g)
+    tg = t.to(DEV)
+    ops.ema_update(tg, s.to(DEV), 0.99, 1e-5)
+    assert_close(tg, ema_update(t, s, 0.99, 1e-5), 1e-6, "ema")
+    p = rnd(3000, gen=g).requires_grad_(True)
+    opt = torch.optim.RAdam([p], lr=1e-3, weight_decay=1e-5)
+    pg = p.detach().clone().to(DEV)
+    m, v = torch.zeros_like(pg), torch.zeros_like(pg)
+    for step in range(1, 9):
+        grad = rnd(3000, gen=g)
+        p.grad = grad.clone()
+        opt.step()
+        ops.radam_step(pg, grad.to(DEV), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-5, step)
+        assert_close(pg, p.detach(), 1e-6, f"radam step {step}")
