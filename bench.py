@@ -126,7 +126,8 @@ def kernel_roofline(ctx, device, steps: int = 3):
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
             "launches_per_step": cnt // steps, "avg_launch_ms": round(sec / cnt * 1e3, 4)}
     detail = {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / steps * 1e3, 3),
-                  "launches_per_step": v[2] // steps} for k, v in fam.items()}
+                  "launches_per_step": v[2] // steps, "tflop_per_step": round(v[0] / steps / 1e12, 4)}
+              for k, v in fam.items()}
     return roof, detail
 
 
@@ -236,7 +237,11 @@ def main():
         per_step = dt / a.steps
         slices = (a.n_labeled + a.n_unlabeled) * world
         passes = (a.n_labeled + 2 * a.n_unlabeled)
-        flops_step = passes * 75.04e9 * (a.hw / 224.0) ** 2 if a.max_channel == 512 else None
+        # algorithmic conv FLOPs actually executed per step (forward of all passes, backward only
+        # where a loss reaches: the decoder of the unlabeled pass gets no gradient in this config),
+        # summed over the instrumented launches; falls back to the SURVEY formula without them
+        flops_step = sum(v["tflop_per_step"] for v in detail.values()) * 1e12 if detail else (
+            passes * 75.04e9 * (a.hw / 224.0) ** 2 if a.max_channel == 512 else None)
         line = {
             "metric": "2D slices/sec on ACDC U-Net+InfoNCE step", "value": round(slices / per_step, 2),
             "unit": "slices/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -27,7 +27,7 @@ import torch
 from torch import Tensor, nn
 
 from cyhip import ops
-from cyhip.functions import ChainCfg, ConvChainFn, HeadFn
+from cyhip.functions import ChainCfg, ConvChainFn, HeadFn, defer_batch_counters
 
 from ._base import _check_params, _complete_arch_start2end
 from .utils import get_bn_track, get_requires_grad
@@ -150,6 +150,10 @@ class UNet(nn.Module):
             raise ValueError(f"expected [N,{self._input_dim},H,W], got {tuple(x.shape)}")
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise ValueError("spatial dims must be multiples of 16 (four 2x2 poolings)")
+        with defer_batch_counters():
+            return self._forward(x, until)
+
+    def _forward(self, x: Tensor, until: Optional[str]):
         e1 = self._Conv1(x)
         if until == "Conv1":
             return e1

@@ -25,39 +25,47 @@ __device__ __forceinline__ bool affine_src(const float* th, int oy, int ox, int 
   return true;
 }
 
+// thread = (output pixel, group of 8 channels)
 template <typename T>
 __global__ void __launch_bounds__(256)
     affine_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, const float* __restrict__ theta,
                       const float* __restrict__ gamma, int N, int C, int H, int W) {
-  const long total = (long)N * H * W;
-  for (long p = blockIdx.x * 256L + threadIdx.x; p < total; p += (long)gridDim.x * 256L) {
+  const int G = (C + 7) / 8;
+  const long total = (long)N * H * W * G;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const int g = (int)(e % G);
+    const long p = e / G;
     const int ox = (int)(p % W);
     const int oy = (int)((p / W) % H);
     const int n = (int)(p / ((long)W * H));
     int iy, ix;
     const bool ok = affine_src(theta + n * 6, oy, ox, H, W, &iy, &ix);
-    T* op = out + p * C;
-    if (ok) {
-      const T* ip = x + ((long)(n * H + iy) * W + ix) * C;
-      if (gamma) {
-        const float g = gamma[n];
-        for (int c = 0; c < C; ++c) op[c] = from_f32<T>(powf(to_f32<T>(ip[c]), g));
-      } else {
-        for (int c = 0; c < C; ++c) op[c] = ip[c];
+    const int c0 = g * 8;
+    T* op = out + p * C + c0;
+    const T* ip = x + ((long)(n * H + iy) * W + ix) * C + c0;
+    const float gm = gamma ? gamma[n] : 1.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (c0 + j < C) {
+        float v = ok ? to_f32<T>(ip[j]) : 0.f;
+        if (gamma && ok) v = powf(v, gm);
+        op[j] = from_f32<T>(v);
       }
-    } else {
-      for (int c = 0; c < C; ++c) op[c] = from_f32<T>(0.f);
     }
   }
 }
 
-// adjoint in gather form: every input pixel scans the output window that can map onto it
+// adjoint in gather form: every (input pixel, 8-channel group) scans the output window that can
+// map onto the pixel and sums the matching gradients in scan order (deterministic, no atomics)
 template <typename T>
 __global__ void __launch_bounds__(256)
     affine_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx,
                       const float* __restrict__ theta, int N, int C, int H, int W) {
-  const long total = (long)N * H * W;
-  for (long p = blockIdx.x * 256L + threadIdx.x; p < total; p += (long)gridDim.x * 256L) {
+  const int G = (C + 7) / 8;
+  const long total = (long)N * H * W * G;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const int g = (int)(e % G);
+    const long p = e / G;
     const int ix = (int)(p % W);
     const int iy = (int)((p / W) % H);
     const int n = (int)(p / ((long)W * H));
@@ -66,7 +74,6 @@ __global__ void __launch_bounds__(256)
     const float xi = (2.f * ix + 1.f) / (float)W - 1.f;
     const float yi = (2.f * iy + 1.f) / (float)H - 1.f;
     const float det = th[0] * th[4] - th[1] * th[3];
-    T* dp = dx + p * C;
     int x0 = 0, x1 = -1, y0 = 0, y1 = -1;  // empty window when theta is singular
     if (fabsf(det) > 1e-12f) {
       const float i00 = th[4] / det, i01 = -th[1] / det, i10 = -th[3] / det, i11 = th[0] / det;
@@ -84,24 +91,24 @@ __global__ void __launch_bounds__(256)
       if (x1 > W - 1) x1 = W - 1;
       if (y1 > H - 1) y1 = H - 1;
     }
-    for (int c0 = 0; c0 < C; c0 += 8) {
-      float acc[8];
+    const int c0 = g * 8;
+    float acc[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-      for (int oy = y0; oy <= y1; ++oy)
-        for (int ox = x0; ox <= x1; ++ox) {
-          int sy2, sx2;
-          if (affine_src(th, oy, ox, H, W, &sy2, &sx2) && sy2 == iy && sx2 == ix) {
-            const T* gp = dout + ((long)(n * H + oy) * W + ox) * C + c0;
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int oy = y0; oy <= y1; ++oy)
+      for (int ox = x0; ox <= x1; ++ox) {
+        int sy2, sx2;
+        if (affine_src(th, oy, ox, H, W, &sy2, &sx2) && sy2 == iy && sx2 == ix) {
+          const T* gp = dout + ((long)(n * H + oy) * W + ox) * C + c0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (c0 + j < C) acc[j] += to_f32<T>(gp[j]);
-          }
+          for (int j = 0; j < 8; ++j)
+            if (c0 + j < C) acc[j] += to_f32<T>(gp[j]);
         }
+      }
+    T* dp = dx + p * C + c0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (c0 + j < C) dp[c0 + j] = from_f32<T>(acc[j]);
-    }
+    for (int j = 0; j < 8; ++j)
+      if (c0 + j < C) dp[j] = from_f32<T>(acc[j]);
   }
 }
 
@@ -155,7 +162,7 @@ int cy_affine_nearest_fwd(const void* x, void* out, const float* theta, const fl
                           int C, int H, int W, int dtype, void* stream) {
   if (!x || !out || !theta || N <= 0 || C <= 0 || H <= 0 || W <= 0) return CY_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = grid_for((long)N * H * W);
+  const int grid = grid_for((long)N * H * W * ((C + 7) / 8));
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(affine_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x,
                        (bf16*)out, theta, gamma, N, C, H, W);
@@ -172,7 +179,7 @@ int cy_affine_nearest_bwd(const void* dout, void* dx, const float* theta, int N,
                           int W, int dtype, void* stream) {
   if (!dout || !dx || !theta || N <= 0 || C <= 0 || H <= 0 || W <= 0) return CY_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = grid_for((long)N * H * W);
+  const int grid = grid_for((long)N * H * W * ((C + 7) / 8));
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(affine_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout,
                        (bf16*)dx, theta, N, C, H, W);

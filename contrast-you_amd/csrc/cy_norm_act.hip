@@ -10,18 +10,19 @@
 namespace {
 
 // ------------------------------------------------------------------ finalize
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
     bn_finalize_kernel(const float* __restrict__ partials, int P, int C, double count,
                        const float* __restrict__ gamma, const float* __restrict__ beta,
                        float* running_mean, float* running_var, float momentum, float eps,
                        int use_batch_stats, int update_running, float* scale, float* shift,
                        float* mean_out, float* invstd_out) {
-  __shared__ double sred[2][16][16];
+  // block = 16 channels x 64 partial slices; fixed summation order (slice-major) => deterministic
+  __shared__ double sred[2][64][16];
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C && use_batch_stats) {
-    for (int p = sl; p < P; p += 16) {
+    for (int p = sl; p < P; p += 64) {
       s1 += (double)partials[((size_t)p * 2 + 0) * C + c];
       s2 += (double)partials[((size_t)p * 2 + 1) * C + c];
     }
@@ -33,7 +34,7 @@ __global__ void __launch_bounds__(256)
     double mean, var;
     if (use_batch_stats) {
       double t1 = 0.0, t2 = 0.0;
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 0; q < 64; ++q) {
         t1 += sred[0][q][cl];
         t2 += sred[1][q][cl];
       }
@@ -187,8 +188,10 @@ __global__ void __launch_bounds__(256)
 }
 
 __global__ void __launch_bounds__(256)
-    bn_bwd_finalize_kernel(const float* __restrict__ partials, int P, int C, float* dgamma,
-                           float* dbeta) {
+    bn_bwd_finalize_kernel(const float* __restrict__ partials, int P, int C,
+                           const float* __restrict__ scale, const float* __restrict__ mean,
+                           const float* __restrict__ invstd, double count, int batch_stats,
+                           float* dgamma, float* dbeta, int accumulate, float* __restrict__ coef) {
   __shared__ double sred[2][16][16];
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
@@ -208,8 +211,17 @@ __global__ void __launch_bounds__(256)
       t1 += sred[0][q][cl];
       t2 += sred[1][q][cl];
     }
-    dbeta[c] = (float)t1;
-    dgamma[c] = (float)t2;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)t1 : (float)t1;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)t2 : (float)t2;
+    // dy = scale*dz + k1*y + k0   (k1 = k0 = 0 when BN used running statistics)
+    double k1 = 0.0, k0 = 0.0;
+    if (batch_stats) {
+      const double sc = scale[c], mu = mean[c], is = invstd[c];
+      k1 = -sc * is * t2 / count;
+      k0 = -sc * t1 / count - k1 * mu;
+    }
+    coef[c] = (float)k1;
+    coef[C + c] = (float)k0;
   }
 }
 
@@ -217,29 +229,30 @@ template <typename T>
 __global__ void __launch_bounds__(256)
     bn_relu_bwd_apply_kernel(const T* __restrict__ da, int ld_da, const T* __restrict__ y,
                              const float* __restrict__ scale, const float* __restrict__ shift,
-                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                             const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                             T* __restrict__ dy, long npix, int C, float inv_count,
-                             int batch_stats) {
+                             const float* __restrict__ coef, T* __restrict__ dy, long npix, int C) {
   const int G = C / 8;
+  const bool pow2 = (G & (G - 1)) == 0;
+  const int gshift = 31 - __clz(G);
   const long total = npix * G;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-    const int g = (int)(i % G);
-    const long p = i / G;
+    const int g = pow2 ? (int)(i & (G - 1)) : (int)(i % G);
+    const long p = pow2 ? (i >> gshift) : (i / G);
     float d[8], v[8], o[8];
     load8<T>(da + p * ld_da + g * 8, d);
     load8<T>(y + p * C + g * 8, v);
+    const f32x4* sc = reinterpret_cast<const f32x4*>(scale + g * 8);
+    const f32x4* sh = reinterpret_cast<const f32x4*>(shift + g * 8);
+    const f32x4* k1 = reinterpret_cast<const f32x4*>(coef + g * 8);
+    const f32x4* k0 = reinterpret_cast<const f32x4*>(coef + C + g * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = g * 8 + j;
-      const float sc = scale[c];
-      const float z = fmaf(sc, v[j], shift[c]);
-      const float dz = z > 0.f ? d[j] : 0.f;
-      if (batch_stats) {
-        const float xh = (v[j] - mean[c]) * invstd[c];
-        o[j] = sc * (dz - dbeta[c] * inv_count - xh * dgamma[c] * inv_count);
-      } else {
-        o[j] = sc * dz;
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 a = sc[h], b = sh[h], c1 = k1[h], c0 = k0[h];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float yv = v[4 * h + j];
+        const float z = fmaf(a[j], yv, b[j]);
+        const float dz = z > 0.f ? d[4 * h + j] : 0.f;
+        o[4 * h + j] = fmaf(a[j], dz, fmaf(c1[j], yv, c0[j]));
       }
     }
     store8<T>(dy + p * C + g * 8, o);
@@ -342,7 +355,7 @@ int cy_bn_finalize(const float* partials, int num_partials, int C, double count,
   if (C <= 0 || !scale || !shift || !mean || !invstd) return CY_ERR_ARG;
   if (use_batch_stats && (!partials || num_partials <= 0 || count <= 0)) return CY_ERR_ARG;
   if ((!use_batch_stats || update_running) && (!running_mean || !running_var)) return CY_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cy_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cy_cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream,
                      partials, num_partials, C, count, gamma, beta, running_mean, running_var,
                      momentum, eps, use_batch_stats, update_running, scale, shift, mean, invstd);
   CY_CHECK_LAUNCH();
@@ -403,33 +416,33 @@ int cy_bn_relu_bwd_reduce(const void* da, int ld_da, const void* y, const float*
   return CY_OK;
 }
 
-int cy_bn_bwd_finalize(const float* partials, int num_partials, int C, float* dgamma,
-                       float* dbeta, void* stream) {
-  if (!partials || !dgamma || !dbeta || num_partials <= 0 || C <= 0) return CY_ERR_ARG;
+int cy_bn_bwd_finalize(const float* partials, int num_partials, int C, const float* scale,
+                       const float* mean, const float* invstd, double count, int batch_stats,
+                       float* dgamma, float* dbeta, int accumulate, float* coef, void* stream) {
+  if (!partials || !coef || num_partials <= 0 || C <= 0) return CY_ERR_ARG;
+  if (batch_stats && (!scale || !mean || !invstd || count <= 0)) return CY_ERR_ARG;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cy_cdiv(C, 16)), dim3(256), 0,
-                     (hipStream_t)stream, partials, num_partials, C, dgamma, dbeta);
+                     (hipStream_t)stream, partials, num_partials, C, scale, mean, invstd, count,
+                     batch_stats, dgamma, dbeta, accumulate, coef);
   CY_CHECK_LAUNCH();
   return CY_OK;
 }
 
 int cy_bn_relu_bwd_apply(const void* da, int ld_da, const void* y, const float* scale,
-                         const float* shift, const float* mean, const float* invstd,
-                         const float* dgamma, const float* dbeta, void* dy, long npix, int C,
-                         double count, int batch_stats, int dtype, void* stream) {
-  if (!da || !y || !scale || !shift || !dy) return CY_ERR_ARG;
-  if (batch_stats && (!mean || !invstd || !dgamma || !dbeta || count <= 0)) return CY_ERR_ARG;
+                         const float* shift, const float* coef, void* dy, long npix, int C,
+                         int dtype, void* stream) {
+  if (!da || !y || !scale || !shift || !coef || !dy) return CY_ERR_ARG;
   if (C % 8 || ld_da % 8 || ld_da < C) return CY_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int grid = stream_grid(npix * (C / 8));
-  const float inv_count = batch_stats ? (float)(1.0 / count) : 0.f;
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st,
-                       (const bf16*)da, ld_da, (const bf16*)y, scale, shift, mean, invstd, dgamma,
-                       dbeta, (bf16*)dy, npix, C, inv_count, batch_stats);
+                       (const bf16*)da, ld_da, (const bf16*)y, scale, shift, coef, (bf16*)dy, npix,
+                       C);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st,
-                       (const float*)da, ld_da, (const float*)y, scale, shift, mean, invstd,
-                       dgamma, dbeta, (float*)dy, npix, C, inv_count, batch_stats);
+                       (const float*)da, ld_da, (const float*)y, scale, shift, coef, (float*)dy,
+                       npix, C);
   else
     return CY_ERR_DTYPE;
   CY_CHECK_LAUNCH();

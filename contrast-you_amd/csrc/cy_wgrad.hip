@@ -222,17 +222,32 @@ __global__ void __launch_bounds__(256, 1)
 
 __global__ void __launch_bounds__(256)
     wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int Cout,
-                        int Cin, int co_pad, int ci_pad) {
-  const long total = 9L * Cout * Cin;
+                        int Cin, int co_pad, int ci_pad, int accumulate) {
+  // thread = one (co, ci): sums the S slabs in split order for all nine taps and writes the nine
+  // contiguous floats dw[co][ci][0..8]; consecutive threads = consecutive ci (coalesced reads)
+  const long total = (long)Cout * Cin;
   const size_t slab = (size_t)9 * co_pad * ci_pad;
+  const size_t tapstride = (size_t)co_pad * ci_pad;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int ci = (int)(i % Cin);
-    const int co = (int)((i / Cin) % Cout);
-    const int tap = (int)(i / ((long)Cin * Cout));
-    const size_t off = ((size_t)tap * co_pad + co) * ci_pad + ci;
-    float s = 0.f;
-    for (int q = 0; q < S; ++q) s += ws[q * slab + off];
-    dw[((size_t)co * Cin + ci) * 9 + tap] = s;
+    const int co = (int)(i / Cin);
+    const size_t off = (size_t)co * ci_pad + ci;
+    float s[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] = 0.f;
+    for (int q = 0; q < S; ++q) {
+      const float* p = ws + q * slab + off;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) s[t] += p[t * tapstride];
+    }
+    float* o = dw + (size_t)i * 9;
+    if (accumulate) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) o[t] += s[t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) o[t] = s[t];
+    }
   }
 }
 
@@ -267,7 +282,11 @@ WgPlan plan_wgrad(const cy_conv_desc* d) {
   p.tiles_w = cy_cdiv(d->W, p.TW);
   const int out_tiles = (p.co_pad / (32 * p.wco)) * (p.ci_pad / (32 * p.wci));
   const int ntiles = p.tiles_h * p.tiles_w;
-  int S = 1024 / out_tiles;
+  // enough workgroups to fill 256 CUs twice, slabs bounded to ~48 MB
+  int S = 512 / out_tiles;
+  const long slab_bytes = 9L * p.co_pad * p.ci_pad * 4;
+  const long cap = (48L << 20) / slab_bytes;
+  if (S > cap) S = (int)cap;
   if (S < 1) S = 1;
   if (S > ntiles) S = ntiles;
   p.S = S;
@@ -354,18 +373,18 @@ __global__ void __launch_bounds__(256)
 
 __global__ void __launch_bounds__(256)
     first_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nblk,
-                              int total) {
+                              int total, int accumulate) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < total) {
     float s = 0.f;
     for (int q = 0; q < nblk; ++q) s += ws[(size_t)q * total + i];
-    dw[i] = s;
+    dw[i] = accumulate ? dw[i] + s : s;
   }
 }
 
 int first_wgrad_blocks(long npix) {
-  long b = (npix + 511) / 512;
-  if (b > 512) b = 512;
+  long b = (npix + 1023) / 1024;
+  if (b > 256) b = 256;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -381,8 +400,8 @@ size_t cy_conv3x3_wgrad_ws_bytes(const cy_conv_desc* d) {
 }
 
 int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
-                     const float* shift, const void* dy, float* dw, void* ws, size_t ws_bytes,
-                     void* stream) {
+                     const float* shift, const void* dy, float* dw, int accumulate, void* ws,
+                     size_t ws_bytes, void* stream) {
   if (!d || !src1 || !dy || !dw || !ws) return CY_ERR_ARG;
   if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C1 <= 0 || d->C2 < 0 || d->Cout <= 0)
     return CY_ERR_SHAPE;
@@ -423,10 +442,10 @@ int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, 
   }
   if (rc != CY_OK) return rc;
   const int Cin = d->C1 + d->C2;
-  const long total = 9L * d->Cout * Cin;
-  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  const long total = (long)d->Cout * Cin;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw,
-                     p.S, d->Cout, Cin, p.co_pad, p.ci_pad);
+                     p.S, d->Cout, Cin, p.co_pad, p.ci_pad, accumulate);
   CY_CHECK_LAUNCH();
   return CY_OK;
 }
@@ -435,8 +454,9 @@ size_t cy_conv3x3_first_wgrad_ws_bytes(int N, int Cin, int H, int W, int Cout) {
   return (size_t)first_wgrad_blocks((long)N * H * W) * Cout * Cin * 9 * sizeof(float);
 }
 
-int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int N, int Cin, int H, int W,
-                           int Cout, int dy_dtype, void* ws, size_t ws_bytes, void* stream) {
+int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int accumulate, int N, int Cin,
+                           int H, int W, int Cout, int dy_dtype, void* ws, size_t ws_bytes,
+                           void* stream) {
   if (!x || !dy || !dw || !ws) return CY_ERR_ARG;
   if (Cin < 1 || Cin > 4 || Cout % 8 || Cout > 64 || 256 % (Cout / 8)) return CY_ERR_SHAPE;
   if (ws_bytes < cy_conv3x3_first_wgrad_ws_bytes(N, Cin, H, W, Cout)) return CY_ERR_WORKSPACE;
@@ -453,7 +473,7 @@ int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int N, int
   CY_CHECK_LAUNCH();
   const int total = Cout * Cin * 9;
   hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(cy_cdiv(total, 256)), dim3(256), 0, st,
-                     (const float*)ws, dw, nblk, total);
+                     (const float*)ws, dw, nblk, total, accumulate);
   CY_CHECK_LAUNCH();
   return CY_OK;
 }

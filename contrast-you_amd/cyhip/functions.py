@@ -22,6 +22,26 @@ _weights_epoch = 0
 _pack_cache = {}
 
 
+# num_batches_tracked counters of the BN layers touched by the current U-Net forward: bumped by
+# ONE multi-tensor add at the end of the forward instead of one tiny kernel per BN layer.
+_nbt_pending: Optional[list] = None
+
+
+class defer_batch_counters:
+    def __enter__(self):
+        global _nbt_pending
+        self._outer = _nbt_pending
+        _nbt_pending = []
+        return self
+
+    def __exit__(self, *exc):
+        global _nbt_pending
+        pending, _nbt_pending = _nbt_pending, self._outer
+        if pending and exc[0] is None:
+            torch._foreach_add_(pending, 1)
+        return False
+
+
 def bump_weights_epoch() -> None:
     global _weights_epoch
     _weights_epoch += 1
@@ -105,7 +125,10 @@ class ConvChainFn(torch.autograd.Function):
                 part, count, g.detach(), b.detach(), bn.running_mean, bn.running_var,
                 bn.momentum if bn.momentum is not None else 0.1, bn.eps, use_batch, update, Cout, dev)
             if update and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+                if _nbt_pending is not None:
+                    _nbt_pending.append(bn.num_batches_tracked)
+                else:
+                    bn.num_batches_tracked.add_(1)
             ys.append(y)
             coefs.append((scale, shift, mean, invstd))
             batch_flags.append(use_batch)
@@ -136,26 +159,37 @@ class ConvChainFn(torch.autograd.Function):
         da = dout
         dx1 = dx2 = None
         for i in reversed(range(nconv)):
-            w = params[3 * i]
+            w, g, b = params[3 * i: 3 * i + 3]
             scale, shift, mean, invstd = coefs[i]
-            dy, dgamma, dbeta = ops.bn_relu_bwd(da, ys[i], scale, shift, mean, invstd,
-                                                ctx.batch_flags[i])
-            if need[3 + 3 * i + 1]:
+            need_w, need_g, need_b = need[3 + 3 * i], need[3 + 3 * i + 1], need[3 + 3 * i + 2]
+            # parameter gradients are accumulated straight into .grad when it is a live f32 buffer
+            # (flat-buffer optimizer); otherwise they are returned to autograd as usual
+            gsink = ops.grad_sink(g) if (need_g and need_b) else None
+            bsink = ops.grad_sink(b) if gsink is not None else None
+            if bsink is None:
+                gsink = None
+            dy, dgamma, dbeta = ops.bn_relu_bwd(da, ys[i], scale, shift, mean, invstd, ctx.batch_flags[i],
+                                                dgamma_out=gsink, dbeta_out=bsink,
+                                                want_param_grads=need_g or need_b)
+            if need_g:
                 grads_p[3 * i + 1] = dgamma
-            if need[3 + 3 * i + 2]:
+            if need_b:
                 grads_p[3 * i + 2] = dbeta
+            wsink = ops.grad_sink(w) if need_w else None
             if i > 0:
                 ps, ph = coefs[i - 1][0], coefs[i - 1][1]
-                if need[3 + 3 * i]:
-                    grads_p[3 * i] = ops.conv3x3_wgrad(ys[i - 1], None, dy, scale=ps, shift=ph)
+                if need_w:
+                    dw = ops.conv3x3_wgrad(ys[i - 1], None, dy, scale=ps, shift=ph, out=wsink)
+                    grads_p[3 * i] = None if wsink is not None else dw
                 _, wd = packed_weights(w, dt)
                 da, _ = ops.conv3x3_fwd(dy, None, wd, w.shape[1], want_stats=False)
             else:
-                if need[3]:
+                if need_w:
                     if cfg.first:
-                        grads_p[0] = ops.conv_first_wgrad(x1, dy)
+                        dw = ops.conv_first_wgrad(x1, dy, out=wsink)
                     else:
-                        grads_p[0] = ops.conv3x3_wgrad(x1, x2, dy, mode=cfg.mode)
+                        dw = ops.conv3x3_wgrad(x1, x2, dy, mode=cfg.mode, out=wsink)
+                    grads_p[0] = None if wsink is not None else dw
                 need_x1 = need[1]
                 need_x2 = ctx.has_x2 and need[2]
                 if need_x1 or need_x2:

@@ -161,8 +161,18 @@ def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, 
     return out, stats
 
 
+def grad_sink(p: Tensor) -> Optional[Tensor]:
+    """p.grad when the kernels can accumulate straight into it (f32, contiguous, on the GPU)"""
+    g = p.grad
+    if g is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous():
+        return g
+    return None
+
+
 def conv3x3_wgrad(src1: Tensor, src2: Optional[Tensor], dy: Tensor, *, mode: int = 0,
-                  scale: Optional[Tensor] = None, shift: Optional[Tensor] = None) -> Tensor:
+                  scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
+                  out: Optional[Tensor] = None) -> Tensor:
+    """dw [Cout,Cin,3,3] f32; with `out` the result is ADDED into out (gradient accumulation)."""
     require_gpu(src1, dy)
     N, C1 = src1.shape[0], src1.shape[1]
     C2 = 0 if src2 is None else src2.shape[1]
@@ -171,10 +181,10 @@ def conv3x3_wgrad(src1: Tensor, src2: Optional[Tensor], dy: Tensor, *, mode: int
     d = _desc(N, H, W, C1, C2, Cout, mode, 1 if scale is not None else 0, dt, C1, C2, Cout)
     nbytes = _lib.load().cy_conv3x3_wgrad_ws_bytes(C.byref(d))
     ws = _ws(nbytes, src1.device)
-    dw = torch.empty((Cout, C1 + C2, 3, 3), dtype=torch.float32, device=src1.device)
+    dw = out if out is not None else torch.empty((Cout, C1 + C2, 3, 3), dtype=torch.float32, device=src1.device)
     ev = _prof_begin()
     _lib.call("cy_conv3x3_wgrad", C.byref(d), src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
-              dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, _stream())
+              dy.data_ptr(), dw.data_ptr(), 0 if out is None else 1, ws.data_ptr(), nbytes, _stream())
     _prof_end(ev, "conv3x3_wgrad", 2.0 * N * H * W * 9 * (C1 + C2) * Cout)
     return dw
 
@@ -196,16 +206,16 @@ def conv_first_fwd(x: Tensor, w: Tensor, out_dtype: torch.dtype, want_stats: boo
     return out, stats
 
 
-def conv_first_wgrad(x: Tensor, dy: Tensor) -> Tensor:
+def conv_first_wgrad(x: Tensor, dy: Tensor, out: Optional[Tensor] = None) -> Tensor:
     require_gpu(x, dy)
     N, Cin, H, W = x.shape
     Cout = dy.shape[1]
     x = x.contiguous() if x.dtype == torch.float32 else x.float().contiguous()
     nbytes = _lib.load().cy_conv3x3_first_wgrad_ws_bytes(N, Cin, H, W, Cout)
     ws = _ws(nbytes, x.device)
-    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
-    _lib.call("cy_conv3x3_first_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, Cin, H, W, Cout,
-              dtype_code(dy.dtype), ws.data_ptr(), nbytes, _stream())
+    dw = out if out is not None else torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    _lib.call("cy_conv3x3_first_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 0 if out is None else 1, N,
+              Cin, H, W, Cout, dtype_code(dy.dtype), ws.data_ptr(), nbytes, _stream())
     return dw
 
 
@@ -232,8 +242,10 @@ def bn_relu_apply(y: Tensor, scale: Tensor, shift: Tensor, out_dtype: Optional[t
 
 
 def bn_relu_bwd(da: Tensor, y: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor,
-                batch_stats: bool):
-    """Backward of a = relu(bn(y)): returns (dy, dgamma, dbeta)."""
+                batch_stats: bool, dgamma_out: Optional[Tensor] = None, dbeta_out: Optional[Tensor] = None,
+                want_param_grads: bool = True):
+    """Backward of a = relu(bn(y)): returns (dy, dgamma, dbeta).  With dgamma_out/dbeta_out the
+    parameter gradients are ADDED into those buffers (and returned as None)."""
     N, Cc, H, W = y.shape
     npix = N * H * W
     dev = y.device
@@ -246,14 +258,24 @@ def bn_relu_bwd(da: Tensor, y: Tensor, scale: Tensor, shift: Tensor, mean: Tenso
     _lib.call("cy_bn_relu_bwd_reduce", da.data_ptr(), Cc, y.data_ptr(), scale.data_ptr(),
               shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), part.data_ptr(), npix, Cc, dt,
               _stream())
-    gb = _f32(2 * Cc, dev).view(2, Cc)
-    _lib.call("cy_bn_bwd_finalize", part.data_ptr(), npart, Cc, gb[0].data_ptr(), gb[1].data_ptr(),
+    coef = _f32(2 * Cc, dev)
+    acc = dgamma_out is not None
+    dgamma = dbeta = None
+    if acc:
+        pg, pb = dgamma_out, dbeta_out
+    elif want_param_grads:
+        gb = _f32(2 * Cc, dev).view(2, Cc)
+        dgamma, dbeta = gb[0], gb[1]
+        pg, pb = dgamma, dbeta
+    else:
+        pg = pb = None
+    _lib.call("cy_bn_bwd_finalize", part.data_ptr(), npart, Cc, scale.data_ptr(), mean.data_ptr(),
+              invstd.data_ptr(), float(npix), int(batch_stats), _ptr(pg), _ptr(pb), int(acc), coef.data_ptr(),
               _stream())
     dy = empty_nhwc(N, Cc, H, W, y.dtype, dev)
-    _lib.call("cy_bn_relu_bwd_apply", da.data_ptr(), Cc, y.data_ptr(), scale.data_ptr(),
-              shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gb[0].data_ptr(),
-              gb[1].data_ptr(), dy.data_ptr(), npix, Cc, float(npix), int(batch_stats), dt, _stream())
-    return dy, gb[0], gb[1]
+    _lib.call("cy_bn_relu_bwd_apply", da.data_ptr(), Cc, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+              coef.data_ptr(), dy.data_ptr(), npix, Cc, dt, _stream())
+    return dy, dgamma, dbeta
 
 
 def maxpool2_bwd(x: Tensor, dpool: Tensor, add: Optional[Tensor] = None) -> Tensor:

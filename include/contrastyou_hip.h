@@ -93,11 +93,12 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
 /* Weight gradient dw[Cout][Cin][3][3] (f32, reference layout) =
  *   sum_p dy[p][co] * in[p+tap][ci]  with `in` addressed exactly as in
  * cy_conv3x3_fwd (same desc; desc.out_dtype/ldo describe dy).  ws is a
- * workspace of at least cy_conv3x3_wgrad_ws_bytes(d) bytes. */
+ * workspace of at least cy_conv3x3_wgrad_ws_bytes(d) bytes.  accumulate != 0:
+ * dw += result (autograd's gradient accumulation folded into the reduction). */
 size_t cy_conv3x3_wgrad_ws_bytes(const cy_conv_desc* d);
 int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
-                     const float* shift, const void* dy, float* dw, void* ws, size_t ws_bytes,
-                     void* stream);
+                     const float* shift, const void* dy, float* dw, int accumulate, void* ws,
+                     size_t ws_bytes, void* stream);
 
 /* First layer (input_dim 1..4, arch/unet.py:72): x is the f32 NCHW image
  * [N,Cin,H,W]; w is the reference-layout f32 weight [Cout][Cin][3][3]. */
@@ -105,8 +106,9 @@ int cy_conv3x3_first_num_partials(int N, int H, int W, int Cout);
 int cy_conv3x3_first_fwd(const float* x, const float* w, void* out, float* stats, int N, int Cin,
                          int H, int W, int Cout, int out_dtype, void* stream);
 size_t cy_conv3x3_first_wgrad_ws_bytes(int N, int Cin, int H, int W, int Cout);
-int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int N, int Cin, int H, int W,
-                           int Cout, int dy_dtype, void* ws, size_t ws_bytes, void* stream);
+int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int accumulate, int N, int Cin,
+                           int H, int W, int Cout, int dy_dtype, void* ws, size_t ws_bytes,
+                           void* stream);
 
 /* ------------------------------------------------------------------------
  * BatchNorm2d (training statistics) + ReLU   (arch/unet.py:22-23,25-26,40-41)
@@ -133,15 +135,16 @@ int cy_bn_bwd_num_partials(long npix, int C);
 int cy_bn_relu_bwd_reduce(const void* da, int ld_da, const void* y, const float* scale,
                           const float* shift, const float* mean, const float* invstd,
                           float* partials, long npix, int C, int dtype, void* stream);
-/* Step 2: dgamma/dbeta from the partials (fixed summation order). */
-int cy_bn_bwd_finalize(const float* partials, int num_partials, int C, float* dgamma,
-                       float* dbeta, void* stream);
-/* Step 3: dy = scale*(dz - dbeta/M - xhat*dgamma/M)  (batch_stats=1) or
- * dy = scale*dz (batch_stats=0, eval-mode BN). */
+/* Step 2: dgamma/dbeta from the partials (fixed summation order; accumulate != 0
+ * adds into them) and the per-channel coefficients coef[2][C] = {k1, k0} of step 3. */
+int cy_bn_bwd_finalize(const float* partials, int num_partials, int C, const float* scale,
+                       const float* mean, const float* invstd, double count, int batch_stats,
+                       float* dgamma, float* dbeta, int accumulate, float* coef, void* stream);
+/* Step 3: dy = scale*dz + k1*y + k0, i.e. scale*(dz - dbeta/M - xhat*dgamma/M) for batch
+ * statistics and scale*dz (k1 = k0 = 0) for eval-mode BN. */
 int cy_bn_relu_bwd_apply(const void* da, int ld_da, const void* y, const float* scale,
-                         const float* shift, const float* mean, const float* invstd,
-                         const float* dgamma, const float* dbeta, void* dy, long npix, int C,
-                         double count, int batch_stats, int dtype, void* stream);
+                         const float* shift, const float* coef, void* dy, long npix, int C,
+                         int dtype, void* stream);
 
 /* ------------------------------------------------------------------------
  * MaxPool2d(2,2) backward (arch/unet.py:67-70) and nearest-x2 backward
