@@ -73,6 +73,9 @@ __global__ void __launch_bounds__(256, 2)
   const int n0 = blockIdx.y * BN;
   const int Cin = a.C1 + a.C2;
   const int ncc = (Cin + KC - 1) / KC;
+  // split-K: this workgroup reduces the input-channel chunks [cc0, cc1)
+  const int cc0 = (ncc * (int)blockIdx.z) / a.ksplit;
+  const int cc1 = (ncc * ((int)blockIdx.z + 1)) / a.ksplit;
 
   // zero slot + row tables
   for (int idx = tid; idx < HW2 * CPP; idx += 256) {
@@ -130,13 +133,13 @@ __global__ void __launch_bounds__(256, 2)
     }
   };
 
-  conv_stage_halo<T, PITCHB, true>(a, sA, s_row1, s_row2, TH, TW, w0, 0, tid);
-  load_b(0, 0);
+  conv_stage_halo<T, PITCHB, true>(a, sA, s_row1, s_row2, TH, TW, w0, cc0 * KC, tid);
+  load_b(cc0, 0);
   store_b(sB);
   __syncthreads();
 
-  const int nit = ncc * 9;
-  for (int it = 0; it < nit; ++it) {
+  const int it0 = cc0 * 9, nit = cc1 * 9;
+  for (int it = it0; it < nit; ++it) {
     const int cc = it / 9;
     const int tap = it - cc * 9;
     const int dh = tap / 3 - 1, dw = tap % 3 - 1;
@@ -145,7 +148,7 @@ __global__ void __launch_bounds__(256, 2)
       const int it1 = it + 1;
       load_b(it1 / 9, it1 % 9);
     }
-    const unsigned char* sBc = sB + (it & 1) * C::B_BYTES;
+    const unsigned char* sBc = sB + ((it - it0) & 1) * C::B_BYTES;
 
     const unsigned char* apix[M_REP];
     int aswz[M_REP];
@@ -171,7 +174,7 @@ __global__ void __launch_bounds__(256, 2)
       }
     }
 
-    if (has_next) store_b(sB + ((it + 1) & 1) * C::B_BYTES);
+    if (has_next) store_b(sB + ((it + 1 - it0) & 1) * C::B_BYTES);
     if (tap == 8 && has_next) {
       __syncthreads();  // every wave is done reading the halo tile
       conv_stage_halo<T, PITCHB, true>(a, sA, s_row1, s_row2, TH, TW, w0, (cc + 1) * KC, tid);
@@ -180,6 +183,27 @@ __global__ void __launch_bounds__(256, 2)
   }
 
   // ---------------- epilogue ----------------
+  if (a.ksplit > 1) {
+    // raw f32 partial sums; conv_splitk_finish_kernel adds the splits, rounds, stores, takes stats
+    float* wsz = a.ws + (size_t)blockIdx.z * ((size_t)a.NH * a.W) * a.Cout;
+#pragma unroll
+    for (int n = 0; n < N_REP; ++n) {
+      const int co = n0 + (wn * N_REP + n) * 32 + r;
+#pragma unroll
+      for (int m = 0; m < M_REP; ++m) {
+        const int ibase = (wm * M_REP + m) * 32;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int i = ibase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          const int ty = i / TW, tx = i - ty * TW;
+          const int R = R0 + ty, w = w0 + tx;
+          if (R < a.NH && w < a.W && co < a.Cout)
+            wsz[((size_t)R * a.W + w) * a.Cout + co] = acc[m][n][reg];
+        }
+      }
+    }
+    return;
+  }
   constexpr int EPO = 16 / (int)sizeof(TO);  // output elements per 16-byte chunk
   constexpr int CPO = 32 / EPO;              // chunks per 32-cout row
   float* scratch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
@@ -269,6 +293,84 @@ __global__ void __launch_bounds__(256, 2)
   }
 }
 
+// split-K finish: out = round(sum_z ws[z]) (+ split destinations), per-block BN partial sums.
+// thread = (pixel lane, group of 8 couts); block = contiguous pixel range.
+template <typename TO>
+__global__ void __launch_bounds__(256)
+    conv_splitk_finish_kernel(const float* __restrict__ ws, int Z, long npix, int Cout,
+                              TO* __restrict__ out, int ldo, TO* __restrict__ out2, int ldo2,
+                              int split_c, float* __restrict__ stats) {
+  extern __shared__ float sred[];  // [2][rows][gpp*8]
+  const int G = Cout / 8;
+  const int gpp = G < 256 ? G : 256;
+  const int rows = 256 / gpp;
+  const int tid = threadIdx.x;
+  const int g = tid % gpp, prow = tid / gpp;
+  const bool active = tid < rows * gpp;
+  const long per = (npix + gridDim.x - 1) / gridDim.x;
+  const long p0 = (long)blockIdx.x * per;
+  const long p1 = p0 + per < npix ? p0 + per : npix;
+  const size_t zstride = (size_t)npix * Cout;
+  for (int page = 0; page * gpp < G; ++page) {
+    const int gg = page * gpp + g;
+    float a1[8], a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
+    if (active && gg < G) {
+      for (long p = p0 + prow; p < p1; p += rows) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = 0.f;
+        const float* src = ws + (size_t)p * Cout + gg * 8;
+        for (int z = 0; z < Z; ++z) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(src + z * zstride);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(src + z * zstride + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f[j] += lo[j];
+            f[4 + j] += hi[j];
+          }
+        }
+        const int co = gg * 8;
+        TO* dst = (split_c > 0 && co >= split_c) ? out2 + (size_t)p * ldo2 + (co - split_c)
+                                                 : out + (size_t)p * ldo + co;
+        if constexpr (sizeof(TO) == 2) {
+          st16(dst, Chunk<bf16>::pack(f));
+        } else {
+          st16(dst, Chunk<float>::pack(f));
+          st16(dst + 4, Chunk<float>::pack(f + 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float q = round_through<TO>(f[j]);
+          a1[j] += q;
+          a2[j] += q * q;
+        }
+      }
+    }
+    if (stats) {
+      __syncthreads();
+      if (active && gg < G) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          sred[(0 * rows + prow) * (gpp * 8) + g * 8 + j] = a1[j];
+          sred[(1 * rows + prow) * (gpp * 8) + g * 8 + j] = a2[j];
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < 2 * gpp * 8; i += 256) {
+        const int which = i / (gpp * 8), cl = i % (gpp * 8);
+        const int c = page * gpp * 8 + cl;
+        if (c < Cout) {
+          float s = 0.f;
+          for (int q = 0; q < rows; ++q) s += sred[(which * rows + q) * (gpp * 8) + cl];
+          stats[((size_t)blockIdx.x * 2 + which) * Cout + c] = s;
+        }
+      }
+    }
+  }
+}
+
 template <typename T, typename TO, int TH, int TW, int BN, int WGM, int WGN, int PITCHB>
 int launch_conv(ConvArgs a, hipStream_t st) {
   using C = ConvCfg<T, TO, TH, TW, BN, WGM, WGN, PITCHB>;
@@ -283,7 +385,7 @@ int launch_conv(ConvArgs a, hipStream_t st) {
   const int tiles_h = cy_cdiv(a.NH, TH);
   a.tiles_w = cy_cdiv(a.W, TW);
   a.full_tiles = (a.NH % TH == 0) && (a.W % TW == 0);
-  dim3 grid(tiles_h * a.tiles_w, cy_cdiv(a.Cout, BN));
+  dim3 grid(tiles_h * a.tiles_w, cy_cdiv(a.Cout, BN), a.ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(256), C::SMEM, st, a);
   CY_CHECK_LAUNCH();
   return CY_OK;
@@ -312,6 +414,53 @@ TileChoice choose_tile(int W, int Cout) {
     c.th = 16, c.tw = 16;
   }
   return c;
+}
+
+struct ConvPlan {
+  TileChoice tile;
+  int ksplit;         // >1: split-K over input-channel chunks + finish kernel
+  int finish_blocks;  // blocks (= stat partials) of the finish kernel
+  int partials;       // number of BN partials the launch sequence writes
+  size_t ws_bytes;
+};
+
+// Deep layers (14x14 / 28x28 at small batch) have too few output tiles to fill 256 CUs: split
+// the reduction over input-channel chunks across blockIdx.z.
+ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes) {
+  ConvPlan p;
+  p.tile = choose_tile(W, Cout);
+  const long npix = (long)N * H * W;
+  const int tiles = cy_cdiv((long)N * H, p.tile.th) * cy_cdiv(W, p.tile.tw);
+  const int blocks = tiles * cy_cdiv(Cout, p.tile.bn);
+  const bool small_k = Cin * elem_bytes <= 64 && p.tile.bn <= 64;
+  const int kc = (small_k ? 64 : 128) / elem_bytes;
+  const int ncc = cy_cdiv(Cin, kc);
+  int Z = 1;
+  if (blocks < 192 && ncc >= 2 && Cout % 8 == 0) {
+    Z = cy_cdiv(384, blocks);
+    if (Z > ncc) Z = ncc;
+    if (Z > 8) Z = 8;
+  }
+  p.ksplit = Z;
+  long fb = (npix + 63) / 64;
+  if (fb > 1024) fb = 1024;
+  p.finish_blocks = (int)fb;
+  p.partials = Z > 1 ? p.finish_blocks : tiles;
+  p.ws_bytes = Z > 1 ? (size_t)Z * npix * Cout * sizeof(float) : 0;
+  return p;
+}
+
+template <typename TO>
+int launch_finish(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
+  const int G = a.Cout / 8;
+  const int gpp = G < 256 ? G : 256;
+  const int rows = 256 / gpp;
+  const size_t smem = (size_t)2 * rows * gpp * 8 * sizeof(float);
+  hipLaunchKernelGGL(conv_splitk_finish_kernel<TO>, dim3(p.finish_blocks), dim3(256), smem, st, a.ws,
+                     p.ksplit, (long)a.NH * a.W, a.Cout, (TO*)a.out, a.ldo, (TO*)a.out2, a.ldo2,
+                     a.split_c, a.stats);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
 }
 
 template <typename T>
@@ -450,7 +599,7 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------
 extern "C" {
 
-int cy_abi_version(void) { return 2; }
+int cy_abi_version(void) { return 3; }
 const char* cy_build_arch(void) { return "gfx950"; }
 
 int cy_conv3x3_packed_dims(int Cout, int Cin, int* co_pad, int* ci_pad) {
@@ -498,22 +647,30 @@ static int conv_check(const cy_conv_desc* d) {
   return CY_OK;
 }
 
+static ConvPlan plan_of(const cy_conv_desc* d) {
+  return plan_conv(d->N, d->H, d->W, d->C1 + d->C2, d->Cout, d->in_dtype == CY_BF16 ? 2 : 4);
+}
+
 int cy_conv3x3_num_partials(const cy_conv_desc* d) {
   if (conv_check(d) != CY_OK) return CY_ERR_ARG;
-  const TileChoice c = choose_tile(d->W, d->Cout);
-  return cy_cdiv((long)d->N * d->H, c.th) * cy_cdiv(d->W, c.tw);
+  return plan_of(d).partials;
+}
+
+size_t cy_conv3x3_fwd_ws_bytes(const cy_conv_desc* d) {
+  if (conv_check(d) != CY_OK) return 0;
+  return plan_of(d).ws_bytes;
 }
 
 int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
                    const float* shift, const void* w_packed, void* out, void* out2, float* stats,
-                   void* stream) {
+                   void* ws, size_t ws_bytes, void* stream) {
   int rc = conv_check(d);
   if (rc != CY_OK) return rc;
   if (!src1 || !w_packed || !out) return CY_ERR_ARG;
   if (d->C2 && !src2) return CY_ERR_ARG;
   if (d->prologue && (!scale || !shift)) return CY_ERR_ARG;
   if (d->split_c > 0 && !out2) return CY_ERR_ARG;
-  ConvArgs a;
+  ConvArgs a = {};
   a.src1 = src1, a.src2 = src2, a.scale = scale, a.shift = shift, a.w = w_packed;
   a.out = out, a.out2 = out2, a.stats = stats;
   a.N = d->N, a.H = d->H, a.W = d->W, a.NH = d->N * d->H;
@@ -522,9 +679,14 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
   a.ld1 = d->ld1, a.ld2 = d->ld2, a.ldo = d->ldo, a.ldo2 = d->ldo2, a.split_c = d->split_c;
   a.tiles_w = 0, a.full_tiles = 0;
   cy_conv3x3_packed_dims(d->Cout, d->C1 + d->C2, &a.w_co_pad, &a.w_ci_pad);
+  const ConvPlan p = plan_of(d);
+  a.ksplit = p.ksplit;
+  a.ws = (float*)ws;
+  if (p.ksplit > 1 && (!ws || ws_bytes < p.ws_bytes)) return CY_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  if (d->in_dtype == CY_BF16) return dispatch_conv<bf16>(a, st);
-  return dispatch_conv<float>(a, st);
+  rc = d->in_dtype == CY_BF16 ? dispatch_conv<bf16>(a, st) : dispatch_conv<float>(a, st);
+  if (rc != CY_OK || p.ksplit == 1) return rc;
+  return d->in_dtype == CY_BF16 ? launch_finish<bf16>(a, p, st) : launch_finish<float>(a, p, st);
 }
 
 int cy_conv3x3_first_num_partials(int N, int H, int W, int Cout) {

@@ -31,6 +31,8 @@ struct ConvArgs {
   int tiles_w;  // number of column tiles
   int w_co_pad, w_ci_pad;
   int full_tiles;  // 1: every tile is entirely inside the image grid
+  float* ws;       // split-K: f32 partial outputs [ksplit][N*H*W][Cout]
+  int ksplit;      // number of K splits over input-channel chunks (blockIdx.z)
 };
 
 // ---- MFMA fragment abstraction: one "k-step" is 16 input channels ----------

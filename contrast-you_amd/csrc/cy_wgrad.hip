@@ -68,7 +68,7 @@ struct WgCfg {
 };
 
 template <typename T, int WCO, int WCI, int WK>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, 2)
     wgrad_kernel(const WgradArgs g) {
   using C = WgCfg<T, WCO, WCI, WK>;
   constexpr int PA = C::PA, PB = C::PB;
@@ -221,25 +221,42 @@ __global__ void __launch_bounds__(256, 1)
 }
 
 __global__ void __launch_bounds__(256)
-    wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int Cout,
+    wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int SG, int Cout,
                         int Cin, int co_pad, int ci_pad, int accumulate) {
-  // thread = one (co, ci): sums the S slabs in split order for all nine taps and writes the nine
-  // contiguous floats dw[co][ci][0..8]; consecutive threads = consecutive ci (coalesced reads)
+  // block = (256/SG) consecutive (co,ci) outputs x SG slab groups.  Group g sums slabs
+  // g, g+SG, ... in increasing order, then the SG group sums are added in group order: the
+  // summation tree is a function of (S, SG) only => bitwise reproducible.
+  __shared__ float sred[256 * 9];
+  const int opb = 256 / SG;
+  const int ol = threadIdx.x % opb, sg = threadIdx.x / opb;
   const long total = (long)Cout * Cin;
+  const long i = (long)blockIdx.x * opb + ol;
   const size_t slab = (size_t)9 * co_pad * ci_pad;
   const size_t tapstride = (size_t)co_pad * ci_pad;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+  float s[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) s[t] = 0.f;
+  if (i < total) {
     const int ci = (int)(i % Cin);
     const int co = (int)(i / Cin);
     const size_t off = (size_t)co * ci_pad + ci;
-    float s[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) s[t] = 0.f;
-    for (int q = 0; q < S; ++q) {
+    for (int q = sg; q < S; q += SG) {
       const float* p = ws + q * slab + off;
 #pragma unroll
       for (int t = 0; t < 9; ++t) s[t] += p[t * tapstride];
     }
+  }
+  if (SG > 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sred[(sg * opb + ol) * 9 + t] = s[t];
+    __syncthreads();
+    if (sg == 0) {
+      for (int g = 1; g < SG; ++g)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s[t] += sred[(g * opb + ol) * 9 + t];
+    }
+  }
+  if (sg == 0 && i < total) {
     float* o = dw + (size_t)i * 9;
     if (accumulate) {
 #pragma unroll
@@ -415,7 +432,7 @@ int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, 
   if (d->mode1 == CY_SRC_UP2 && ((d->H & 1) || (d->W & 1))) return CY_ERR_SHAPE;
   const WgPlan p = plan_wgrad(d);
   if (ws_bytes < (size_t)p.S * 9 * p.co_pad * p.ci_pad * sizeof(float)) return CY_ERR_WORKSPACE;
-  WgradArgs g;
+  WgradArgs g = {};
   ConvArgs& a = g.c;
   a.src1 = src1, a.src2 = src2, a.scale = scale, a.shift = shift, a.w = nullptr;
   a.out = nullptr, a.out2 = nullptr, a.stats = nullptr;
@@ -443,9 +460,12 @@ int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, 
   if (rc != CY_OK) return rc;
   const int Cin = d->C1 + d->C2;
   const long total = (long)d->Cout * Cin;
-  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  int SG = 1;  // slab groups per output: more when there are few outputs and many slabs
+  while (SG < 32 && SG * 2 <= p.S && (total * SG) / 256 < 1024) SG *= 2;
+  const int opb = 256 / SG;
+  const int blocks = (int)((total + opb - 1) / opb);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw,
-                     p.S, d->Cout, Cin, p.co_pad, p.ci_pad, accumulate);
+                     p.S, SG, d->Cout, Cin, p.co_pad, p.ci_pad, accumulate);
   CY_CHECK_LAUNCH();
   return CY_OK;
 }

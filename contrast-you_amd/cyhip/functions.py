@@ -19,7 +19,6 @@ from . import ops
 # bumped by anything that rewrites parameter memory without going through torch
 # (fused optimizer, flat-buffer EMA): invalidates the packed-weight cache.
 _weights_epoch = 0
-_pack_cache = {}
 
 
 # num_batches_tracked counters of the BN layers touched by the current U-Net forward: bumped by
@@ -48,14 +47,18 @@ def bump_weights_epoch() -> None:
 
 
 def packed_weights(w: Tensor, dtype: torch.dtype):
-    """(forward image, dgrad image) of a 3x3 weight, cached until the weight changes."""
-    key = (id(w), dtype)
+    """(forward image, dgrad image) of a 3x3 weight, cached ON the parameter object until the
+    weight changes.  (A global dict keyed by id(w) would hand a new parameter that reuses a dead
+    one's id and storage address the dead one's packed weights.)"""
     tag = (w._version, _weights_epoch, w.data_ptr())
-    hit = _pack_cache.get(key)
+    cache = w.__dict__.get("_cy_pack")
+    if cache is None:
+        cache = w.__dict__["_cy_pack"] = {}
+    hit = cache.get(dtype)
     if hit is not None and hit[0] == tag:
         return hit[1], hit[2]
     wf, wd = ops.pack_weights(w, dtype, want_dgrad=True)
-    _pack_cache[key] = (tag, wf, wd)
+    cache[dtype] = (tag, wf, wd)
     return wf, wd
 
 

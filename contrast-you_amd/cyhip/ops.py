@@ -152,9 +152,11 @@ def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, 
     if want_stats:
         npart = _lib.call("cy_conv3x3_num_partials", C.byref(d))
         stats = _f32(npart * 2 * Cout, dev).view(npart, 2, Cout)
+    nbytes = _lib.load().cy_conv3x3_fwd_ws_bytes(C.byref(d))
+    ws = _ws(nbytes, dev) if nbytes else None
     ev = _prof_begin()
     _lib.call("cy_conv3x3_fwd", C.byref(d), src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
-              wf.data_ptr(), out.data_ptr(), _ptr(out2), _ptr(stats), _stream())
+              wf.data_ptr(), out.data_ptr(), _ptr(out2), _ptr(stats), _ptr(ws), nbytes, _stream())
     _prof_end(ev, "conv3x3_igemm", 2.0 * N * H * W * 9 * (C1 + C2) * Cout)
     if split:
         return (out, out2), None

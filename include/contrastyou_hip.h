@@ -85,10 +85,13 @@ int cy_conv3x3_pack_weights(const float* w, void* wf, void* wd, int Cout, int Ci
  * (stats buffer is float[num_partials][2][Cout]: sum, sum of squares). */
 int cy_conv3x3_num_partials(const cy_conv_desc* d);
 
-/* out = conv3x3(concat(src1', src2), w).  stats may be NULL. */
+/* out = conv3x3(concat(src1', src2), w).  stats may be NULL.  Layers with too few
+ * output tiles to fill the chip run split-K over input-channel chunks and need a
+ * workspace of cy_conv3x3_fwd_ws_bytes(d) bytes (0 for the others; ws may then be NULL). */
+size_t cy_conv3x3_fwd_ws_bytes(const cy_conv_desc* d);
 int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
                    const float* shift, const void* w_packed, void* out, void* out2, float* stats,
-                   void* stream);
+                   void* ws, size_t ws_bytes, void* stream);
 
 /* Weight gradient dw[Cout][Cin][3][3] (f32, reference layout) =
  *   sum_p dy[p][co] * in[p+tap][ci]  with `in` addressed exactly as in

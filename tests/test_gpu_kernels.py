@@ -116,10 +116,12 @@ def test_conv3x3_fwd_and_stats(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_conv3x3_dgrad_with_split(dtype):
+@pytest.mark.parametrize("shape", [(2, 16, 16, 32, 64, 64), (2, 14, 14, 64, 64, 256), (1, 28, 28, 128, 128, 128)])
+def test_conv3x3_dgrad_with_split(shape, dtype):
+    """data gradient with the two-destination (concat) epilogue, incl. the split-K path"""
     ops = _ops()
     g = torch.Generator().manual_seed(7)
-    N, H, W, Cin1, Cin2, Cout = 2, 16, 16, 32, 64, 64
+    N, H, W, Cin1, Cin2, Cout = shape
     w = (rnd(Cout, Cin1 + Cin2, 3, 3, gen=g) / 20).to(dtype).float()
     dy = rnd(N, Cout, H, W, gen=g).to(dtype).float()
     ref = F.conv_transpose2d(dy, w, None, 1, 1)  # = dgrad of a stride-1 pad-1 conv
