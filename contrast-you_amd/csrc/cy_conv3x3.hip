@@ -20,7 +20,7 @@
 
 namespace {
 
-template <typename T, typename TO, int TH, int TW, int BN, int WGM, int WGN, int PITCHB>
+template <typename T, typename TO, int TH, int TW, int BN, int WGM, int WGN, int PITCHB, bool ALLT>
 struct ConvCfg {
   static constexpr int EPC = ElemTr<T>::EPC;
   static constexpr int KC = PITCHB / (int)sizeof(T);
@@ -36,7 +36,8 @@ struct ConvCfg {
   static constexpr int BREG = (BN * CPP + 255) / 256;
   static constexpr int TAB_BYTES = (3 * TH + 4) * 4;
   static constexpr int EPI_BYTES = 4 * 32 * 36 * 4 + WGM * 2 * BN * 4;
-  static constexpr int MAIN_BYTES = A_BYTES + 2 * B_BYTES;
+  static constexpr int NBUF = ALLT ? 9 : 2;  // B slices resident in LDS: all nine taps, or a 2-deep ring
+  static constexpr int MAIN_BYTES = A_BYTES + NBUF * B_BYTES;
   static constexpr int SMEM = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) + TAB_BYTES + 16;
   static_assert(WGM * WGN == 4, "4 waves");
   static_assert((TH * TW) % 32 == 0 && MT % WGM == 0, "tile/wave split");
@@ -44,10 +45,10 @@ struct ConvCfg {
   static_assert(256 % CPP == 0, "chunk ownership");
 };
 
-template <typename T, typename TO, int TH, int TW, int BN, int WGM, int WGN, int PITCHB>
+template <typename T, typename TO, int TH, int TW, int BN, int WGM, int WGN, int PITCHB, bool ALLT>
 __global__ void __launch_bounds__(256, 2)
     conv3x3_igemm_kernel(const ConvArgs a) {
-  using C = ConvCfg<T, TO, TH, TW, BN, WGM, WGN, PITCHB>;
+  using C = ConvCfg<T, TO, TH, TW, BN, WGM, WGN, PITCHB, ALLT>;
   using M = Mma<T>;
   constexpr int EPC = C::EPC, KC = C::KC, CPP = C::CPP, KS = C::KS, HW2 = C::HW2;
   constexpr int M_REP = C::M_REP, N_REP = C::N_REP, BREG = C::BREG;
@@ -86,13 +87,13 @@ __global__ void __launch_bounds__(256, 2)
   __syncthreads();
 
   // per-lane pixel coordinates of the A rows this lane feeds
-  int pty[M_REP], ptx[M_REP], pfl[M_REP];
+  // packed (ty << 12) | (tx << 4) | row flags: one register per A row-tile
+  int ppk[M_REP];
 #pragma unroll
   for (int m = 0; m < M_REP; ++m) {
     const int i = (wm * M_REP + m) * 32 + r;
-    pty[m] = i / TW;
-    ptx[m] = i - pty[m] * TW;
-    pfl[m] = s_flag[pty[m]];
+    const int ty = i / TW;
+    ppk[m] = (ty << 12) | ((i - ty * TW) << 4) | s_flag[ty];
   }
   // per-lane B rows
   int brow[N_REP], bswz[N_REP];
@@ -133,53 +134,113 @@ __global__ void __launch_bounds__(256, 2)
     }
   };
 
-  conv_stage_halo<T, PITCHB, true>(a, sA, s_row1, s_row2, TH, TW, w0, cc0 * KC, tid);
-  load_b(cc0, 0);
-  store_b(sB);
-  __syncthreads();
-
-  const int it0 = cc0 * 9, nit = cc1 * 9;
-  for (int it = it0; it < nit; ++it) {
-    const int cc = it / 9;
-    const int tap = it - cc * 9;
-    const int dh = tap / 3 - 1, dw = tap % 3 - 1;
-    const bool has_next = it + 1 < nit;
-    if (has_next) {
-      const int it1 = it + 1;
-      load_b(it1 / 9, it1 % 9);
-    }
-    const unsigned char* sBc = sB + ((it - it0) & 1) * C::B_BYTES;
-
-    const unsigned char* apix[M_REP];
-    int aswz[M_REP];
+  if constexpr (ALLT) {
+    // Small-N layers (Cout <= 64): all nine weight taps of a chunk sit in LDS at once, so a
+    // chunk is {stage A + B, barrier, 9 taps x KS k-steps of MFMA, barrier}: no per-tap barrier.
+    constexpr int NB = 9 * BN * CPP;           // 16-byte chunks of the nine-tap weight slab
+    constexpr int NBR = (NB + 255) / 256;
+    for (int cc = cc0; cc < cc1; ++cc) {
+      if (cc != cc0) __syncthreads();  // every wave is done with the previous chunk's LDS
+      u32x4 wreg[NBR];
 #pragma unroll
-    for (int m = 0; m < M_REP; ++m) {
-      int slot = pty[m] + 1 + dh;
-      if ((dh < 0 && (pfl[m] & 1)) || (dh > 0 && (pfl[m] & 2))) slot = C::ZSLOT;
-      const int p = slot * HW2 + ptx[m] + 1 + dw;
-      apix[m] = sA + p * PITCHB;
-      aswz[m] = lds_swz<PITCHB>(p);
-    }
+      for (int i = 0; i < NBR; ++i) {
+        const int idx = tid + i * 256;
+        if (idx < NB) {
+          const int tap = idx / (BN * CPP), rem = idx % (BN * CPP);
+          const int row = rem / CPP, ch = rem % CPP;
+          wreg[i] = ld16(wp + ((size_t)(tap * a.w_co_pad + n0 + row)) * a.w_ci_pad + cc * KC + ch * EPC);
+        }
+      }
+      conv_stage_halo<T, PITCHB, true>(a, sA, s_row1, s_row2, TH, TW, w0, cc * KC, tid);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int fi = 2 * ks + h;
-      typename M::Frag bf[N_REP];
+      for (int i = 0; i < NBR; ++i) {
+        const int idx = tid + i * 256;
+        if (idx < NB) {
+          const int tap = idx / (BN * CPP), rem = idx % (BN * CPP);
+          const int row = rem / CPP, ch = rem % CPP;
+          st16(sB + tap * C::B_BYTES + row * PITCHB + ((ch ^ lds_swz<PITCHB>(row)) << 4), wreg[i]);
+        }
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+        const unsigned char* sBc = sB + tap * C::B_BYTES;
+        const unsigned char* apix[M_REP];
+        int aswz[M_REP];
 #pragma unroll
-      for (int n = 0; n < N_REP; ++n) bf[n] = M::load(sBc + brow[n] * PITCHB, fi, bswz[n]);
+        for (int m = 0; m < M_REP; ++m) {
+          int slot = (ppk[m] >> 12) + 1 + dh;
+          if ((dh < 0 && (ppk[m] & 1)) || (dh > 0 && (ppk[m] & 2))) slot = C::ZSLOT;
+          const int p = slot * HW2 + ((ppk[m] >> 4) & 0xff) + 1 + dw;
+          apix[m] = sA + p * PITCHB;
+          aswz[m] = lds_swz<PITCHB>(p);
+        }
 #pragma unroll
-      for (int m = 0; m < M_REP; ++m) {
-        typename M::Frag af = M::load(apix[m], fi, aswz[m]);
+        for (int ks = 0; ks < KS; ++ks) {
+          const int fi = 2 * ks + h;
+          typename M::Frag bf[N_REP];
 #pragma unroll
-        for (int n = 0; n < N_REP; ++n) M::mma(af, bf[n], acc[m][n]);
+          for (int n = 0; n < N_REP; ++n) bf[n] = M::load(sBc + brow[n] * PITCHB, fi, bswz[n]);
+#pragma unroll
+          for (int m = 0; m < M_REP; ++m) {
+            typename M::Frag af = M::load(apix[m], fi, aswz[m]);
+#pragma unroll
+            for (int n = 0; n < N_REP; ++n) M::mma(af, bf[n], acc[m][n]);
+          }
+        }
       }
     }
-
-    if (has_next) store_b(sB + ((it + 1 - it0) & 1) * C::B_BYTES);
-    if (tap == 8 && has_next) {
-      __syncthreads();  // every wave is done reading the halo tile
-      conv_stage_halo<T, PITCHB, true>(a, sA, s_row1, s_row2, TH, TW, w0, (cc + 1) * KC, tid);
-    }
     __syncthreads();
+  } else {
+    conv_stage_halo<T, PITCHB, true>(a, sA, s_row1, s_row2, TH, TW, w0, cc0 * KC, tid);
+    load_b(cc0, 0);
+    store_b(sB);
+    __syncthreads();
+
+    const int it0 = cc0 * 9, nit = cc1 * 9;
+    for (int it = it0; it < nit; ++it) {
+      const int cc = it / 9;
+      const int tap = it - cc * 9;
+      const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+      const bool has_next = it + 1 < nit;
+      if (has_next) {
+        const int it1 = it + 1;
+        load_b(it1 / 9, it1 % 9);
+      }
+      const unsigned char* sBc = sB + ((it - it0) & 1) * C::B_BYTES;
+
+      const unsigned char* apix[M_REP];
+      int aswz[M_REP];
+  #pragma unroll
+      for (int m = 0; m < M_REP; ++m) {
+        int slot = (ppk[m] >> 12) + 1 + dh;
+        if ((dh < 0 && (ppk[m] & 1)) || (dh > 0 && (ppk[m] & 2))) slot = C::ZSLOT;
+        const int p = slot * HW2 + ((ppk[m] >> 4) & 0xff) + 1 + dw;
+        apix[m] = sA + p * PITCHB;
+        aswz[m] = lds_swz<PITCHB>(p);
+      }
+  #pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int fi = 2 * ks + h;
+        typename M::Frag bf[N_REP];
+  #pragma unroll
+        for (int n = 0; n < N_REP; ++n) bf[n] = M::load(sBc + brow[n] * PITCHB, fi, bswz[n]);
+  #pragma unroll
+        for (int m = 0; m < M_REP; ++m) {
+          typename M::Frag af = M::load(apix[m], fi, aswz[m]);
+  #pragma unroll
+          for (int n = 0; n < N_REP; ++n) M::mma(af, bf[n], acc[m][n]);
+        }
+      }
+
+      if (has_next) store_b(sB + ((it + 1 - it0) & 1) * C::B_BYTES);
+      if (tap == 8 && has_next) {
+        __syncthreads();  // every wave is done reading the halo tile
+        conv_stage_halo<T, PITCHB, true>(a, sA, s_row1, s_row2, TH, TW, w0, (cc + 1) * KC, tid);
+      }
+      __syncthreads();
+    }
   }
 
   // ---------------- epilogue ----------------
@@ -371,10 +432,10 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-template <typename T, typename TO, int TH, int TW, int BN, int WGM, int WGN, int PITCHB>
+template <typename T, typename TO, int TH, int TW, int BN, int WGM, int WGN, int PITCHB, bool ALLT>
 int launch_conv(ConvArgs a, hipStream_t st) {
-  using C = ConvCfg<T, TO, TH, TW, BN, WGM, WGN, PITCHB>;
-  auto kern = conv3x3_igemm_kernel<T, TO, TH, TW, BN, WGM, WGN, PITCHB>;
+  using C = ConvCfg<T, TO, TH, TW, BN, WGM, WGN, PITCHB, ALLT>;
+  auto kern = conv3x3_igemm_kernel<T, TO, TH, TW, BN, WGM, WGN, PITCHB, ALLT>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -432,8 +493,7 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes) {
   const long npix = (long)N * H * W;
   const int tiles = cy_cdiv((long)N * H, p.tile.th) * cy_cdiv(W, p.tile.tw);
   const int blocks = tiles * cy_cdiv(Cout, p.tile.bn);
-  const bool small_k = Cin * elem_bytes <= 64 && p.tile.bn <= 64;
-  const int kc = (small_k ? 64 : 128) / elem_bytes;
+  const int kc = (p.tile.bn <= 64 ? 64 : 128) / elem_bytes;  // must match dispatch_conv's PITCHB
   const int ncc = cy_cdiv(Cin, kc);
   int Z = 1;
   if (blocks < 192 && ncc >= 2 && Cout % 8 == 0) {
@@ -466,30 +526,27 @@ int launch_finish(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
 template <typename T>
 int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   const TileChoice c = choose_tile(a.W, a.Cout);
-  const int Cin = a.C1 + a.C2;
-  const bool small_k = Cin * (int)sizeof(T) <= 64 && c.bn <= 64;
-#define CY_CONV_CASE(TH_, TW_, BN_, WGM_, WGN_, P_) \
-  return launch_conv<T, T, TH_, TW_, BN_, WGM_, WGN_, P_>(a, st)
+  // BN <= 64 (small-channel, HBM-leaning layers): 64-byte channel chunks, all nine weight taps
+  // resident in LDS.  BN = 128: 128-byte chunks, weights through a 2-deep per-tap ring.
+#define CY_CONV_CASE(TH_, TW_, BN_, WGM_, WGN_, P_, ALLT_) \
+  return launch_conv<T, T, TH_, TW_, BN_, WGM_, WGN_, P_, ALLT_>(a, st)
   if (c.th == 8 && c.tw == 32) {
-    if (c.bn == 128) CY_CONV_CASE(8, 32, 128, 2, 2, 128);
-    if (c.bn == 64) { if (small_k) CY_CONV_CASE(8, 32, 64, 4, 1, 64); CY_CONV_CASE(8, 32, 64, 4, 1, 128); }
-    if (small_k) CY_CONV_CASE(8, 32, 32, 4, 1, 64);
-    CY_CONV_CASE(8, 32, 32, 4, 1, 128);
+    if (c.bn == 128) CY_CONV_CASE(8, 32, 128, 2, 2, 128, false);
+    if (c.bn == 64) CY_CONV_CASE(8, 32, 64, 4, 1, 64, true);
+    CY_CONV_CASE(8, 32, 32, 4, 1, 64, true);
   }
   if (c.th == 16 && c.tw == 16) {
-    if (c.bn == 128) CY_CONV_CASE(16, 16, 128, 2, 2, 128);
-    if (c.bn == 64) { if (small_k) CY_CONV_CASE(16, 16, 64, 4, 1, 64); CY_CONV_CASE(16, 16, 64, 4, 1, 128); }
-    if (small_k) CY_CONV_CASE(16, 16, 32, 4, 1, 64);
-    CY_CONV_CASE(16, 16, 32, 4, 1, 128);
+    if (c.bn == 128) CY_CONV_CASE(16, 16, 128, 2, 2, 128, false);
+    if (c.bn == 64) CY_CONV_CASE(16, 16, 64, 4, 1, 64, true);
+    CY_CONV_CASE(16, 16, 32, 4, 1, 64, true);
   }
   if (c.th == 32 && c.tw == 8) {
-    if (c.bn == 128) CY_CONV_CASE(32, 8, 128, 2, 2, 128);
-    if (c.bn == 64) { if (small_k) CY_CONV_CASE(32, 8, 64, 4, 1, 64); CY_CONV_CASE(32, 8, 64, 4, 1, 128); }
-    if (small_k) CY_CONV_CASE(32, 8, 32, 4, 1, 64);
-    CY_CONV_CASE(32, 8, 32, 4, 1, 128);
+    if (c.bn == 128) CY_CONV_CASE(32, 8, 128, 2, 2, 128, false);
+    if (c.bn == 64) CY_CONV_CASE(32, 8, 64, 4, 1, 64, true);
+    CY_CONV_CASE(32, 8, 32, 4, 1, 64, true);
   }
-  if (c.th == 8 && c.tw == 28) CY_CONV_CASE(8, 28, 128, 1, 4, 128);
-  if (c.th == 16 && c.tw == 14) CY_CONV_CASE(16, 14, 128, 1, 4, 128);
+  if (c.th == 8 && c.tw == 28) CY_CONV_CASE(8, 28, 128, 1, 4, 128, false);
+  if (c.th == 16 && c.tw == 14) CY_CONV_CASE(16, 14, 128, 1, 4, 128, false);
 #undef CY_CONV_CASE
   return CY_ERR_SHAPE;
 }
