@@ -116,12 +116,15 @@ __device__ __forceinline__ void conv_row_tables(const ConvArgs& a, int TH, int R
 }
 
 // Stage the (TH+2)x(TW+2) halo tile of input channels [c0, c0+KC) into sA.
+// Loads are issued in batches of four independent 16-byte requests per thread before any of
+// them is consumed (a one-load-per-iteration loop serialises on L2/HBM latency).
 template <typename T, int PITCHB, bool SWZ>
 __device__ __forceinline__ void conv_stage_halo(const ConvArgs& a, unsigned char* sA,
                                                 const int* s_row1, const int* s_row2, int TH,
                                                 int TW, int w0, int c0, int tid) {
   constexpr int EPC = ElemTr<T>::EPC;
   constexpr int CPP = PITCHB / 16;
+  constexpr int NB = 4;  // loads in flight per thread
   const int HW2 = TW + 2;
   const int NCH = (TH + 2) * HW2 * CPP;
   const int ch = tid & (CPP - 1);  // constant per thread (256 % CPP == 0)
@@ -130,8 +133,42 @@ __device__ __forceinline__ void conv_stage_halo(const ConvArgs& a, unsigned char
   const bool cvalid = cabs < a.C1 + a.C2;
   const T* s1 = reinterpret_cast<const T*>(a.src1);
   const T* s2 = reinterpret_cast<const T*>(a.src2);
-  float sc[EPC], sh[EPC];
+
+  if (a.mode1 == CY_SRC_POOL2 && !in2) {
+    // 2x2 max on load: four requests per chunk are already independent
+    for (int idx = tid; idx < NCH; idx += 256) {
+      const int pix = idx / CPP;
+      const int hr = pix / HW2;
+      const int hc = pix - hr * HW2;
+      const int w = w0 - 1 + hc;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      const int rp = s_row1[hr];
+      if (cvalid && w >= 0 && w < a.W && rp >= 0) {
+        const T* p = s1 + (size_t)(rp + 2 * w) * a.ld1 + cabs;
+        const size_t rowstep = (size_t)(2 * a.W) * a.ld1;
+        u32x4 v00 = ld16(p), v01 = ld16(p + a.ld1), v10 = ld16(p + rowstep),
+              v11 = ld16(p + rowstep + a.ld1);
+        float f0[EPC], f1[EPC], f2[EPC], f3[EPC];
+        Chunk<T>::unpack(v00, f0);
+        Chunk<T>::unpack(v01, f1);
+        Chunk<T>::unpack(v10, f2);
+        Chunk<T>::unpack(v11, f3);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) f0[j] = fmaxf(fmaxf(f0[j], f1[j]), fmaxf(f2[j], f3[j]));
+        v = Chunk<T>::pack(f0);
+      }
+      st16(sA + pix * PITCHB + ((SWZ ? (ch ^ lds_swz<PITCHB>(pix)) : ch) << 4), v);
+    }
+    return;
+  }
+
+  // direct / nearest-upsample / second (concat) source: one request per chunk
+  const T* base = in2 ? s2 + (cabs - a.C1) : s1 + cabs;
+  const int ld = in2 ? a.ld2 : a.ld1;
+  const int* rtab = in2 ? s_row2 : s_row1;
+  const int wsh = (!in2 && a.mode1 == CY_SRC_UP2) ? 1 : 0;
   const bool pro = a.prologue && !in2 && cvalid;
+  float sc[EPC], sh[EPC];
   if (pro) {
 #pragma unroll
     for (int j = 0; j < EPC; ++j) {
@@ -139,47 +176,35 @@ __device__ __forceinline__ void conv_stage_halo(const ConvArgs& a, unsigned char
       sh[j] = a.shift[cabs + j];
     }
   }
-  for (int idx = tid; idx < NCH; idx += 256) {
-    const int pix = idx / CPP;
-    const int hr = pix / HW2;
-    const int hc = pix - hr * HW2;
-    const int w = w0 - 1 + hc;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (cvalid && w >= 0 && w < a.W) {
-      if (!in2) {
-        const int rp = s_row1[hr];
-        if (rp >= 0) {
-          if (a.mode1 == CY_SRC_DIRECT) {
-            v = ld16(s1 + (size_t)(rp + w) * a.ld1 + cabs);
-            if (pro) {
-              float f[EPC];
-              Chunk<T>::unpack(v, f);
+  for (int idx0 = tid; idx0 < NCH; idx0 += 256 * NB) {
+    u32x4 v[NB];
+    int dst[NB];
+    bool ok[NB];
 #pragma unroll
-              for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(sc[j], f[j], sh[j]), 0.f);
-              v = Chunk<T>::pack(f);
-            }
-          } else if (a.mode1 == CY_SRC_POOL2) {
-            const T* p = s1 + (size_t)(rp + 2 * w) * a.ld1 + cabs;
-            const size_t rowstep = (size_t)(2 * a.W) * a.ld1;
-            u32x4 v00 = ld16(p), v01 = ld16(p + a.ld1), v10 = ld16(p + rowstep),
-                  v11 = ld16(p + rowstep + a.ld1);
-            float f0[EPC], f1[EPC], f2[EPC], f3[EPC];
-            Chunk<T>::unpack(v00, f0);
-            Chunk<T>::unpack(v01, f1);
-            Chunk<T>::unpack(v10, f2);
-            Chunk<T>::unpack(v11, f3);
+    for (int b = 0; b < NB; ++b) {
+      const int idx = idx0 + b * 256;
+      const int pix = idx / CPP;
+      const int hr = pix / HW2;
+      const int hc = pix - hr * HW2;
+      const int w = w0 - 1 + hc;
+      dst[b] = idx < NCH ? pix * PITCHB + ((SWZ ? (ch ^ lds_swz<PITCHB>(pix)) : ch) << 4) : -1;
+      const int rp = idx < NCH ? rtab[hr] : -1;
+      ok[b] = cvalid && rp >= 0 && w >= 0 && w < a.W;
+      v[b] = u32x4{0u, 0u, 0u, 0u};
+      if (ok[b]) v[b] = ld16(base + (size_t)(rp + (w >> wsh)) * ld);
+    }
 #pragma unroll
-            for (int j = 0; j < EPC; ++j) f0[j] = fmaxf(fmaxf(f0[j], f1[j]), fmaxf(f2[j], f3[j]));
-            v = Chunk<T>::pack(f0);
-          } else {
-            v = ld16(s1 + (size_t)(rp + (w >> 1)) * a.ld1 + cabs);
-          }
+    for (int b = 0; b < NB; ++b) {
+      if (dst[b] >= 0) {
+        if (pro && ok[b]) {
+          float f[EPC];
+          Chunk<T>::unpack(v[b], f);
+#pragma unroll
+          for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(sc[j], f[j], sh[j]), 0.f);
+          v[b] = Chunk<T>::pack(f);
         }
-      } else {
-        const int rp = s_row2[hr];
-        if (rp >= 0) v = ld16(s2 + (size_t)(rp + w) * a.ld2 + (cabs - a.C1));
+        st16(sA + dst[b], v[b]);
       }
     }
-    st16(sA + pix * PITCHB + ((SWZ ? (ch ^ lds_swz<PITCHB>(pix)) : ch) << 4), v);
   }
 }

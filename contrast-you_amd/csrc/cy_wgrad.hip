@@ -122,15 +122,24 @@ __global__ void __launch_bounds__(256, 2)
       constexpr int CPA = PA / 16;
       const int ch = tid % CPA;
       const int co = co0 + ch * EPC;
-      for (int idx = tid; idx < npix_pad * CPA; idx += 256) {
-        const int k = idx / CPA;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (k < npix && co < a.Cout) {
-          const int ty = k / TW, tx = k - ty * TW;
-          const int R = R0 + ty, w = w0 + tx;
-          if (R < a.NH && w < a.W) v = ld16(dyp + ((size_t)R * a.W + w) * g.ldy + co);
+      const int nch = npix_pad * CPA;
+      for (int idx0 = tid; idx0 < nch; idx0 += 1024) {  // four independent requests in flight
+        u32x4 v[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int k = (idx0 + b * 256) / CPA;
+          v[b] = u32x4{0u, 0u, 0u, 0u};
+          if (k < npix && co < a.Cout) {
+            const int ty = k / TW, tx = k - ty * TW;
+            const int R = R0 + ty, w = w0 + tx;
+            if (R < a.NH && w < a.W) v[b] = ld16(dyp + ((size_t)R * a.W + w) * g.ldy + co);
+          }
         }
-        st16(sDy + k * PA + ch * 16, v);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int idx = idx0 + b * 256;
+          if (idx < nch) st16(sDy + (idx / CPA) * PA + ch * 16, v[b]);
+        }
       }
     }
     __syncthreads();
