@@ -27,6 +27,9 @@ def is_normalized(feature: Tensor, dim=1) -> bool:
     return torch.allclose(norms, torch.ones_like(norms))
 
 
+_label_cache = {}  # label tuple -> int32 device tensor (a few distinct partitions per dataset)
+
+
 def _encode_target(target, n: int, device) -> Tensor:
     """labels as int32 codes (equality is all that matters: contrastive.py:41)"""
     if isinstance(target, Tensor):
@@ -35,9 +38,18 @@ def _encode_target(target, n: int, device) -> Tensor:
             _, t = torch.unique(t, return_inverse=True)
         t = t.to(device=device, dtype=torch.int32)
     else:
-        vals = list(target)
-        lut = {}
-        t = torch.tensor([lut.setdefault(v, len(lut)) for v in vals], dtype=torch.int32, device=device)
+        vals = tuple(target)
+        assert len(vals) == n, (len(vals), n)
+        key = (vals, str(device))
+        t = _label_cache.get(key)
+        if t is None:
+            lut = {}
+            host = torch.tensor([lut.setdefault(v, len(lut)) for v in vals], dtype=torch.int32)
+            t = ops.pinned.upload(host, device)
+            if len(_label_cache) > 512:
+                _label_cache.clear()
+            _label_cache[key] = t
+        return t
     assert t.numel() == n, (t.numel(), n)
     return t.contiguous()
 

@@ -458,9 +458,14 @@ struct TileChoice {
 
 // Tile selection: exact column tilings where the image width allows, a masked
 // 16x16 tile otherwise.  7-MFMA-tile shapes (8x28, 16x14) exist for BN=128.
-TileChoice choose_tile(int W, int Cout) {
+TileChoice choose_tile(long NH, int W, int Cout) {
   TileChoice c;
   c.bn = Cout >= 128 ? 128 : (Cout > 32 ? 64 : 32);
+  if (Cout == 128 && W % 8 == 0) {
+    // 128-cout layers with few spatial tiles: two 64-cout tiles give the chip 2 workgroups per CU
+    const int th = W % 32 == 0 ? 8 : (W % 16 == 0 ? 16 : 32), tw = 256 / th;
+    if (cy_cdiv(NH, th) * cy_cdiv(W, tw) < 300) c.bn = 64;
+  }
   if (W % 32 == 0) {
     c.th = 8, c.tw = 32;
   } else if (W % 16 == 0) {
@@ -489,7 +494,7 @@ struct ConvPlan {
 // the reduction over input-channel chunks across blockIdx.z.
 ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes) {
   ConvPlan p;
-  p.tile = choose_tile(W, Cout);
+  p.tile = choose_tile((long)N * H, W, Cout);
   const long npix = (long)N * H * W;
   const int tiles = cy_cdiv((long)N * H, p.tile.th) * cy_cdiv(W, p.tile.tw);
   const int blocks = tiles * cy_cdiv(Cout, p.tile.bn);
@@ -525,7 +530,7 @@ int launch_finish(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
 
 template <typename T>
 int dispatch_conv(const ConvArgs& a, hipStream_t st) {
-  const TileChoice c = choose_tile(a.W, a.Cout);
+  const TileChoice c = choose_tile(a.NH, a.W, a.Cout);
   // BN <= 64 (small-channel, HBM-leaning layers): 64-byte channel chunks, all nine weight taps
   // resident in LDS.  BN = 128: 128-byte chunks, weights through a 2-deep per-tap ring.
 #define CY_CONV_CASE(TH_, TW_, BN_, WGM_, WGN_, P_, ALLT_) \

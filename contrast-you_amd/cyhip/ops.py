@@ -45,8 +45,35 @@ def dtype_code(dt: torch.dtype) -> int:
         raise TypeError(f"unsupported dtype {dt}: the HIP path computes in float32 or bfloat16") from None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """raw hipStream_t of torch's current stream on the current device"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+class PinnedRing:
+    """small ring of pinned host buffers for sync-free H2D copies of per-step parameters"""
+
+    def __init__(self, slots: int = 16):
+        self._slots, self._bufs, self._i = slots, {}, 0
+
+    def upload(self, host: Tensor, device) -> Tensor:
+        key = (tuple(host.shape), host.dtype)
+        ring = self._bufs.get(key)
+        if ring is None:
+            ring = self._bufs[key] = [torch.empty(host.shape, dtype=host.dtype).pin_memory()
+                                      for _ in range(self._slots)]
+        self._i = (self._i + 1) % self._slots
+        buf = ring[self._i]
+        buf.copy_(host)
+        return buf.to(device, non_blocking=True)
+
+
+pinned = PinnedRing()
 
 
 def _ptr(t: Optional[Tensor]) -> Optional[int]:

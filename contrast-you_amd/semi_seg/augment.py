@@ -53,8 +53,9 @@ class AffineAugment:
         hit = self._cache.get(key)
         if hit is None:
             theta, gam = self.sample(n, seed)
-            hit = (torch.from_numpy(theta).reshape(n, 6).to(device),
-                   None if gam is None else torch.from_numpy(gam).to(device))
+            from cyhip.ops import pinned
+            hit = (pinned.upload(torch.from_numpy(theta).reshape(n, 6), device),
+                   None if gam is None else pinned.upload(torch.from_numpy(gam), device))
             self._cache = {key: hit}  # one step's worth
         return hit
 
