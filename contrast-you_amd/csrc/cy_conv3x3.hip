@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256, 2)
           wreg[i] = ld16(wp + ((size_t)(tap * a.w_co_pad + n0 + row)) * a.w_ci_pad + cc * KC + ch * EPC);
         }
       }
-      conv_stage_halo<T, PITCHB, true>(a, sA, s_row1, s_row2, TH, TW, w0, cc * KC, tid);
+      conv_stage_halo<T, PITCHB, 1>(a, sA, s_row1, s_row2, TH, TW, HW2, w0, cc * KC, tid);
 #pragma unroll
       for (int i = 0; i < NBR; ++i) {
         const int idx = tid + i * 256;
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256, 2)
     }
     __syncthreads();
   } else {
-    conv_stage_halo<T, PITCHB, true>(a, sA, s_row1, s_row2, TH, TW, w0, cc0 * KC, tid);
+    conv_stage_halo<T, PITCHB, 1>(a, sA, s_row1, s_row2, TH, TW, HW2, w0, cc0 * KC, tid);
     load_b(cc0, 0);
     store_b(sB);
     __syncthreads();
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256, 2)
       if (has_next) store_b(sB + ((it + 1 - it0) & 1) * C::B_BYTES);
       if (tap == 8 && has_next) {
         __syncthreads();  // every wave is done reading the halo tile
-        conv_stage_halo<T, PITCHB, true>(a, sA, s_row1, s_row2, TH, TW, w0, (cc + 1) * KC, tid);
+        conv_stage_halo<T, PITCHB, 1>(a, sA, s_row1, s_row2, TH, TW, HW2, w0, (cc + 1) * KC, tid);
       }
       __syncthreads();
     }

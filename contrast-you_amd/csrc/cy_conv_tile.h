@@ -118,10 +118,20 @@ __device__ __forceinline__ void conv_row_tables(const ConvArgs& a, int TH, int R
 // Stage the (TH+2)x(TW+2) halo tile of input channels [c0, c0+KC) into sA.
 // Loads are issued in batches of four independent 16-byte requests per thread before any of
 // them is consumed (a one-load-per-iteration loop serialises on L2/HBM latency).
-template <typename T, int PITCHB, bool SWZ>
+// SWZ: 0 = linear, 1 = forward-kernel chunk swizzle (lds_swz), 2 = "pair" swizzle for the
+// transposed reads of the weight-gradient kernel (128-byte pixels: the two 64-byte halves of
+// every second pixel pair are exchanged, so 4 consecutive pixels x 64 B cover all 64 banks).
+// HP = LDS row pitch of the halo tile in pixels (>= TW+2).
+template <int PITCHB, int SWZ> __device__ __forceinline__ int halo_chunk(int pix, int ch) {
+  if (SWZ == 1) return ch ^ lds_swz<PITCHB>(pix);
+  if (SWZ == 2) return ch ^ (((pix >> 1) & 1) << 2);
+  return ch;
+}
+
+template <typename T, int PITCHB, int SWZ>
 __device__ __forceinline__ void conv_stage_halo(const ConvArgs& a, unsigned char* sA,
                                                 const int* s_row1, const int* s_row2, int TH,
-                                                int TW, int w0, int c0, int tid) {
+                                                int TW, int HP, int w0, int c0, int tid) {
   constexpr int EPC = ElemTr<T>::EPC;
   constexpr int CPP = PITCHB / 16;
   constexpr int NB = 4;  // loads in flight per thread
@@ -137,9 +147,10 @@ __device__ __forceinline__ void conv_stage_halo(const ConvArgs& a, unsigned char
   if (a.mode1 == CY_SRC_POOL2 && !in2) {
     // 2x2 max on load: four requests per chunk are already independent
     for (int idx = tid; idx < NCH; idx += 256) {
-      const int pix = idx / CPP;
-      const int hr = pix / HW2;
-      const int hc = pix - hr * HW2;
+      const int lin = idx / CPP;
+      const int hr = lin / HW2;
+      const int hc = lin - hr * HW2;
+      const int pix = hr * HP + hc;
       const int w = w0 - 1 + hc;
       u32x4 v = {0u, 0u, 0u, 0u};
       const int rp = s_row1[hr];
@@ -157,7 +168,7 @@ __device__ __forceinline__ void conv_stage_halo(const ConvArgs& a, unsigned char
         for (int j = 0; j < EPC; ++j) f0[j] = fmaxf(fmaxf(f0[j], f1[j]), fmaxf(f2[j], f3[j]));
         v = Chunk<T>::pack(f0);
       }
-      st16(sA + pix * PITCHB + ((SWZ ? (ch ^ lds_swz<PITCHB>(pix)) : ch) << 4), v);
+      st16(sA + pix * PITCHB + (halo_chunk<PITCHB, SWZ>(pix, ch) << 4), v);
     }
     return;
   }
@@ -183,11 +194,12 @@ __device__ __forceinline__ void conv_stage_halo(const ConvArgs& a, unsigned char
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int idx = idx0 + b * 256;
-      const int pix = idx / CPP;
-      const int hr = pix / HW2;
-      const int hc = pix - hr * HW2;
+      const int lin = idx / CPP;
+      const int hr = lin / HW2;
+      const int hc = lin - hr * HW2;
+      const int pix = hr * HP + hc;
       const int w = w0 - 1 + hc;
-      dst[b] = idx < NCH ? pix * PITCHB + ((SWZ ? (ch ^ lds_swz<PITCHB>(pix)) : ch) << 4) : -1;
+      dst[b] = idx < NCH ? pix * PITCHB + (halo_chunk<PITCHB, SWZ>(pix, ch) << 4) : -1;
       const int rp = idx < NCH ? rtab[hr] : -1;
       ok[b] = cvalid && rp >= 0 && w >= 0 && w < a.W;
       v[b] = u32x4{0u, 0u, 0u, 0u};

@@ -56,7 +56,7 @@ struct WgCfg {
   static constexpr int PA = BCO * (int)sizeof(T);  // dy tile pitch (bytes)
   static constexpr int PB = BCI * (int)sizeof(T);  // halo pitch
   static constexpr int MAXPIX = 256;               // TH*TW padded to 16 <= 256
-  static constexpr int MAXHALO = 352;              // (TH+2)*(TW+2) upper bound used for sizing
+  static constexpr int MAXHALO = 360;              // (TH+2)*roundup(TW+2,4) upper bound used for sizing
   static constexpr int A_BYTES = MAXPIX * PA;
   static constexpr int B_BYTES = MAXHALO * PB;
   static constexpr int RED_BYTES = WK > 1 ? WCO * WCI * WK * 32 * 32 * 4 : 0;
@@ -74,6 +74,9 @@ __global__ void __launch_bounds__(256, 2)
   constexpr int PA = C::PA, PB = C::PB;
   constexpr int EPC = ElemTr<T>::EPC;
   constexpr bool IS_BF16 = sizeof(T) == 2;
+  // bf16 operands with 128-byte pixels are read by ds_read_b64_tr_b16: pair-swizzle them
+  constexpr int SWA = (IS_BF16 && PA == 128) ? 2 : 0;
+  constexpr int SWB = (IS_BF16 && PB == 128) ? 2 : 0;
   const ConvArgs& a = g.c;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -92,7 +95,8 @@ __global__ void __launch_bounds__(256, 2)
   const int wco = wave / (WK * WCI);
   const int r = lane & 31, h = lane >> 5;
 
-  const int TH = g.TH, TW = g.TW, HW2 = TW + 2;
+  const int TH = g.TH, TW = g.TW;
+  const int HW2 = (TW + 2 + 3) & ~3;  // LDS row pitch of the halo tile (pixels), multiple of 4
   const int npix = TH * TW;
   const int nsteps = (npix + 15) / 16;
   const int npix_pad = nsteps * 16;
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(256, 2)
     __syncthreads();  // previous tile fully consumed
     conv_row_tables(a, TH, R0, tid, s_row1, s_row2, s_flag, true);
     __syncthreads();
-    conv_stage_halo<T, PB, false>(a, sIn, s_row1, s_row2, TH, TW, w0, ci0, tid);
+    conv_stage_halo<T, PB, SWB>(a, sIn, s_row1, s_row2, TH, TW, HW2, w0, ci0, tid);
     // dy tile: rows = pixels k (ty*TW+tx), BCO channels
     {
       constexpr int CPA = PA / 16;
@@ -138,7 +142,10 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const int idx = idx0 + b * 256;
-          if (idx < nch) st16(sDy + (idx / CPA) * PA + ch * 16, v[b]);
+          if (idx < nch) {
+            const int k = idx / CPA;
+            st16(sDy + k * PA + (halo_chunk<PA, SWA>(k, ch) << 4), v[b]);
+          }
         }
       }
     }
@@ -150,19 +157,29 @@ __global__ void __launch_bounds__(256, 2)
         // this lane supplies row q of the 4x16 blocks of its 16-lane group
         const int q = (lane & 15) >> 2, p = lane & 3, gsel = (lane >> 4) & 1;
         const int k1 = kb + 8 * h + q, k2 = k1 + 4;
-        const unsigned char* a_lo = sDy + k1 * PA + (wco * 32 + 16 * gsel + 4 * p) * 2;
+        // (k1 >> 1) & 1 == ((k1 + 4) >> 1) & 1: both rows share the swizzle term
+        const int acol = ((wco * 32 + 16 * gsel + 4 * p) * 2) ^ (SWA == 2 ? (((k1 >> 1) & 1) << 6) : 0);
+        const unsigned char* a_lo = sDy + k1 * PA + acol;
         const unsigned char* a_hi = a_lo + 4 * PA;
         const Mma<bf16>::Frag af = WFrag<bf16>::load(a_lo, a_hi);
         int kk1 = k1 < npix ? k1 : 0, kk2 = k2 < npix ? k2 : 0;
         const int ty1 = kk1 / TW, tx1 = kk1 - ty1 * TW;
         const int ty2 = kk2 / TW, tx2 = kk2 - ty2 * TW;
         const int colb = (wci * 32 + 16 * gsel + 4 * p) * 2;
-        const unsigned char* b1 = sIn + ((ty1 + 1) * HW2 + tx1 + 1) * PB + colb;
-        const unsigned char* b2 = sIn + ((ty2 + 1) * HW2 + tx2 + 1) * PB + colb;
+        const int p1 = (ty1 + 1) * HW2 + tx1 + 1, p2 = (ty2 + 1) * HW2 + tx2 + 1;
+        // swizzle term of pixel p + dh*HW2 + dw depends on dw only (HW2 % 4 == 0)
+        int c1[3], c2[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          c1[d] = colb ^ (SWB == 2 ? ((((p1 + d - 1) >> 1) & 1) << 6) : 0);
+          c2[d] = colb ^ (SWB == 2 ? ((((p2 + d - 1) >> 1) & 1) << 6) : 0);
+        }
+        const unsigned char* b1 = sIn + p1 * PB;
+        const unsigned char* b2 = sIn + p2 * PB;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           const int off = ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) * PB;
-          const Mma<bf16>::Frag bf = WFrag<bf16>::load(b1 + off, b2 + off);
+          const Mma<bf16>::Frag bf = WFrag<bf16>::load(b1 + off + c1[tap % 3], b2 + off + c2[tap % 3]);
           Mma<bf16>::mma(af, bf, acc[tap]);
         }
       } else {
@@ -302,7 +319,7 @@ WgPlan plan_wgrad(const cy_conv_desc* d) {
   p.TW = d->W <= 32 ? d->W : (d->W % 32 == 0 ? 32 : 16);
   int best = 1;
   for (int th = 1; th <= d->H && th * p.TW <= 256; ++th)
-    if (d->H % th == 0 && (th + 2) * (p.TW + 2) <= 352 && th + 2 <= 40) best = th;
+    if (d->H % th == 0 && (th + 2) * ((p.TW + 2 + 3) & ~3) <= 360 && th + 2 <= 40) best = th;
   p.TH = best;
   p.tiles_h = (d->N * d->H) / p.TH;
   p.tiles_w = cy_cdiv(d->W, p.TW);

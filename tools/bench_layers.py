@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--hw", type=int, default=224)
     ap.add_argument("--maxc", type=int, default=512)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--only", default="", help="comma list of layer names")
+    ap.add_argument("--iters", type=int, default=10)
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda"
@@ -49,7 +51,10 @@ def main():
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     totf = 0.0
     print(f"{'layer':12s} {'HxW':>5s} {'Cin':>5s} {'Cout':>5s} | {'fwd ms':>8s} {'TF/s':>7s} | {'dgrad ms':>8s} {'TF/s':>7s} | {'wgrad ms':>8s} {'TF/s':>7s}")
+    only = set(x for x in a.only.split(",") if x)
     for name, H, C1, C2, Cout, mode, pro in layers:
+        if only and name not in only:
+            continue
         N = a.n
         sh = 2 * H if mode == 1 else (H // 2 if mode == 2 else H)
         x1 = ops.empty_nhwc(N, C1, sh, sh, dt, dev).normal_()
@@ -60,9 +65,9 @@ def main():
         shift = torch.rand(C1, device=dev) - 0.5 if pro else None
         dy = ops.empty_nhwc(N, Cout, H, H, dt, dev).normal_()
         flops = 2.0 * N * H * H * 9 * (C1 + C2) * Cout
-        t_f = timeit(lambda: ops.conv3x3_fwd(x1, x2, wf, Cout, mode=mode, scale=scale, shift=shift))
-        t_d = timeit(lambda: ops.conv3x3_fwd(dy, None, wd, C1 + C2, want_stats=False))
-        t_w = timeit(lambda: ops.conv3x3_wgrad(x1, x2, dy, mode=mode, scale=scale, shift=shift))
+        t_f = timeit(lambda: ops.conv3x3_fwd(x1, x2, wf, Cout, mode=mode, scale=scale, shift=shift), a.iters, 1)
+        t_d = timeit(lambda: ops.conv3x3_fwd(dy, None, wd, C1 + C2, want_stats=False), a.iters, 1)
+        t_w = timeit(lambda: ops.conv3x3_wgrad(x1, x2, dy, mode=mode, scale=scale, shift=shift), a.iters, 1)
         tot["fwd"] += t_f
         tot["dgrad"] += t_d
         tot["wgrad"] += t_w
