@@ -45,18 +45,19 @@ def create_mt_hook(*, model: nn.Module, weight: float, alpha: float = 0.999, wei
 
 
 def _infonce_hook(*, model: nn.Module, feature_name: str, weight: float, contrast_on: str, data_name: str,
-                  spatial_size: int):
+                  spatial_size: int, global_negatives: bool = False):
     return INFONCEHook(name=f"infonce/{feature_name}/{contrast_on}", model=model, feature_name=feature_name,
                        weight=weight, data_name=data_name, contrast_on=contrast_on,
-                       spatial_size=(spatial_size, spatial_size))
+                       spatial_size=(spatial_size, spatial_size), global_negatives=global_negatives)
 
 
 def create_infonce_hooks(*, model: nn.Module, feature_names: Union[str, List[str]],
                          weights: Union[float, List[float]], contrast_ons: Union[str, List[str]],
-                         spatial_size: Union[int, Sequence[int]] = 1, data_name: str):
+                         spatial_size: Union[int, Sequence[int]] = 1, data_name: str,
+                         global_negatives: bool = False):
     n = 1 if isinstance(feature_names, str) else len(feature_names)
     rep = ntuple(n)
     hooks = [_infonce_hook(model=model, feature_name=f, weight=w, contrast_on=c, data_name=data_name,
-                           spatial_size=ss)
+                           spatial_size=ss, global_negatives=global_negatives)
              for f, w, c, ss in zip(rep(feature_names), rep(weights), rep(contrast_ons), rep(spatial_size))]
     return CombineTrainerHook(*hooks)

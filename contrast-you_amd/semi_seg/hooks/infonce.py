@@ -20,6 +20,7 @@ from contrastyou.arch.utils import SingleFeatureExtractor
 from contrastyou.hooks.base import EpocherHook, TrainerHook
 from contrastyou.losses.contrastive import SupConLoss1
 from contrastyou.meters import AverageValueMeter, MeterInterface
+from cyhip import parallel
 
 from .utils import get_label
 
@@ -31,8 +32,11 @@ class INFONCEHook(TrainerHook):
         return [self._projector]
 
     def __init__(self, *, name, model: nn.Module, feature_name: str, weight: float = 1.0,
-                 spatial_size: t.Sequence[int] = None, data_name: str, contrast_on: str) -> None:
+                 spatial_size: t.Sequence[int] = None, data_name: str, contrast_on: str,
+                 global_negatives: bool = False) -> None:
         super().__init__(hook_name=name)
+        # data-parallel runs: contrast against the embeddings of every rank (all-gather over RCCL)
+        self._global_negatives = global_negatives
         self.register_non_trackable_buffer("_model", model)
         assert feature_name in model.arch_elements, feature_name
         self._feature_name = feature_name
@@ -52,7 +56,8 @@ class INFONCEHook(TrainerHook):
     def __call__(self):
         return _INFONCEEpochHook(name=self._hook_name, weight=self._weight, extractor=self._extractor,
                                  projector=self._projector, criterion=self._criterion,
-                                 label_generator=self._label_generator)
+                                 label_generator=self._label_generator,
+                                 global_negatives=self._global_negatives)
 
     def init_criterion(self) -> SupConLoss1:
         self._criterion = SupConLoss1()
@@ -75,8 +80,9 @@ class INFONCEHook(TrainerHook):
 class _INFONCEEpochHook(EpocherHook):
 
     def __init__(self, *, name: str, weight: float, extractor, projector, criterion: Union[SupConLoss1],
-                 label_generator) -> None:
+                 label_generator, global_negatives: bool = False) -> None:
         super().__init__(name=name)
+        self._global_negatives = global_negatives
         self._extractor = extractor
         self._extractor.bind()
         self._weight = weight
@@ -106,8 +112,17 @@ class _INFONCEEpochHook(EpocherHook):
         unlabeled_features_tf = affine_transformer(unlabeled_features)
         norm_features_tf, norm_tf_features = torch.chunk(
             self._projector(torch.cat([unlabeled_features_tf, unlabeled_tf_features], dim=0)), 2)
-        labels = self._label_generator(partition_group=partition_group, label_group=label_group)
-        loss = self._criterion(norm_features_tf, norm_tf_features, target=labels)
+        if self._global_negatives and parallel.is_parallel():
+            # same label semantics on the concatenated groups of all ranks; every rank evaluates the
+            # full matrix, autograd follows its own rows, and the loss is scaled by world_size
+            # because the optimizer averages gradients over ranks
+            labels = self._label_generator(partition_group=parallel.gather_labels(partition_group),
+                                           label_group=parallel.gather_labels(label_group))
+            loss = self._criterion(parallel.gather_cat(norm_features_tf), parallel.gather_cat(norm_tf_features),
+                                   target=labels) * parallel.world_size()
+        else:
+            labels = self._label_generator(partition_group=partition_group, label_group=label_group)
+            loss = self._criterion(norm_features_tf, norm_tf_features, target=labels)
         self.meters["loss"].add(loss.detach())
         self._n += 1
         return loss * self._weight

@@ -1,0 +1,70 @@
+"""world_size-2 `gloo` tests (CPU) of the data-parallel plumbing: flat-buffer gradient all-reduce
+inside FusedRAdam and the embedding all-gather with local-only autograd."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = Path(__file__).resolve().parents[1]
+
+
+def _worker(rank: int, world: int, port: int, q):
+    sys.path.insert(0, str(REPO / "contrast-you_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from contrastyou.optim.fused_radam import FusedRAdam
+        from cyhip import parallel
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+        head = torch.nn.Linear(3, 2)
+        opt = FusedRAdam([{"params": list(net.parameters())}, {"params": list(head.parameters())}], lr=1e-3)
+        assert opt._dp, "data-parallel mode must switch on by itself when world_size > 1"
+        opt.zero_grad()
+        # parameters now live in one flat buffer per group
+        p0 = next(net.parameters())
+        assert p0.data_ptr() == opt._flat[0].data.data_ptr()
+        x = torch.randn(4, 5, generator=torch.Generator().manual_seed(100 + rank))
+        loss = head(net(x)).pow(2).mean()
+        loss.backward()
+        local = [f.grad.clone() for f in opt._flat]
+        opt.all_reduce_grads()
+        gathered = [[torch.empty_like(g) for _ in range(world)] for g in local]
+        for g, buf in zip(local, gathered):
+            dist.all_gather(buf, g)
+        for f, buf in zip(opt._flat, gathered):
+            assert torch.allclose(f.grad, torch.stack(buf).mean(0), atol=1e-7)
+        # embedding all-gather: values from every rank, gradient only into the local rows
+        z = torch.full((3, 4), float(rank + 1), requires_grad=True)
+        zg = parallel.gather_cat(z)
+        assert zg.shape == (3 * world, 4)
+        assert torch.equal(zg[:3], torch.full((3, 4), 1.0)) and torch.equal(zg[3:], torch.full((3, 4), 2.0))
+        (zg * torch.arange(zg.numel()).view_as(zg).float()).sum().backward()
+        expect = torch.arange(zg.numel()).view_as(zg).float()[3 * rank: 3 * rank + 3]
+        assert torch.equal(z.grad, expect)
+        labels = parallel.gather_labels([f"r{rank}_{i}" for i in range(2)])
+        assert labels == ["r0_0", "r0_1", "r1_0", "r1_1"]
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_grad_allreduce_and_embedding_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r, msg in results:
+        assert msg == "ok", f"rank {r}: {msg}"
