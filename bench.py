@@ -111,19 +111,28 @@ def kernel_roofline(ctx, device, steps: int = 3):
     run_epoch(ctx, device, steps, 99)
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
-    fam = {}
-    for kind, flops, e0, e1 in rec:
+    fam, fam_bytes = {}, {}
+    for kind, flops, e0, e1, *rest in rec:
         f = fam.setdefault(kind, [0.0, 0.0, 0])
         f[0] += flops
         f[1] += e0.elapsed_time(e1) * 1e-3
         f[2] += 1
+        if rest:
+            fam_bytes[kind] = fam_bytes.get(kind, 0.0) + rest[0]
     if not fam:
         return None, {}
     dom = max(fam, key=lambda k: fam[k][1])
     fl, sec, cnt = fam[dom]
     ach = fl / sec / 1e12
+    # HBM bytes per launch of the same family from the two PMC passes (FETCH_SIZE, WRITE_SIZE) of this
+    # command, summarised by tools/traffic_summary.py into profiles/ (a profiler cannot wrap itself)
+    traffic = None
+    tfile = REPO / "profiles" / "r01_traffic.json"
+    if tfile.exists():
+        traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
     roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": round(fam_bytes.get(dom, 0.0) / cnt) if fam_bytes.get(dom) else None,
             "launches_per_step": cnt // steps, "avg_launch_ms": round(sec / cnt * 1e3, 4)}
     detail = {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / steps * 1e3, 3),
                   "launches_per_step": v[2] // steps, "tflop_per_step": round(v[0] / steps / 1e12, 4)}

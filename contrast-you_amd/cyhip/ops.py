@@ -30,12 +30,12 @@ def _prof_begin():
     return e
 
 
-def _prof_end(e0, kind: str, flops: float):
+def _prof_end(e0, kind: str, flops: float, nbytes: float = 0.0):
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    PROFILE.append((kind, flops, e0, e1))
+    PROFILE.append((kind, flops, e0, e1, nbytes))
 
 
 def dtype_code(dt: torch.dtype) -> int:
@@ -184,7 +184,10 @@ def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, 
     ev = _prof_begin()
     _lib.call("cy_conv3x3_fwd", C.byref(d), src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
               wf.data_ptr(), out.data_ptr(), _ptr(out2), _ptr(stats), _ptr(ws), nbytes, _stream())
-    _prof_end(ev, "conv3x3_igemm", 2.0 * N * H * W * 9 * (C1 + C2) * Cout)
+    if ev is not None:  # algorithmic bytes: every input and output element once, packed weights once
+        esz = src1.element_size()
+        nb = esz * (src1.numel() + (0 if src2 is None else src2.numel()) + N * H * W * Cout + 9 * (C1 + C2) * Cout)
+        _prof_end(ev, "conv3x3_igemm", 2.0 * N * H * W * 9 * (C1 + C2) * Cout, float(nb))
     if split:
         return (out, out2), None
     return out, stats
@@ -214,7 +217,10 @@ def conv3x3_wgrad(src1: Tensor, src2: Optional[Tensor], dy: Tensor, *, mode: int
     ev = _prof_begin()
     _lib.call("cy_conv3x3_wgrad", C.byref(d), src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
               dy.data_ptr(), dw.data_ptr(), 0 if out is None else 1, ws.data_ptr(), nbytes, _stream())
-    _prof_end(ev, "conv3x3_wgrad", 2.0 * N * H * W * 9 * (C1 + C2) * Cout)
+    if ev is not None:
+        esz = src1.element_size()
+        nb = esz * (src1.numel() + (0 if src2 is None else src2.numel()) + dy.numel()) + 4 * 9 * (C1 + C2) * Cout
+        _prof_end(ev, "conv3x3_wgrad", 2.0 * N * H * W * 9 * (C1 + C2) * Cout, float(nb))
     return dw
 
 
