@@ -61,7 +61,8 @@ struct WgCfg {
   static constexpr int B_BYTES = MAXHALO * PB;
   static constexpr int RED_BYTES = WK > 1 ? WCO * WCI * WK * 32 * 32 * 4 : 0;
   static constexpr int MAIN = A_BYTES + B_BYTES;
-  static constexpr int TAB = 3 * 40 * 4;
+  static constexpr int HP = 36;                    // fixed LDS row pitch of the halo tile (pixels)
+  static constexpr int TAB = 3 * 40 * 4 + 256 * 4;  // row tables + pixel->halo index table
   static constexpr int SMEM = (MAIN > RED_BYTES ? MAIN : RED_BYTES) + TAB + 16;
   static_assert(WCO * WCI * WK == 4, "4 waves");
   static_assert(PB == 64 || PB == 128, "halo pitch");
@@ -86,6 +87,7 @@ __global__ void __launch_bounds__(256, 2)
   int* s_row1 = reinterpret_cast<int*>(smem + ((MAINB + 15) & ~15));
   int* s_row2 = s_row1 + 40;
   int* s_flag = s_row2 + 40;
+  int* s_ktab = s_flag + 40;  // tile pixel k -> halo pixel index (ty+1)*HP + tx+1
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -96,7 +98,9 @@ __global__ void __launch_bounds__(256, 2)
   const int r = lane & 31, h = lane >> 5;
 
   const int TH = g.TH, TW = g.TW;
-  const int HW2 = (TW + 2 + 3) & ~3;  // LDS row pitch of the halo tile (pixels), multiple of 4
+  // Fixed halo row pitch: the nine tap offsets are compile-time immediates of the LDS reads and the
+  // pair-swizzle term of a shifted pixel depends on dw only (pitch % 4 == 0).
+  constexpr int HW2 = C::HP;
   const int npix = TH * TW;
   const int nsteps = (npix + 15) / 16;
   const int npix_pad = nsteps * 16;
@@ -113,13 +117,20 @@ __global__ void __launch_bounds__(256, 2)
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
   const T* dyp = reinterpret_cast<const T*>(g.dy);
+  // the tile shape is the same for every tile: tabulate pixel -> halo index once
+  {
+    const int npix_ = g.TH * g.TW;
+    const int kk = tid < npix_ ? tid : 0;
+    const int ty = kk / g.TW, tx = kk - ty * g.TW;
+    s_ktab[tid] = (ty + 1) * C::HP + tx + 1;
+  }
 
   for (int tile = split; tile < ntiles; tile += g.S) {
     const int ct = tile % g.tiles_w, rt = tile / g.tiles_w;
     const int R0 = rt * TH, w0 = ct * TW;
     __syncthreads();  // previous tile fully consumed
     conv_row_tables(a, TH, R0, tid, s_row1, s_row2, s_flag, true);
-    __syncthreads();
+    __syncthreads();  // (also publishes s_ktab on the first tile)
     conv_stage_halo<T, PB, SWB>(a, sIn, s_row1, s_row2, TH, TW, HW2, w0, ci0, tid);
     // dy tile: rows = pixels k (ty*TW+tx), BCO channels
     {
@@ -134,7 +145,8 @@ __global__ void __launch_bounds__(256, 2)
           const int k = (idx0 + b * 256) / CPA;
           v[b] = u32x4{0u, 0u, 0u, 0u};
           if (k < npix && co < a.Cout) {
-            const int ty = k / TW, tx = k - ty * TW;
+            const int hp = s_ktab[k];
+            const int ty = hp / HW2 - 1, tx = hp % HW2 - 1;
             const int R = R0 + ty, w = w0 + tx;
             if (R < a.NH && w < a.W) v[b] = ld16(dyp + ((size_t)R * a.W + w) * g.ldy + co);
           }
@@ -162,11 +174,8 @@ __global__ void __launch_bounds__(256, 2)
         const unsigned char* a_lo = sDy + k1 * PA + acol;
         const unsigned char* a_hi = a_lo + 4 * PA;
         const Mma<bf16>::Frag af = WFrag<bf16>::load(a_lo, a_hi);
-        int kk1 = k1 < npix ? k1 : 0, kk2 = k2 < npix ? k2 : 0;
-        const int ty1 = kk1 / TW, tx1 = kk1 - ty1 * TW;
-        const int ty2 = kk2 / TW, tx2 = kk2 - ty2 * TW;
         const int colb = (wci * 32 + 16 * gsel + 4 * p) * 2;
-        const int p1 = (ty1 + 1) * HW2 + tx1 + 1, p2 = (ty2 + 1) * HW2 + tx2 + 1;
+        const int p1 = s_ktab[k1], p2 = s_ktab[k2];  // (pad pixels map to pixel 0; their dy rows are zero)
         // swizzle term of pixel p + dh*HW2 + dw depends on dw only (HW2 % 4 == 0)
         int c1[3], c2[3];
 #pragma unroll
@@ -174,12 +183,19 @@ __global__ void __launch_bounds__(256, 2)
           c1[d] = colb ^ (SWB == 2 ? ((((p1 + d - 1) >> 1) & 1) << 6) : 0);
           c2[d] = colb ^ (SWB == 2 ? ((((p2 + d - 1) >> 1) & 1) << 6) : 0);
         }
-        const unsigned char* b1 = sIn + p1 * PB;
-        const unsigned char* b2 = sIn + p2 * PB;
+        // three bases per row (one per dw); the tap offsets below are compile-time immediates
+        const unsigned char* b1[3];
+        const unsigned char* b2[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          b1[d] = sIn + p1 * PB + c1[d];
+          b2[d] = sIn + p2 * PB + c2[d];
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          const int off = ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) * PB;
-          const Mma<bf16>::Frag bf = WFrag<bf16>::load(b1 + off + c1[tap % 3], b2 + off + c2[tap % 3]);
+          constexpr int dummy = 0;
+          const int off = ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) * PB + dummy;
+          const Mma<bf16>::Frag bf = WFrag<bf16>::load(b1[tap % 3] + off, b2[tap % 3] + off);
           Mma<bf16>::mma(af, bf, acc[tap]);
         }
       } else {
@@ -191,9 +207,7 @@ __global__ void __launch_bounds__(256, 2)
           const int k = kb + 8 * h + j;
           const float v = *reinterpret_cast<const float*>(sDy + k * PA + (wco * 32 + r) * 4);
           if (j < 4) af.lo[j] = v; else af.hi[j - 4] = v;
-          const int kk = k < npix ? k : 0;
-          const int ty = kk / TW, tx = kk - ty * TW;
-          hidx[j] = (ty + 1) * HW2 + tx + 1;
+          hidx[j] = s_ktab[k];
         }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -315,11 +329,12 @@ WgPlan plan_wgrad(const cy_conv_desc* d) {
   }
   p.co_pad = cy_roundup(d->Cout, 32 * p.wco);
   p.ci_pad = cy_roundup(Cin, 32 * p.wci);
-  // spatial tile: TW columns, TH rows with TH | H and TH*TW <= 256, (TH+2)*(TW+2) <= 352
-  p.TW = d->W <= 32 ? d->W : (d->W % 32 == 0 ? 32 : 16);
+  // spatial tile: TW <= 32 columns (halo row pitch is fixed at 36 pixels), TH <= 8 rows with
+  // TH | H (tiles never span images) and TH*TW <= 256
+  p.TW = d->W <= 32 ? d->W : (d->W % 32 == 0 ? 32 : (d->W % 28 == 0 ? 28 : 16));
   int best = 1;
-  for (int th = 1; th <= d->H && th * p.TW <= 256; ++th)
-    if (d->H % th == 0 && (th + 2) * ((p.TW + 2 + 3) & ~3) <= 360 && th + 2 <= 40) best = th;
+  for (int th = 1; th <= 8 && th <= d->H && th * p.TW <= 256; ++th)
+    if (d->H % th == 0) best = th;
   p.TH = best;
   p.tiles_h = (d->N * d->H) / p.TH;
   p.tiles_w = cy_cdiv(d->W, p.TW);
