@@ -16,13 +16,14 @@ __global__ void __launch_bounds__(1024)
                        float* running_mean, float* running_var, float momentum, float eps,
                        int use_batch_stats, int update_running, float* scale, float* shift,
                        float* mean_out, float* invstd_out) {
-  // block = 16 channels x 64 partial slices; fixed summation order (slice-major) => deterministic
-  __shared__ double sred[2][64][16];
-  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  // block = 4 channels x 256 partial slices (many small blocks: the reduction is latency-bound);
+  // fixed summation order (slice-major) => deterministic
+  __shared__ double sred[2][256][4];
+  const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C && use_batch_stats) {
-    for (int p = sl; p < P; p += 64) {
+    for (int p = sl; p < P; p += 256) {
       s1 += (double)partials[((size_t)p * 2 + 0) * C + c];
       s2 += (double)partials[((size_t)p * 2 + 1) * C + c];
     }
@@ -34,7 +35,7 @@ __global__ void __launch_bounds__(1024)
     double mean, var;
     if (use_batch_stats) {
       double t1 = 0.0, t2 = 0.0;
-      for (int q = 0; q < 64; ++q) {
+      for (int q = 0; q < 256; ++q) {
         t1 += sred[0][q][cl];
         t2 += sred[1][q][cl];
       }
@@ -192,12 +193,12 @@ __global__ void __launch_bounds__(256)
                            const float* __restrict__ scale, const float* __restrict__ mean,
                            const float* __restrict__ invstd, double count, int batch_stats,
                            float* dgamma, float* dbeta, int accumulate, float* __restrict__ coef) {
-  __shared__ double sred[2][16][16];
-  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  __shared__ double sred[2][64][4];
+  const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
-    for (int p = sl; p < P; p += 16) {
+    for (int p = sl; p < P; p += 64) {
       s1 += (double)partials[((size_t)p * 2 + 0) * C + c];
       s2 += (double)partials[((size_t)p * 2 + 1) * C + c];
     }
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   if (sl == 0 && c < C) {
     double t1 = 0.0, t2 = 0.0;
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < 64; ++q) {
       t1 += sred[0][q][cl];
       t2 += sred[1][q][cl];
     }
@@ -355,7 +356,7 @@ int cy_bn_finalize(const float* partials, int num_partials, int C, double count,
   if (C <= 0 || !scale || !shift || !mean || !invstd) return CY_ERR_ARG;
   if (use_batch_stats && (!partials || num_partials <= 0 || count <= 0)) return CY_ERR_ARG;
   if ((!use_batch_stats || update_running) && (!running_mean || !running_var)) return CY_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cy_cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cy_cdiv(C, 4)), dim3(1024), 0, (hipStream_t)stream,
                      partials, num_partials, C, count, gamma, beta, running_mean, running_var,
                      momentum, eps, use_batch_stats, update_running, scale, shift, mean, invstd);
   CY_CHECK_LAUNCH();
@@ -421,7 +422,7 @@ int cy_bn_bwd_finalize(const float* partials, int num_partials, int C, const flo
                        float* dgamma, float* dbeta, int accumulate, float* coef, void* stream) {
   if (!partials || !coef || num_partials <= 0 || C <= 0) return CY_ERR_ARG;
   if (batch_stats && (!scale || !mean || !invstd || count <= 0)) return CY_ERR_ARG;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cy_cdiv(C, 16)), dim3(256), 0,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cy_cdiv(C, 4)), dim3(256), 0,
                      (hipStream_t)stream, partials, num_partials, C, scale, mean, invstd, count,
                      batch_stats, dgamma, dbeta, accumulate, coef);
   CY_CHECK_LAUNCH();

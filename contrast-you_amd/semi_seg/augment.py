@@ -12,6 +12,7 @@ same `seed` gives the same geometry for images, logits and feature maps of any r
 from __future__ import annotations
 
 import math
+from contextlib import contextmanager
 from typing import Optional, Tuple
 
 import numpy as np
@@ -27,7 +28,18 @@ class AffineAugment:
                  mirror_p: float = 0.9, gamma: Optional[Tuple[float, float]] = (0.5, 2.0)) -> None:
         self.scale, self.rotation, self.translation = scale, rotation, translation
         self.mirror_p, self.gamma = mirror_p, gamma
+        self.enabled = True
         self._cache = {}
+
+    @contextmanager
+    def disabled(self):
+        """identity transform inside the block (the reference's `disable_rising_augmentation`,
+        semi_seg/epochers/pretrain.py:128-152, sets p=0 on every rising transform)"""
+        prev, self.enabled = self.enabled, False
+        try:
+            yield self
+        finally:
+            self.enabled = prev
 
     def sample(self, n: int, seed: int):
         """host-side parameters for a batch of n: theta [n,2,3] (output->input, normalised coords,
@@ -61,6 +73,8 @@ class AffineAugment:
 
     def __call__(self, image: Tensor, *, mode: str, seed: int) -> Tensor:
         assert mode in {"image", "feature"}, f"`mode` must be in `image` or `feature`, given {mode}."
+        if not self.enabled:
+            return image.float() if mode == "image" else image
         theta, gam = self.params(image.shape[0], seed, image.device)
         if mode == "image":
             return AffineFn.apply(image.float(), theta, gam)
