@@ -2,3 +2,4 @@ from .averagemeter import AverageValueDictionaryMeter, AverageValueListMeter, Av
 from .general_dice_meter import UniversalDice  # noqa: F401
 from .meter_interface import MeterInterface  # noqa: F401
 from .metric import Metric  # noqa: F401
+from .storage import Storage  # noqa: F401

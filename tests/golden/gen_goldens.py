@@ -6,8 +6,8 @@ Runs only in the build container (needs /root/reference, which never travels to 
     python tests/golden/gen_goldens.py
 
 It copies nothing from the reference into the repo: /root/reference is copied to a scratch dir
-under /tmp (its packages mkdir at import), three no-arithmetic import stubs (loguru, termcolor,
-segmentation_models_pytorch, medpy) are written next to it, the reference modules are imported
+under /tmp (its packages mkdir at import), no-arithmetic import stubs (loguru, termcolor,
+segmentation_models_pytorch, medpy, torch_optimizer) are written next to it, the reference modules are imported
 from there, fed seeded inputs/weights produced by oracle.* initialisers, and only numeric
 inputs/outputs are saved.
 """
@@ -38,6 +38,7 @@ STUBS = {
         "class Unet(nn.Module):\n"
         "    def __init__(self, *a, **k):\n"
         "        super().__init__()\n"),
+    "torch_optimizer/__init__.py": "",  # `from torch_optimizer import *` in contrastyou/optim/__init__.py:2
     "medpy/__init__.py": "",
     "medpy/metric/__init__.py": "def assd(*a, **k):\n    raise NotImplementedError\n",
     "medpy/metric/binary.py": "def __surface_distances(*a, **k):\n    raise NotImplementedError\n",
@@ -61,8 +62,116 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
+def gen_next_rows(scratch):
+    """section-8 "next" rows: dense InfoNCE head with grads, cluster heads, discrete-MI losses,
+    GroupNorm+SiLU block, bilinear resize and the warm-up/cosine lr law -> next_rows.npz"""
+    import types
+
+    from oracle import losses as ol
+    from oracle import next_rows as onr
+    from contrastyou.losses.kl import Entropy
+    from contrastyou.projectors.heads import ClusterHead, DenseClusterHead, DenseProjectionHead
+
+    # discreteMI.py:17 imports semi_seg.hooks.midl (-> tensorboard, absent); it only needs this
+    # module attribute (midl.py:13), so seed it before the import (SURVEY.md section 8c)
+    midl = types.ModuleType("semi_seg.hooks.midl")
+    midl.entropy_criterion = Entropy(reduction="none", eps=1e-8)
+    hooks_pkg = types.ModuleType("semi_seg.hooks")
+    hooks_pkg.midl = midl
+    hooks_pkg.__path__ = []
+    sys.modules.setdefault("semi_seg.hooks", hooks_pkg)
+    sys.modules.setdefault("semi_seg.hooks.midl", midl)
+    from contrastyou.losses.discreteMI import IIDLoss, IIDSegmentationLoss
+    from contrastyou.arch.unet2 import Block
+    from contrastyou.optim.scheduler import GradualWarmupScheduler
+
+    g = torch.Generator().manual_seed(21)
+    out = {}
+
+    # dense projection head (a7), fwd + all grads, non-divisible pooling (13 -> 4, overlapping bins)
+    dsd = ol.init_dense_projector_sd(16, 32, 32, seed=4)
+    dhead = DenseProjectionHead(input_dim=16, hidden_dim=32, output_dim=32, head_type="mlp", normalize=True,
+                                spatial_size=(4, 4))
+    dhead.load_state_dict(dsd, strict=True)
+    feat = torch.randn(3, 16, 13, 13, generator=g).requires_grad_(True)
+    z = dhead(feat)
+    (z * torch.linspace(-1, 1, z.numel()).view_as(z)).sum().backward()
+    out["dp_feat"], out["dp_z"], out["dp_dfeat"] = npy(feat), npy(z), npy(feat.grad)
+    for n, p in dhead.named_parameters():
+        out[f"dp_grad_{n}"] = npy(p.grad)
+
+    # cluster heads (a17)
+    for dense, cls, tag in ((False, ClusterHead, "ch"), (True, DenseClusterHead, "dch")):
+        sds = onr.init_cluster_sds(16, 6, 3, dense, seed=9)
+        head = cls(input_dim=16, num_clusters=6, num_subheads=3, head_type="linear", T=1, normalize=False)
+        head.load_state_dict({f"_headers.{i}.{k}": v for i, sd in enumerate(sds) for k, v in sd.items()},
+                             strict=True)
+        x = torch.randn(4, 16, 8, 8, generator=g)
+        out[f"{tag}_feat"] = npy(x)
+        for i, pr in enumerate(head(x)):
+            out[f"{tag}_prob{i}"] = npy(pr)
+
+    # IIDLoss on [n,k] simplex pairs
+    a = torch.randn(12, 6, generator=g).softmax(1).requires_grad_(True)
+    b = torch.randn(12, 6, generator=g).softmax(1).requires_grad_(True)
+    l, l0, pij = IIDLoss(lamb=1.5)(a, b)
+    l.backward()
+    out["iid_a"], out["iid_b"] = npy(a), npy(b)
+    out["iid_loss"], out["iid_loss_nolamb"], out["iid_joint"] = npy(l), npy(l0), npy(pij)
+    out["iid_da"], out["iid_db"] = npy(a.grad), npy(b.grad)
+
+    # IIDSegmentationLoss, padding 0 / 1 / 2, symmetric and not
+    xa = torch.randn(2, 5, 9, 11, generator=g).softmax(1)
+    xb = torch.randn(2, 5, 9, 11, generator=g).softmax(1)
+    out["seg_a"], out["seg_b"] = npy(xa), npy(xb)
+    for pad in (0, 1, 2):
+        for sym in (False, True):
+            pa, pb = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+            crit = IIDSegmentationLoss(lamda=1.2, padding=pad, symmetric=sym)
+            l = crit(pa, pb)
+            l.backward()
+            t = f"seg_p{pad}_s{int(sym)}"
+            out[f"{t}_loss"], out[f"{t}_da"], out[f"{t}_db"] = npy(l), npy(pa.grad), npy(pb.grad)
+
+    # GroupNorm + SiLU block (a18)
+    bsd = onr.init_gn_block(16, 32, seed=13)
+    blk = Block(16, 32, groups=8)
+    blk.load_state_dict(bsd, strict=True)
+    x = torch.randn(2, 16, 12, 12, generator=g).requires_grad_(True)
+    y = blk(x)
+    (y * torch.linspace(-1, 1, y.numel()).view_as(y)).sum().backward()
+    out["gn_x"], out["gn_y"], out["gn_dx"] = npy(x), npy(y), npy(x.grad)
+    for n, p in blk.named_parameters():
+        out[f"gn_grad_{n}"] = npy(p.grad)
+
+    # bilinear resize (a19): the call of semi_seg/hooks/cc.py:132
+    img = torch.rand(2, 1, 24, 24, generator=g)
+    out["bl_img"] = npy(img)
+    for hw in ((7, 7), (12, 10), (48, 40)):
+        out[f"bl_{hw[0]}x{hw[1]}"] = npy(torch.nn.functional.interpolate(img, size=hw, mode="bilinear"))
+
+    # lr law: config/base.yaml:10-17 (lr 1e-6... multiplier 300, warmup 10) over 40 epochs
+    par = [torch.nn.Parameter(torch.zeros(1))]
+    opt = torch.optim.SGD(par, lr=1e-6)
+    cos = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=40 - 10, eta_min=1e-7)
+    sch = GradualWarmupScheduler(opt, 300, total_epoch=10, after_scheduler=cos)
+    lrs = []
+    for _ in range(40):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    out["lr_seq"] = np.array(lrs, dtype=np.float64)
+    np.savez_compressed(OUT / "next_rows.npz", **out)
+
+
 def main():
     sys.path.insert(0, str(REPO))
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "next":
+        scratch = setup_reference()
+        gen_next_rows(scratch)
+        shutil.rmtree(scratch, ignore_errors=True)
+        print("wrote next_rows.npz")
+        return
     from oracle import losses as ol
     from oracle import unet as ou
     scratch = setup_reference()
@@ -167,6 +276,7 @@ def main():
     out["dice_vals"] = np.array([summ[k] for k in sorted(summ.keys())], dtype=np.float64)
     np.savez_compressed(OUT / "heads_losses.npz", **out)
 
+    gen_next_rows(scratch)
     shutil.rmtree(scratch, ignore_errors=True)
     print("wrote", sorted(p.name for p in OUT.glob("*.npz")))
 

@@ -208,3 +208,77 @@ def test_epocher_protocol_order_and_guards(monkeypatch):
     assert not torch.equal(w0, net.c.weight)
     m = ep.get_metric()
     assert set(m["semi"]) == {"lr", "sup_loss", "sup_dice", "reg_loss"} and "h" not in m or m.get("h") == {}
+
+
+def test_warmup_scheduler_matches_reference_sequence(golden_dir):
+    """GradualWarmupScheduler (product) against the lr sequence the reference class produced"""
+    import numpy as np
+    from contrastyou.optim import GradualWarmupScheduler
+    g = np.load(golden_dir / "next_rows.npz")
+    par = [torch.nn.Parameter(torch.zeros(1))]
+    opt = torch.optim.SGD(par, lr=1e-6)
+    cos = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=30, eta_min=1e-7)
+    sch = GradualWarmupScheduler(opt, 300, total_epoch=10, after_scheduler=cos)
+    lrs = []
+    for e in range(40):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+        if e == 20:  # checkpoint round trip in the middle of the cosine phase
+            state, opt_state = sch.state_dict(), opt.state_dict()
+            opt = torch.optim.SGD(par, lr=1e-6)
+            cos = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=30, eta_min=1e-7)
+            sch = GradualWarmupScheduler(opt, 300, total_epoch=10, after_scheduler=cos)
+            opt.load_state_dict(opt_state)  # the order Trainer.load_state_dict uses
+            sch.load_state_dict(state)
+    assert np.allclose(lrs, g["lr_seq"], rtol=1e-12, atol=0)
+    with pytest.raises(ValueError):
+        GradualWarmupScheduler(opt, 1.0, total_epoch=10)
+
+
+def test_trainer_checkpoint_schema_and_resume(tmp_path):
+    """Trainer: optimizer from config (+ hook param group), reference checkpoint schema, safe
+    (weights_only) resume of epoch counters, scheduler, optimizer lr and storage"""
+    from contrastyou.arch import UNet
+    from contrastyou.losses.kl import KL_div
+    from semi_seg.trainers import trainer_zoo
+    cfg = {"Optim": {"name": "RAdam", "lr": 1e-6, "weight_decay": 1e-5},
+           "Scheduler": {"multiplier": 300, "warmup_max": 10}, "Trainer": {"name": "semi"}}
+
+    def make():
+        tr = trainer_zoo["semi"](model=UNet(input_dim=1, num_classes=4, max_channel=128), labeled_loader=[],
+                                 unlabeled_loader=[], val_loader=[], test_loader=[], criterion=KL_div(),
+                                 save_dir=str(tmp_path), max_epoch=30, num_batches=2, device="cpu", disable_bn=False,
+                                 two_stage=True, config=cfg, enable_scale=True)
+        tr.init()
+        return tr
+
+    tr = make()
+    with pytest.raises(RuntimeError):
+        tr.init()
+    with pytest.raises(RuntimeError):
+        with tr.register_hook():
+            pass
+    sd = tr.state_dict()
+    assert list(sd) == ["module_state", "buffer_state", "other_state"]
+    assert set(sd["buffer_state"]) == {"_save_dir", "_max_epoch", "_num_batches", "config", "_cur_epoch",
+                                       "_start_epoch", "_best_score"}
+    assert {"_optimizer", "_scheduler", "scaler", "_storage"} <= set(sd["other_state"])
+    assert "_model._Conv1.conv.0.weight" in sd["module_state"]
+    tr._cur_epoch, tr._best_score = 7, 0.5
+    for _ in range(7):
+        tr._optimizer.step() if False else None
+        tr._scheduler.step()
+    tr._storage.put("tra/semi/sup_loss", {"mean": 1.0}, epoch=7)
+    with torch.no_grad():
+        tr._model._Deconv_1x1.bias.fill_(0.25)
+    tr.save_to(save_name="last.pth")
+    tr2 = make()
+    tr2.resume_from_path(str(tmp_path))
+    assert tr2._cur_epoch == 7 and tr2._best_score == 0.5 and tr2._scheduler.last_epoch == 7
+    assert abs(tr2._optimizer.param_groups[0]["lr"] - tr._optimizer.param_groups[0]["lr"]) < 1e-15
+    assert tr2._storage.get("tra/semi/sup_loss", 7) == {"mean": 1.0}
+    assert float(tr2._model._Deconv_1x1.bias[0]) == 0.25
+    assert (tmp_path / "config.yaml").exists() and (tmp_path / "config_1.yaml").exists()
+    with pytest.raises(NotImplementedError):
+        trainer_zoo["mixup"]()
