@@ -1,2 +1,3 @@
 from .contrastive import SupConLoss1, is_normalized  # noqa: F401
+from .discreteMI import IIDLoss, IIDSegmentationLoss  # noqa: F401
 from .kl import KL_div, Entropy  # noqa: F401

@@ -1,2 +1,2 @@
-from .heads import ProjectionHead  # noqa: F401
+from .heads import ClusterHead, DenseClusterHead, DenseProjectionHead, ProjectionHead  # noqa: F401
 from .nn import Normalize  # noqa: F401

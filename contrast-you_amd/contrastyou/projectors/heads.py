@@ -9,11 +9,22 @@ from __future__ import annotations
 
 from torch import Tensor, nn
 
-from cyhip.functions import AvgPoolFn, L2NormFn, LinearFn
+from typing import List, Optional, Sequence, Tuple
 
-from .nn import Flatten, Identical, Normalize
+import numpy as np
+import torch
 
-__all__ = ["ProjectionHead"]
+from cyhip import ops
+from cyhip.functions import (AdaptiveAvgPoolFn, AvgPoolFn, DenseProjHiddenFn, GroupSoftmaxFn, HeadFn, L2NormFn,
+                             LinearFn)
+
+from .nn import Flatten, Identical, Normalize, SoftmaxWithT
+
+__all__ = ["ProjectionHead", "DenseProjectionHead", "ClusterHead", "DenseClusterHead"]
+
+
+def _pair(v) -> Tuple[int, int]:
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
 
 
 class ProjectionHead(nn.Module):
@@ -45,3 +56,136 @@ class ProjectionHead(nn.Module):
         else:
             x = LinearFn.apply(x, h[2].weight, h[2].bias, 0, 0.0)
         return L2NormFn.apply(x) if self._normalize else x
+
+
+class DenseProjectionHead(nn.Module):
+    """Pixel-wise projection head of the dense InfoNCE hook (contrastyou/projectors/heads.py:31-41,
+    99-123): Conv1x1(C,hidden) -> LeakyReLU(0.01) -> Conv1x1(hidden,out) -> AdaptiveAvgPool2d(s) ->
+    L2 normalise over channels.  `_projector` keeps the reference's Sequential layout (parameter
+    names `_projector.0.weight`, `_projector.2.bias`, ...).
+
+    Execution: the second 1x1 conv and the average pool are linear and commute, so the HIP path
+    pools LeakyReLU(Conv1x1(x)) per output bin straight from the NHWC feature map (the
+    [pixels, hidden] intermediate never exists) and applies the second conv to the pooled rows.
+    `forward(features)` returns the full [N, out, s, s] map as the reference does;
+    `project_points(features, points)` evaluates only the listed (image, row, col) bins -- what the
+    dense hook needs after `region_extractor` -- and returns [len(points), out] rows."""
+
+    def __init__(self, *, input_dim: int, hidden_dim=128, output_dim: int, head_type: str, normalize: bool,
+                 pool_name="adaptive_avg", spatial_size=(16, 16)):
+        super().__init__()
+        assert head_type in ("mlp", "linear"), head_type
+        assert pool_name in ("adaptive_avg", "adaptive_max", "identical", "none"), pool_name
+        if pool_name != "adaptive_avg":
+            raise NotImplementedError("the HIP dense projector implements adaptive_avg pooling (the hook's setting)")
+        self._input_dim, self._output_dim = input_dim, output_dim
+        self._head_type, self._normalize = head_type, normalize
+        self._pool_name, self._spatial_size = pool_name, _pair(spatial_size)
+        self._pooling_module = nn.AdaptiveAvgPool2d(self._spatial_size)
+        if head_type == "mlp":
+            self._projector = nn.Sequential(nn.Conv2d(input_dim, hidden_dim, 1, 1, 0),
+                                            nn.LeakyReLU(0.01, inplace=True),
+                                            nn.Conv2d(hidden_dim, output_dim, 1, 1, 0))
+        else:
+            self._projector = nn.Sequential(nn.Conv2d(input_dim, output_dim, 1, 1, 0))
+
+    def _rows(self, features: Tensor, bins: Optional[Tensor]) -> Tensor:
+        pr = self._projector
+        if self._head_type == "mlp":
+            hp = DenseProjHiddenFn.apply(features, pr[0].weight, pr[0].bias, self._spatial_size, bins)
+            w2 = pr[2].weight.reshape(pr[2].weight.shape[0], -1)
+            rows = LinearFn.apply(hp, w2, pr[2].bias, 0, 0.0)
+        else:
+            if bins is not None:
+                raise NotImplementedError("point evaluation is implemented for the mlp head")
+            pooled = AdaptiveAvgPoolFn.apply(features, self._spatial_size)
+            rows = LinearFn.apply(pooled, pr[0].weight.reshape(pr[0].weight.shape[0], -1), pr[0].bias, 0, 0.0)
+        return L2NormFn.apply(rows) if self._normalize else rows
+
+    def forward(self, features: Tensor) -> Tensor:
+        ops.require_gpu(features)
+        n = features.shape[0]
+        sh, sw = self._spatial_size
+        rows = self._rows(features, None)  # [n*sh*sw, out] == NHWC
+        return rows.view(n, sh, sw, -1).permute(0, 3, 1, 2)
+
+    def project_points(self, features: Tensor, points: Sequence[Sequence[Tuple[int, int]]]) -> Tensor:
+        """points[i] = [(row, col), ...] on the s x s output grid of image i (distinct per image)
+        -> [sum_i len(points[i]), out], image-major: == region_extractor(self(features))"""
+        ops.require_gpu(features)
+        bins = np.asarray([(i, a, b) for i, pts in enumerate(points) for a, b in pts], dtype=np.int32)
+        assert len(np.unique(bins, axis=0)) == len(bins), "sampled bins must be distinct"
+        return self._rows(features, ops._bins_tensor(bins, features.device))
+
+
+def _sub_header(dense: bool, head_type: str, input_dim: int, hidden_dim: int, num_clusters: int, normalize: bool,
+                T: float) -> nn.Sequential:
+    tail = [Normalize() if normalize else Identical(), SoftmaxWithT(1, T=T)]
+    if dense:
+        if head_type == "linear":
+            return nn.Sequential(nn.Conv2d(input_dim, num_clusters, 1, 1, 0), *tail)
+        return nn.Sequential(nn.Conv2d(input_dim, hidden_dim, 1, 1, 0), nn.LeakyReLU(0.01, inplace=True),
+                             nn.Conv2d(hidden_dim, num_clusters, 1, 1, 0), *tail)
+    if head_type == "linear":
+        return nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), Flatten(), nn.Linear(input_dim, num_clusters), *tail)
+    return nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), Flatten(), nn.Linear(input_dim, 128),
+                         nn.LeakyReLU(0.01, inplace=True), nn.Linear(128, num_clusters), *tail)
+
+
+class _ClusterBase(nn.Module):
+    _dense = False
+
+    def __init__(self, *, input_dim: int, num_clusters: int, num_subheads: int, head_type: str, T: float,
+                 normalize: bool, hidden_dim: int = 64):
+        super().__init__()
+        assert head_type in ("mlp", "linear"), head_type
+        if head_type != "linear" or normalize:
+            raise NotImplementedError("the HIP cluster heads implement head_type='linear', normalize=False "
+                                      "(what DiscreteMITrainHook creates, semi_seg/hooks/discretemi.py:43-46)")
+        self._input_dim, self._output_dim = input_dim, num_clusters
+        self._head_type, self._normalize = head_type, normalize
+        self._num_clusters, self._num_subheads, self._T = num_clusters, num_subheads, T
+        self._headers = nn.ModuleList([_sub_header(self._dense, head_type, input_dim, hidden_dim, num_clusters,
+                                                   normalize, T) for _ in range(num_subheads)])
+
+    def _stacked(self, idx: int):
+        """all sub-heads as ONE [S*k, C] weight so the 1x1 conv / linear runs once"""
+        w = torch.cat([h[idx].weight.reshape(self._num_clusters, -1) for h in self._headers], dim=0)
+        b = torch.cat([h[idx].bias for h in self._headers], dim=0)
+        return w, b
+
+
+class ClusterHead(_ClusterBase):
+    """IIC clustering head on encoder features (contrastyou/projectors/heads.py:44-62,125-148):
+    per sub-head AdaptiveAvgPool2d(1) -> Linear(C,k) -> softmax(./T); returns a list of [n,k]."""
+
+    def __init__(self, *, input_dim: int, num_clusters=5, num_subheads=10, head_type="linear", T=1, normalize=False):
+        super().__init__(input_dim=input_dim, num_clusters=num_clusters, num_subheads=num_subheads,
+                         head_type=head_type, T=T, normalize=normalize)
+
+    def forward(self, features: Tensor) -> List[Tensor]:
+        ops.require_gpu(features)
+        w, b = self._stacked(2)
+        logits = LinearFn.apply(AvgPoolFn.apply(features), w, b, 0, 0.0)
+        probs = GroupSoftmaxFn.apply(logits, self._num_subheads, self._num_clusters, float(self._T))
+        return list(probs.unbind(0))
+
+
+class DenseClusterHead(_ClusterBase):
+    """IIC segmentation clustering head on decoder features (projectors/heads.py:65-78,151-173):
+    per sub-head Conv1x1(C,k) -> softmax over channels; returns a list of [n,k,H,W] (NHWC memory)."""
+    _dense = True
+
+    def __init__(self, *, input_dim: int, num_clusters=10, hidden_dim=64, num_subheads=10, T=1,
+                 head_type: str = "linear", normalize: bool = False):
+        super().__init__(input_dim=input_dim, num_clusters=num_clusters, num_subheads=num_subheads,
+                         head_type=head_type, T=T, normalize=normalize, hidden_dim=hidden_dim)
+
+    def forward(self, features: Tensor) -> List[Tensor]:
+        ops.require_gpu(features)
+        n, _, h, w_ = features.shape
+        w, b = self._stacked(0)
+        logits = HeadFn.apply(features, w.view(w.shape[0], w.shape[1], 1, 1), b)  # [n, S*k, h, w] NHWC f32
+        flat = logits.permute(0, 2, 3, 1).reshape(n * h * w_, -1)
+        probs = GroupSoftmaxFn.apply(flat, self._num_subheads, self._num_clusters, float(self._T))
+        return [p.view(n, h, w_, self._num_clusters).permute(0, 3, 1, 2) for p in probs.unbind(0)]

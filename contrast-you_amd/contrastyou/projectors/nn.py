@@ -22,3 +22,14 @@ class Normalize(nn.Module):
 class Identical(nn.Module):
     def forward(self, input):  # noqa: A002
         return input
+
+
+class SoftmaxWithT(nn.Softmax):
+    """softmax(x / T) (contrastyou/projectors/nn.py:35-44)"""
+
+    def __init__(self, dim, T: float = 1.0) -> None:
+        super().__init__(dim)
+        self._T = T
+
+    def forward(self, input):  # noqa: A002
+        return super().forward(input / self._T)

@@ -661,7 +661,7 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------
 extern "C" {
 
-int cy_abi_version(void) { return 3; }
+int cy_abi_version(void) { return 4; }
 const char* cy_build_arch(void) { return "gfx950"; }
 
 int cy_conv3x3_packed_dims(int Cout, int Cin, int* co_pad, int* ci_pad) {

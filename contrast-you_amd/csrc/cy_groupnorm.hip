@@ -1,0 +1,404 @@
+// GroupNorm + SiLU after a biased 3x3 convolution, and bilinear image resize.
+//   UNet2.Block: Conv2d(3x3, bias) -> GroupNorm(8, C) -> SiLU      contrastyou/arch/unet2.py:208-224
+//   F.interpolate(image, size, mode="bilinear")                    semi_seg/hooks/cc.py:132,
+//                                                                  semi_seg/hooks/ccblock.py:300
+//
+// The convolution itself runs on the implicit-GEMM kernels of cy_conv3x3.hip WITHOUT the bias;
+// the bias is folded into the normalisation here: u = y + b_c, x^ = (u - mean_g) * rstd_g,
+// v = gamma_c x^ + beta_c, z = v * sigmoid(v).  All kernels stream NHWC tensors once
+// (HBM-bound); statistics are two-stage, fixed-order reductions.
+#include "cy_common.h"
+
+namespace {
+
+constexpr int GN_SPLIT = 32;  // pixel splits per image in the reduction kernels
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* f) {
+  if constexpr (sizeof(T) == 2) {
+    Chunk<bf16>::unpack(ld16(p), f);
+  } else {
+    Chunk<float>::unpack(ld16(p), f);
+    Chunk<float>::unpack(ld16(p + 4), f + 4);
+  }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* f) {
+  if constexpr (sizeof(T) == 2) {
+    st16(p, Chunk<bf16>::pack(f));
+  } else {
+    st16(p, Chunk<float>::pack(f));
+    st16(p + 4, Chunk<float>::pack(f + 4));
+  }
+}
+
+inline int grid_for(long n) {
+  long b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+// Generic per-(image, split) channel reduction of NV values per element.
+// grid (GN_SPLIT, N); thread layout: gpp 8-channel groups x rows pixel lanes.
+// F(f_y[8], f_d[8], c0, acc[NV][8]) accumulates.
+template <typename T, int NV, typename F>
+__device__ __forceinline__ void channel_reduce(const T* __restrict__ y, int ldy,
+                                               const T* __restrict__ d, int ldd, int HW, int C,
+                                               float* __restrict__ part, F f) {
+  extern __shared__ float sred[];  // [rows][gpp][NV*8]
+  const int G8 = C / 8;
+  const int gpp = G8 < 256 ? G8 : 256;
+  const int rows = 256 / gpp;
+  const int tid = threadIdx.x;
+  const int g = tid % gpp, prow = tid / gpp;
+  const bool active = prow < rows;
+  const int n = blockIdx.y;
+  const int per = (HW + GN_SPLIT - 1) / GN_SPLIT;
+  const int q0 = blockIdx.x * per, q1 = min(HW, q0 + per);
+  float* dst = part + ((size_t)n * GN_SPLIT + blockIdx.x) * NV * C;
+  const int gg = g;  // C <= 2048 (checked by the host) => every 8-channel group has its own thread
+  float acc[NV][8];
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[v][j] = 0.f;
+  if (active) {
+    for (int q = q0 + prow; q < q1; q += rows) {
+      const long pix = (long)n * HW + q;
+      float fy[8], fd[8];
+      load8<T>(y + pix * ldy + gg * 8, fy);
+      if (d) load8<T>(d + pix * ldd + gg * 8, fd);
+      f(fy, fd, n, gg * 8, acc);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sred[((prow * gpp + g) * NV + v) * 8 + j] = acc[v][j];
+  }
+  __syncthreads();
+  for (int e = tid; e < NV * 8 * gpp; e += 256) {
+    const int gl = e / (NV * 8), r = e - gl * NV * 8, v = r / 8, j = r - v * 8;
+    float s = 0.f;
+    for (int q = 0; q < rows; ++q) s += sred[((q * gpp + gl) * NV + v) * 8 + j];
+    dst[v * C + gl * 8 + j] = s;
+  }
+}
+
+// ---------------------------------------------------------------- forward statistics
+template <typename T>
+__global__ void __launch_bounds__(256)
+    gn_stats_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ bias, int HW, int C,
+                    float* __restrict__ part) {
+  channel_reduce<T, 2>(y, ldy, (const T*)nullptr, 0, HW, C, part,
+                       [&](const float* fy, const float*, int, int c0, float(*acc)[8]) {
+#pragma unroll
+                         for (int j = 0; j < 8; ++j) {
+                           const float u = fy[j] + (bias ? bias[c0 + j] : 0.f);
+                           acc[0][j] += u;
+                           acc[1][j] = fmaf(u, u, acc[1][j]);
+                         }
+                       });
+}
+
+// one thread per (n, group): mean / rstd
+__global__ void __launch_bounds__(256)
+    gn_stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean_rstd, int N,
+                             int C, int G, int HW, float eps) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * G) return;
+  const int n = e / G, g = e - n * G, cg = C / G;
+  double s1 = 0.0, s2 = 0.0;
+  for (int sp = 0; sp < GN_SPLIT; ++sp) {
+    const float* p = part + ((size_t)n * GN_SPLIT + sp) * 2 * C;
+    for (int c = g * cg; c < (g + 1) * cg; ++c) {
+      s1 += (double)p[c];
+      s2 += (double)p[C + c];
+    }
+  }
+  const double m = (double)cg * HW;
+  const double mean = s1 / m;
+  double var = s2 / m - mean * mean;
+  if (var < 0.0) var = 0.0;
+  mean_rstd[2 * e] = (float)mean;
+  mean_rstd[2 * e + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+    gn_silu_apply_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ bias,
+                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                         const float* __restrict__ mean_rstd, T* __restrict__ out, int ldo, int N,
+                         int HW, int C, int G) {
+  const int G8 = C / 8, cg = C / G;
+  const long total = (long)N * HW * G8;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int g8 = (int)(i % G8);
+    const long pix = i / G8;
+    const int n = (int)(pix / HW);
+    float f[8];
+    load8<T>(y + pix * ldy + g8 * 8, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = g8 * 8 + j;
+      const float* mr = mean_rstd + 2 * ((size_t)n * G + c / cg);
+      const float xh = (f[j] + (bias ? bias[c] : 0.f) - mr[0]) * mr[1];
+      const float v = fmaf(gamma[c], xh, beta[c]);
+      f[j] = v * sigmoidf_(v);
+    }
+    store8<T>(out + pix * ldo + g8 * 8, f);
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// per (n, split, channel): A = sum dv, B = sum dv*x^, X = sum x^
+template <typename T>
+__global__ void __launch_bounds__(256)
+    gn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dz, int ldd,
+                         const float* __restrict__ bias, const float* __restrict__ gamma,
+                         const float* __restrict__ beta, const float* __restrict__ mean_rstd,
+                         int HW, int C, int G, float* __restrict__ part) {
+  const int cg = C / G;
+  channel_reduce<T, 3>(y, ldy, dz, ldd, HW, C, part,
+                       [&](const float* fy, const float* fd, int n, int c0, float(*acc)[8]) {
+#pragma unroll
+                         for (int j = 0; j < 8; ++j) {
+                           const int c = c0 + j;
+                           const float* mr = mean_rstd + 2 * ((size_t)n * G + c / cg);
+                           const float xh = (fy[j] + (bias ? bias[c] : 0.f) - mr[0]) * mr[1];
+                           const float v = fmaf(gamma[c], xh, beta[c]);
+                           const float sg = sigmoidf_(v);
+                           const float dv = fd[j] * (sg + v * sg * (1.f - sg));
+                           acc[0][j] += dv;
+                           acc[1][j] = fmaf(dv, xh, acc[1][j]);
+                           acc[2][j] += xh;
+                         }
+                       });
+}
+
+// one block per (n, g): coefficients  du = k1*dv + k0 + k2*x^  and per-image parameter grads
+__global__ void __launch_bounds__(64)
+    gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                           const float* __restrict__ mean_rstd, float* __restrict__ coef,
+                           float* __restrict__ pgrad, int N, int C, int G, int HW) {
+  __shared__ double sA[64], sB[64];
+  __shared__ double sa[2048 / 8], sb[2048 / 8], sx[2048 / 8];  // per-channel sums (cg <= 256)
+  const int n = blockIdx.x / G, g = blockIdx.x - n * G, cg = C / G;
+  const int tid = threadIdx.x;
+  double tA = 0.0, tB = 0.0;
+  for (int cl = tid; cl < cg; cl += 64) {
+    const int c = g * cg + cl;
+    double a = 0.0, b = 0.0, x = 0.0;
+    for (int sp = 0; sp < GN_SPLIT; ++sp) {
+      const float* p = part + ((size_t)n * GN_SPLIT + sp) * 3 * C;
+      a += (double)p[c];
+      b += (double)p[C + c];
+      x += (double)p[2 * C + c];
+    }
+    sa[cl] = a, sb[cl] = b, sx[cl] = x;
+    tA += (double)gamma[c] * a;
+    tB += (double)gamma[c] * b;
+  }
+  sA[tid] = tA, sB[tid] = tB;
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) {
+    if (tid < o) sA[tid] += sA[tid + o], sB[tid] += sB[tid + o];
+    __syncthreads();
+  }
+  const double m = (double)cg * HW;
+  const double m1 = sA[0] / m, m2 = sB[0] / m;
+  const double rstd = mean_rstd[2 * (n * G + g) + 1];
+  for (int cl = tid; cl < cg; cl += 64) {
+    const int c = g * cg + cl;
+    float* k = coef + ((size_t)n * C + c) * 3;
+    k[0] = (float)(-rstd * m1);
+    k[1] = (float)(rstd * (double)gamma[c]);
+    k[2] = (float)(-rstd * m2);
+    float* pg = pgrad + ((size_t)n * C + c) * 3;
+    pg[0] = (float)sb[cl];                                                       // dgamma_n
+    pg[1] = (float)sa[cl];                                                       // dbeta_n
+    pg[2] = (float)(rstd * ((double)gamma[c] * sa[cl] - HW * m1 - m2 * sx[cl]));  // dbias_n
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    gn_param_grad_kernel(const float* __restrict__ pgrad, float* __restrict__ dgamma,
+                         float* __restrict__ dbeta, float* __restrict__ dbias, int N, int C,
+                         int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int n = 0; n < N; ++n)
+    for (int v = 0; v < 3; ++v) s[v] += (double)pgrad[((size_t)n * C + c) * 3 + v];
+  float* dst[3] = {dgamma, dbeta, dbias};
+  for (int v = 0; v < 3; ++v)
+    if (dst[v]) dst[v][c] = accumulate ? dst[v][c] + (float)s[v] : (float)s[v];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+    gn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dz, int ldd,
+                        const float* __restrict__ bias, const float* __restrict__ gamma,
+                        const float* __restrict__ beta, const float* __restrict__ mean_rstd,
+                        const float* __restrict__ coef, T* __restrict__ du, int ldu, int N, int HW,
+                        int C, int G) {
+  const int G8 = C / 8, cg = C / G;
+  const long total = (long)N * HW * G8;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int g8 = (int)(i % G8);
+    const long pix = i / G8;
+    const int n = (int)(pix / HW);
+    float fy[8], fd[8];
+    load8<T>(y + pix * ldy + g8 * 8, fy);
+    load8<T>(dz + pix * ldd + g8 * 8, fd);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = g8 * 8 + j;
+      const float* mr = mean_rstd + 2 * ((size_t)n * G + c / cg);
+      const float xh = (fy[j] + (bias ? bias[c] : 0.f) - mr[0]) * mr[1];
+      const float v = fmaf(gamma[c], xh, beta[c]);
+      const float sg = sigmoidf_(v);
+      const float dv = fd[j] * (sg + v * sg * (1.f - sg));
+      const float* k = coef + ((size_t)n * C + c) * 3;
+      fy[j] = fmaf(k[1], dv, fmaf(k[2], xh, k[0]));
+    }
+    store8<T>(du + pix * ldu + g8 * 8, fy);
+  }
+}
+
+// ---------------------------------------------------------------- bilinear resize (align_corners=False)
+template <typename T>
+__global__ void __launch_bounds__(256)
+    bilinear_kernel(const T* __restrict__ x, T* __restrict__ out, int N, int H, int W, int C, int h,
+                    int w) {
+  const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+  const long total = (long)N * h * w * C;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const int c = (int)(e % C);
+    long t = e / C;
+    const int ox = (int)(t % w);
+    t /= w;
+    const int oy = (int)(t % h), n = (int)(t / h);
+    float fy = fmaxf(((float)oy + 0.5f) * sy - 0.5f, 0.f);
+    float fx = fmaxf(((float)ox + 0.5f) * sx - 0.5f, 0.f);
+    const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const T* b = x + (long)n * H * W * C + c;
+    const float v00 = to_f32<T>(b[((long)y0 * W + x0) * C]), v01 = to_f32<T>(b[((long)y0 * W + x1) * C]);
+    const float v10 = to_f32<T>(b[((long)y1 * W + x0) * C]), v11 = to_f32<T>(b[((long)y1 * W + x1) * C]);
+    const float top = v00 * (1.f - lx) + v01 * lx, bot = v10 * (1.f - lx) + v11 * lx;
+    out[e] = from_f32<T>(top * (1.f - ly) + bot * ly);
+  }
+}
+
+inline size_t reduce_smem(int C, int NV) {
+  const int G8 = C / 8, gpp = G8 < 256 ? G8 : 256, rows = 256 / gpp;
+  return (size_t)rows * gpp * NV * 8 * sizeof(float);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cy_gn_ws_bytes(int N, int C) {
+  /* reduction partials [N][SPLIT][3][C] + coef [N][C][3] + pgrad [N][C][3] */
+  return ((size_t)N * GN_SPLIT * 3 * C + 6 * (size_t)N * C) * sizeof(float);
+}
+
+int cy_gn_silu_fwd(const void* y, int ldy, const float* bias, const float* gamma, const float* beta,
+                   void* out, int ldo, float* mean_rstd, int N, int HW, int C, int G, float eps,
+                   int dtype, void* ws, size_t ws_bytes, void* stream) {
+  if (!y || !gamma || !beta || !out || !mean_rstd || N <= 0 || HW <= 0) return CY_ERR_ARG;
+  if (C % 8 || G <= 0 || C % G || ldy % 8 || ldo % 8 || ldy < C || ldo < C || C / G > 256 || C > 2048)
+    return CY_ERR_SHAPE;
+  if (dtype != CY_BF16 && dtype != CY_F32) return CY_ERR_DTYPE;
+  if (!ws || ws_bytes < cy_gn_ws_bytes(N, C)) return CY_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)ws;
+  const size_t smem = reduce_smem(C, 2);
+  const int grid = grid_for((long)N * HW * (C / 8));
+  if (dtype == CY_BF16) {
+    hipLaunchKernelGGL(gn_stats_kernel<bf16>, dim3(GN_SPLIT, N), dim3(256), smem, st, (const bf16*)y,
+                       ldy, bias, HW, C, part);
+    CY_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(cy_cdiv((long)N * G, 256)), dim3(256), 0, st,
+                       (const float*)part, mean_rstd, N, C, G, HW, eps);
+    CY_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_silu_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, ldy,
+                       bias, gamma, beta, (const float*)mean_rstd, (bf16*)out, ldo, N, HW, C, G);
+  } else {
+    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(GN_SPLIT, N), dim3(256), smem, st,
+                       (const float*)y, ldy, bias, HW, C, part);
+    CY_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(cy_cdiv((long)N * G, 256)), dim3(256), 0, st,
+                       (const float*)part, mean_rstd, N, C, G, HW, eps);
+    CY_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_silu_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y,
+                       ldy, bias, gamma, beta, (const float*)mean_rstd, (float*)out, ldo, N, HW, C, G);
+  }
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_gn_silu_bwd(const void* y, int ldy, const void* dz, int ldd, const float* bias,
+                   const float* gamma, const float* beta, const float* mean_rstd, void* du, int ldu,
+                   float* dgamma, float* dbeta, float* dbias, int accumulate, int N, int HW, int C,
+                   int G, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  if (!y || !dz || !gamma || !beta || !mean_rstd || !du || N <= 0 || HW <= 0) return CY_ERR_ARG;
+  if (C % 8 || G <= 0 || C % G || ldy % 8 || ldd % 8 || ldu % 8 || ldy < C || ldd < C || ldu < C ||
+      C / G > 256 || C > 2048)
+    return CY_ERR_SHAPE;
+  if (dtype != CY_BF16 && dtype != CY_F32) return CY_ERR_DTYPE;
+  if (!ws || ws_bytes < cy_gn_ws_bytes(N, C)) return CY_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)ws;
+  float* coef = part + (size_t)N * GN_SPLIT * 3 * C;
+  float* pgrad = coef + 3 * (size_t)N * C;
+  const size_t smem = reduce_smem(C, 3);
+  const int grid = grid_for((long)N * HW * (C / 8));
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16>, dim3(GN_SPLIT, N), dim3(256), smem, st,
+                       (const bf16*)y, ldy, (const bf16*)dz, ldd, bias, gamma, beta, mean_rstd, HW, C,
+                       G, part);
+  else
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(GN_SPLIT, N), dim3(256), smem, st,
+                       (const float*)y, ldy, (const float*)dz, ldd, bias, gamma, beta, mean_rstd, HW,
+                       C, G, part);
+  CY_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N * G), dim3(64), 0, st, (const float*)part, gamma,
+                     mean_rstd, coef, pgrad, N, C, G, HW);
+  CY_CHECK_LAUNCH();
+  if (dgamma || dbeta || dbias) {
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cy_cdiv(C, 256)), dim3(256), 0, st,
+                       (const float*)pgrad, dgamma, dbeta, dbias, N, C, accumulate);
+    CY_CHECK_LAUNCH();
+  }
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, ldy,
+                       (const bf16*)dz, ldd, bias, gamma, beta, mean_rstd, (const float*)coef,
+                       (bf16*)du, ldu, N, HW, C, G);
+  else
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y, ldy,
+                       (const float*)dz, ldd, bias, gamma, beta, mean_rstd, (const float*)coef,
+                       (float*)du, ldu, N, HW, C, G);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_bilinear_fwd(const void* x, void* out, int N, int H, int W, int C, int h, int w, int dtype,
+                    void* stream) {
+  if (!x || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || h <= 0 || w <= 0) return CY_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for((long)N * h * w * C);
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(bilinear_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x,
+                       (bf16*)out, N, H, W, C, h, w);
+  else if (dtype == CY_F32)
+    hipLaunchKernelGGL(bilinear_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x,
+                       (float*)out, N, H, W, C, h, w);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+}  // extern "C"

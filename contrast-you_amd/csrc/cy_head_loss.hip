@@ -10,7 +10,8 @@
 
 namespace {
 
-constexpr int KMAX = 16;
+constexpr int KMAX = 16;    // segmentation classes
+constexpr int KWIDE = 128;  // stacked cluster-head outputs
 
 template <typename T> __device__ __forceinline__ void load8h(const T* p, float* f) {
   if constexpr (sizeof(T) == 2) {
@@ -30,7 +31,7 @@ template <typename T> __device__ __forceinline__ void store8h(T* p, const float*
 }
 
 // ---------------------------------------------------------------- 1x1 head forward
-template <typename T>
+template <typename T, int KM>
 __global__ void __launch_bounds__(256)
     head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                     const float* __restrict__ b, float* __restrict__ logits, long npix, int C,
@@ -40,14 +41,14 @@ __global__ void __launch_bounds__(256)
   for (int i = threadIdx.x; i < K; i += 256) sw[K * C + i] = b ? b[i] : 0.f;
   __syncthreads();
   for (long p = blockIdx.x * 256L + threadIdx.x; p < npix; p += (long)gridDim.x * 256L) {
-    float acc[KMAX];
+    float acc[KM];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) acc[k] = k < K ? sw[K * C + k] : 0.f;
+    for (int k = 0; k < KM; ++k) acc[k] = k < K ? sw[K * C + k] : 0.f;
     for (int c0 = 0; c0 < C; c0 += 8) {
       float f[8];
       load8h<T>(x + p * C + c0, f);
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
+      for (int k = 0; k < KM; ++k) {
         if (k < K) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc[k] = fmaf(f[j], sw[k * C + c0 + j], acc[k]);
@@ -55,7 +56,7 @@ __global__ void __launch_bounds__(256)
       }
     }
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k)
+    for (int k = 0; k < KM; ++k)
       if (k < K) logits[p * K + k] = acc[k];
   }
 }
@@ -377,18 +378,27 @@ extern "C" {
 int cy_head1x1_fwd(const void* x, const float* w, const float* b, float* logits, long npix, int C,
                    int K, int x_dtype, void* stream) {
   if (!x || !w || !logits || npix <= 0) return CY_ERR_ARG;
-  if (C % 8 || K < 1 || K > KMAX || (size_t)(K * C + K) * 4 > 60000) return CY_ERR_SHAPE;
+  if (C % 8 || K < 1 || K > KWIDE || (size_t)(K * C + K) * 4 > 60000) return CY_ERR_SHAPE;
+  if (x_dtype != CY_BF16 && x_dtype != CY_F32) return CY_ERR_DTYPE;
   hipStream_t st = (hipStream_t)stream;
   const int grid = loss_blocks(npix) * 2;
   const size_t smem = (size_t)(K * C + K) * sizeof(float);
-  if (x_dtype == CY_BF16)
-    hipLaunchKernelGGL(head_fwd_kernel<bf16>, dim3(grid), dim3(256), smem, st, (const bf16*)x, w, b,
-                       logits, npix, C, K);
-  else if (x_dtype == CY_F32)
-    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(grid), dim3(256), smem, st, (const float*)x, w,
-                       b, logits, npix, C, K);
-  else
-    return CY_ERR_DTYPE;
+  const bool h = x_dtype == CY_BF16;
+  if (K <= KMAX) {  // segmentation classes
+    if (h)
+      hipLaunchKernelGGL((head_fwd_kernel<bf16, KMAX>), dim3(grid), dim3(256), smem, st,
+                         (const bf16*)x, w, b, logits, npix, C, K);
+    else
+      hipLaunchKernelGGL((head_fwd_kernel<float, KMAX>), dim3(grid), dim3(256), smem, st,
+                         (const float*)x, w, b, logits, npix, C, K);
+  } else {  // stacked cluster sub-heads (DenseClusterHead: 5 x 20 outputs)
+    if (h)
+      hipLaunchKernelGGL((head_fwd_kernel<bf16, KWIDE>), dim3(grid), dim3(256), smem, st,
+                         (const bf16*)x, w, b, logits, npix, C, K);
+    else
+      hipLaunchKernelGGL((head_fwd_kernel<float, KWIDE>), dim3(grid), dim3(256), smem, st,
+                         (const float*)x, w, b, logits, npix, C, K);
+  }
   CY_CHECK_LAUNCH();
   return CY_OK;
 }
@@ -401,7 +411,7 @@ int cy_head1x1_bwd(const void* x, const float* w, const float* dlogits, void* dx
                    float* db, long npix, int C, int K, int x_dtype, void* ws, size_t ws_bytes,
                    void* stream) {
   if (!x || !w || !dlogits || npix <= 0) return CY_ERR_ARG;
-  if (C % 8 || K < 1 || K > KMAX || (size_t)(K * C + K) * 4 > 60000) return CY_ERR_SHAPE;
+  if (C % 8 || K < 1 || K > KWIDE || (size_t)(K * C + K) * 4 > 60000) return CY_ERR_SHAPE;
   if (x_dtype != CY_BF16 && x_dtype != CY_F32) return CY_ERR_DTYPE;
   hipStream_t st = (hipStream_t)stream;
   if (dx) {

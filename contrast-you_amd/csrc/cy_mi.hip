@@ -1,0 +1,418 @@
+// Discrete mutual-information losses over cluster-probability maps.
+//   DenseClusterHead / ClusterHead softmax(T)     contrastyou/projectors/heads.py:44-78,125-173,
+//                                                 contrastyou/projectors/nn.py:35-44
+//   compute_joint (vectors)                       contrastyou/losses/discreteMI.py:201-222
+//   compute_joint_2D (displaced, padding > 0)     contrastyou/losses/discreteMI.py:225-243
+//   compute_joint_2D_with_padding_zeros           contrastyou/losses/discreteMI.py:246-261
+//   IIDLoss / IIDSegmentationLoss                 contrastyou/losses/discreteMI.py:90-170
+//
+// The k x k joint of two [pixels][k] probability maps is a skinny contraction over N*H*W pixels
+// (k = 20): HBM-bound, 2*k*4 bytes read per pixel, k*k FMAs.  It is NOT reshaped into an MFMA
+// GEMM: each thread keeps a 4x4 register tile of the joint and walks a slice of the pixels of an
+// LDS-staged tile; block partials are reduced in a fixed order (deterministic).
+// Layouts: probability maps are NHWC f32 [N][H][W][k]; joints are [T*T][k][k], T = 2*padding+1.
+#include "cy_common.h"
+
+namespace {
+
+constexpr int J_P = 64;      // pixels per staged tile
+constexpr int J_KMAX = 64;   // max clusters
+
+inline int grid_for(long n) {
+  long b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+// ---------------------------------------------------------------- grouped softmax
+// in  [M][S*k] logits  ->  out [S][M][k] probabilities of softmax(logits * invT) per group
+__global__ void __launch_bounds__(256)
+    group_softmax_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, long M, int S,
+                             int k, float invT) {
+  const long total = M * S;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const int s = (int)(e % S);
+    const long m = e / S;
+    const float* src = in + m * (long)(S * k) + (long)s * k;
+    float mx = -INFINITY;
+    for (int i = 0; i < k; ++i) mx = fmaxf(mx, src[i] * invT);
+    float sum = 0.f;
+    for (int i = 0; i < k; ++i) sum += __expf(src[i] * invT - mx);
+    const float r = 1.f / sum;
+    float* dst = out + ((long)s * M + m) * k;
+    for (int i = 0; i < k; ++i) dst[i] = __expf(src[i] * invT - mx) * r;
+  }
+}
+
+// dlogits[m][s*k+i] = invT * p_i * (dp_i - sum_j p_j dp_j)
+__global__ void __launch_bounds__(256)
+    group_softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                             float* __restrict__ dlogits, long M, int S, int k, float invT) {
+  const long total = M * S;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const int s = (int)(e % S);
+    const long m = e / S;
+    const float* pp = p + ((long)s * M + m) * k;
+    const float* dd = dp + ((long)s * M + m) * k;
+    float dot = 0.f;
+    for (int i = 0; i < k; ++i) dot = fmaf(pp[i], dd[i], dot);
+    float* dst = dlogits + m * (long)(S * k) + (long)s * k;
+    for (int i = 0; i < k; ++i) dst[i] = invT * pp[i] * (dd[i] - dot);
+  }
+}
+
+// ---------------------------------------------------------------- joint forward
+// part[blockIdx.y = displacement][blockIdx.x][k*k]
+__global__ void __launch_bounds__(256)
+    joint_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                     float* __restrict__ part, int N, int H, int W, int k, int pad) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int kp = (k + 3) & ~3, k4 = kp >> 2;
+  const int tps = k4 * k4;           // threads per pixel slice
+  const int nsl = 256 / tps;         // slices (>= 1 because k <= 64)
+  float* xs1 = sm;                   // [J_P][kp]
+  float* xs2 = sm + J_P * kp;        // [J_P][kp]
+  float* red = sm + 2 * J_P * kp;    // [nsl][kp*kp]
+  const int tid = threadIdx.x;
+  const int T = 2 * pad + 1;
+  const int du = (int)blockIdx.y / T - pad, dv = (int)blockIdx.y % T - pad;
+  const int sl = tid / tps, tt = tid - sl * tps;
+  const int ti = tt / k4, tj = tt - ti * k4;
+  const bool active = sl < nsl;
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  const long npix = (long)N * H * W;
+  const long per = ((npix + gridDim.x - 1) / gridDim.x + J_P - 1) / J_P * J_P;
+  const long p0 = (long)blockIdx.x * per;
+  const long p1 = p0 + per < npix ? p0 + per : npix;
+  for (long pt = p0; pt < p1; pt += J_P) {
+    __syncthreads();
+    for (int e = tid; e < J_P * kp; e += 256) {
+      const int p = e / kp, c = e - p * kp;
+      const long pix = pt + p;
+      float a = 0.f, b = 0.f;
+      if (pix < p1 && c < k) {
+        b = x2[pix * k + c];
+        if (pad == 0) {
+          a = x1[pix * k + c];
+        } else {
+          const int w = (int)(pix % W);
+          const long t = pix / W;
+          const int h = (int)(t % H);
+          const int hh = h + du, ww = w + dv;
+          if (hh >= 0 && hh < H && ww >= 0 && ww < W) a = x1[(pix + (long)du * W + dv) * k + c];
+        }
+      }
+      xs1[e] = a;
+      xs2[e] = b;
+    }
+    __syncthreads();
+    if (active) {
+      for (int p = sl; p < J_P; p += nsl) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xs1 + p * kp + 4 * ti);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(xs2 + p * kp + 4 * tj);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+      }
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[sl * kp * kp + (4 * ti + i) * kp + 4 * tj + j] = acc[i][j];
+  }
+  __syncthreads();
+  float* dst = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (k * k);
+  for (int e = tid; e < k * k; e += 256) {
+    const int i = e / k, j = e - i * k;
+    float s = 0.f;
+    for (int q = 0; q < nsl; ++q) s += red[q * kp * kp + i * kp + j];
+    dst[e] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    joint_reduce_kernel(const float* __restrict__ part, float* __restrict__ J, int TT, int nblk,
+                         int kk, double scale) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= TT * kk) return;
+  const int d = e / kk, r = e - d * kk;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)part[((size_t)d * nblk + b) * kk + r];
+  J[e] = (float)(s * scale);
+}
+
+// ---------------------------------------------------------------- joint backward
+// which = 0: dx1[pix][i] = g*scale * sum_{d,j} dJ[d][i][j] * x2[pix - disp(d)][j]
+// which = 1: dx2[pix][j] = g*scale * sum_{d,i} dJ[d][i][j] * x1[pix + disp(d)][i]
+__global__ void __launch_bounds__(256)
+    joint_bwd_kernel(const float* __restrict__ other, const float* __restrict__ dJ,
+                     const float* __restrict__ gscale, float* __restrict__ dx, int N, int H, int W,
+                     int k, int pad, float scale, int which) {
+  extern __shared__ float sdj[];  // [T*T][k][k]
+  const int T = 2 * pad + 1, TT = T * T;
+  for (int e = threadIdx.x; e < TT * k * k; e += 256) sdj[e] = dJ[e];
+  __syncthreads();
+  const float g = gscale[0] * scale;
+  const long total = (long)N * H * W * k;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const int c = (int)(e % k);
+    const long pix = e / k;
+    const int w = (int)(pix % W);
+    const int h = (int)((pix / W) % H);
+    float s = 0.f;
+    for (int d = 0; d < TT; ++d) {
+      const int du = d / T - pad, dv = d % T - pad;
+      const int hh = which ? h + du : h - du, ww = which ? w + dv : w - dv;
+      if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+      const long q = which ? pix + (long)du * W + dv : pix - (long)du * W - dv;
+      const float* o = other + q * k;
+      const float* m = sdj + d * k * k;
+      if (which) {
+        for (int i = 0; i < k; ++i) s = fmaf(m[i * k + c], o[i], s);
+      } else {
+        for (int j = 0; j < k; ++j) s = fmaf(m[c * k + j], o[j], s);
+      }
+    }
+    dx[e] = g * s;
+  }
+}
+
+// ---------------------------------------------------------------- loss on the joint (one block)
+__device__ __forceinline__ double block_sum(double v, double* sred) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  sred[tid] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) sred[tid] += sred[tid + o];
+    __syncthreads();
+  }
+  const double r = sred[0];
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ double block_min(double v, double* sred) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  sred[tid] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) sred[tid] = fmin(sred[tid], sred[tid + o]);
+    __syncthreads();
+  }
+  const double r = sred[0];
+  __syncthreads();
+  return r;
+}
+
+// mode 0: segmentation, padding 0 (no normalisation)      mode 1: segmentation, padding > 0
+// mode 2: vectors (IIDLoss): symmetrise + normalise to 1
+// ws: 4 arrays of TT*kk floats (p1, p2/p, dP, tmp) + (2*TT*k) marginals
+// out[0] = loss, out[1] = loss with lambda = 1 (mode 2 only); P = final joint; dJ = dloss/dJ.
+__global__ void __launch_bounds__(256)
+    iid_loss_kernel(const float* __restrict__ J, float* __restrict__ out, float* __restrict__ P,
+                    float* __restrict__ dJ, float* __restrict__ ws, int TT, int k, int mode,
+                    int symmetric, float lamda, float eps) {
+  __shared__ double sred[256];
+  const int tid = threadIdx.x;
+  const int kk = k * k, n = TT * kk;
+  float* p1 = ws;            // per-displacement normalised (mode 1) / raw
+  float* p = ws + n;         // final joint
+  float* dP = ws + 2 * n;    // dloss/dp, then dloss/dp2
+  float* row = ws + 4 * n;   // r_i  [TT][k]
+  float* col = row + TT * k; // c_j  [TT][k]
+  float* S = col + TT * k;   // [TT] displacement sums (mode 1)
+
+  // ---- forward normalisations
+  double Z = 1.0;
+  if (mode == 1) {
+    double mn = 1e300;
+    for (int e = tid; e < n; e += 256) mn = fmin(mn, (double)J[e]);
+    mn = block_min(mn, sred);
+    for (int d = 0; d < TT; ++d) {
+      double s = 0.0;
+      for (int e = tid; e < kk; e += 256) s += (double)J[d * kk + e] - mn + 1e-8;
+      s = block_sum(s, sred);
+      if (tid == 0) S[d] = (float)s;
+      for (int e = tid; e < kk; e += 256) p1[d * kk + e] = (float)(((double)J[d * kk + e] - mn + 1e-8) / s);
+    }
+  } else {
+    for (int e = tid; e < n; e += 256) p1[e] = J[e];
+  }
+  __syncthreads();
+  {  // symmetrise into p (unnormalised), then global normalisation for modes 1, 2
+    double z = 0.0;
+    for (int e = tid; e < n; e += 256) {
+      const int d = e / kk, r = e - d * kk, i = r / k, j = r - i * k;
+      float v = p1[e];
+      if (symmetric) v = 0.5f * (v + p1[d * kk + j * k + i]);
+      p[e] = v;
+      z += (double)v;
+    }
+    if (mode != 0) {
+      Z = block_sum(z, sred);
+      for (int e = tid; e < n; e += 256) p[e] = (float)((double)p[e] / Z);
+    }
+  }
+  __syncthreads();
+  // ---- marginals per displacement
+  for (int e = tid; e < TT * k; e += 256) {
+    const int d = e / k, a = e - d * k;
+    double r = 0.0, c = 0.0;
+    for (int b = 0; b < k; ++b) {
+      r += (double)p[d * kk + a * k + b];
+      c += (double)p[d * kk + b * k + a];
+    }
+    row[e] = (float)r;
+    col[e] = (float)c;
+  }
+  __syncthreads();
+  // ---- loss and dloss/dp
+  const double invTT = mode == 1 ? 1.0 / (double)TT : 1.0;
+  double l = 0.0, l1 = 0.0;
+  for (int e = tid; e < n; e += 256) {
+    const int d = e / kk, r = e - d * kk, a = r / k, b = r - a * k;
+    const double pv = p[e], ra = row[d * k + a], cb = col[d * k + b];
+    const double lp = log(pv + eps), lr = log(ra + eps), lc = log(cb + eps);
+    l += -pv * (lp - lamda * lc - lamda * lr);
+    l1 += -pv * (lp - lc - lr);
+    const double g = -(lp - lamda * lc - lamda * lr) - pv / (pv + eps) + lamda * cb / (cb + eps) +
+                     lamda * ra / (ra + eps);
+    dP[e] = (float)(g * invTT);
+    if (P) P[e] = (float)pv;
+  }
+  l = block_sum(l, sred);
+  l1 = block_sum(l1, sred);
+  if (tid == 0) {
+    out[0] = (float)(l * invTT);
+    out[1] = (float)(l1 * invTT);
+  }
+  if (!dJ) return;
+  // ---- backward through the normalisations
+  if (mode != 0) {  // p = p2 / Z
+    double dot = 0.0;
+    for (int e = tid; e < n; e += 256) dot += (double)dP[e] * (double)p[e];
+    dot = block_sum(dot, sred);
+    for (int e = tid; e < n; e += 256) dP[e] = (float)(((double)dP[e] - dot) / Z);
+  }
+  __syncthreads();
+  float* dp1 = ws + 3 * n;
+  for (int e = tid; e < n; e += 256) {
+    const int d = e / kk, r = e - d * kk, i = r / k, j = r - i * k;
+    dp1[e] = symmetric ? 0.5f * (dP[e] + dP[d * kk + j * k + i]) : dP[e];
+  }
+  __syncthreads();
+  if (mode == 1) {
+    for (int d = 0; d < TT; ++d) {
+      double dot = 0.0;
+      for (int e = tid; e < kk; e += 256) dot += (double)dp1[d * kk + e] * (double)p1[d * kk + e];
+      dot = block_sum(dot, sred);
+      const double s = S[d];
+      for (int e = tid; e < kk; e += 256) dJ[d * kk + e] = (float)(((double)dp1[d * kk + e] - dot) / s);
+    }
+  } else {
+    for (int e = tid; e < n; e += 256) dJ[e] = dp1[e];
+  }
+}
+
+inline int joint_blocks(long npix) {
+  long b = (npix + 4095) / 4096;
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int cy_group_softmax_fwd(const float* logits, float* probs, long M, int S, int k, float invT,
+                         void* stream) {
+  if (!logits || !probs || M <= 0 || S <= 0 || k <= 0) return CY_ERR_ARG;
+  hipLaunchKernelGGL(group_softmax_fwd_kernel, dim3(grid_for(M * S)), dim3(256), 0,
+                     (hipStream_t)stream, logits, probs, M, S, k, invT);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_group_softmax_bwd(const float* probs, const float* dprobs, float* dlogits, long M, int S,
+                         int k, float invT, void* stream) {
+  if (!probs || !dprobs || !dlogits || M <= 0 || S <= 0 || k <= 0) return CY_ERR_ARG;
+  hipLaunchKernelGGL(group_softmax_bwd_kernel, dim3(grid_for(M * S)), dim3(256), 0,
+                     (hipStream_t)stream, probs, dprobs, dlogits, M, S, k, invT);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+size_t cy_joint_ws_bytes(int N, int H, int W, int k, int pad) {
+  const int T = 2 * pad + 1;
+  return (size_t)T * T * joint_blocks((long)N * H * W) * k * k * sizeof(float);
+}
+
+/* J[T*T][k][k] = scale * sum over pixels of x1[shifted] (x) x2 ; scale = 1/(N*H*W) when
+ * normalise != 0 (the padding-0 segmentation joint), else 1. */
+int cy_joint_fwd(const float* x1, const float* x2, float* J, int N, int H, int W, int k, int pad,
+                 int normalise, void* ws, size_t ws_bytes, void* stream) {
+  if (!x1 || !x2 || !J || N <= 0 || H <= 0 || W <= 0) return CY_ERR_ARG;
+  if (k < 1 || k > J_KMAX || pad < 0 || pad >= H || pad >= W) return CY_ERR_SHAPE;
+  if (!ws || ws_bytes < cy_joint_ws_bytes(N, H, W, k, pad)) return CY_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const long npix = (long)N * H * W;
+  const int nblk = joint_blocks(npix), T = 2 * pad + 1;
+  const int kp = (k + 3) & ~3, k4 = kp / 4, nsl = 256 / (k4 * k4);
+  const size_t smem = (size_t)(2 * J_P * kp + nsl * kp * kp) * sizeof(float);
+  hipLaunchKernelGGL(joint_fwd_kernel, dim3(nblk, T * T), dim3(256), smem, st, x1, x2, (float*)ws,
+                     N, H, W, k, pad);
+  CY_CHECK_LAUNCH();
+  hipLaunchKernelGGL(joint_reduce_kernel, dim3(cy_cdiv((long)T * T * k * k, 256)), dim3(256), 0, st,
+                     (const float*)ws, J, T * T, nblk, k * k,
+                     normalise ? 1.0 / (double)npix : 1.0);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_joint_bwd(const float* x1, const float* x2, const float* dJ, const float* gscale, float* dx1,
+                 float* dx2, int N, int H, int W, int k, int pad, int normalise, void* stream) {
+  if (!x1 || !x2 || !dJ || !gscale || N <= 0 || H <= 0 || W <= 0) return CY_ERR_ARG;
+  if (k < 1 || k > J_KMAX || pad < 0) return CY_ERR_SHAPE;
+  const int T = 2 * pad + 1;
+  const size_t smem = (size_t)T * T * k * k * sizeof(float);
+  if (smem > 64 * 1024) return CY_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const long npix = (long)N * H * W;
+  const float scale = normalise ? (float)(1.0 / (double)npix) : 1.f;
+  const int grid = grid_for(npix * k);
+  if (dx1) {
+    hipLaunchKernelGGL(joint_bwd_kernel, dim3(grid), dim3(256), smem, st, x2, dJ, gscale, dx1, N, H,
+                       W, k, pad, scale, 0);
+    CY_CHECK_LAUNCH();
+  }
+  if (dx2) {
+    hipLaunchKernelGGL(joint_bwd_kernel, dim3(grid), dim3(256), smem, st, x1, dJ, gscale, dx2, N, H,
+                       W, k, pad, scale, 1);
+    CY_CHECK_LAUNCH();
+  }
+  return CY_OK;
+}
+
+size_t cy_iid_loss_ws_bytes(int TT, int k) {
+  return ((size_t)4 * TT * k * k + 2 * (size_t)TT * k + TT) * sizeof(float);
+}
+
+int cy_iid_loss(const float* J, float* out2, float* P, float* dJ, int TT, int k, int mode,
+                int symmetric, float lamda, float eps, void* ws, size_t ws_bytes, void* stream) {
+  if (!J || !out2 || TT <= 0 || k <= 0) return CY_ERR_ARG;
+  if (mode < 0 || mode > 2 || k > J_KMAX) return CY_ERR_SHAPE;
+  if (!ws || ws_bytes < cy_iid_loss_ws_bytes(TT, k)) return CY_ERR_WORKSPACE;
+  hipLaunchKernelGGL(iid_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, J, out2, P, dJ,
+                     (float*)ws, TT, k, mode, symmetric, lamda, eps);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+}  // extern "C"

@@ -11,7 +11,7 @@ from pathlib import Path
 
 CY_F32, CY_BF16 = 0, 1
 CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2 = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _ERRORS = {-1: "CY_ERR_ARG (bad/NULL argument)", -2: "CY_ERR_SHAPE (unsupported shape)",
            -3: "CY_ERR_DTYPE (unsupported dtype)", -4: "CY_ERR_LAUNCH (HIP launch failed)",
@@ -89,6 +89,27 @@ _SIGS = {
     "cy_softmax_mse_bwd": (c_int, [_P, _P, _P, _P, _P, c_long, c_int, _P]),
     "cy_radam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_float,
                               c_long, _P]),
+    "cy_dense_proj_fwd": (c_int, [_P, _P, _P, _P, c_int, _P] + [c_int] * 8 + [c_float, c_int, _P]),
+    "cy_dense_proj_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cy_dense_proj_bwd": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int] + [c_int] * 8 +
+                          [c_float, c_int, _P, c_size_t, _P]),
+    "cy_adaptive_avgpool_fwd": (c_int, [_P, _P, c_int, _P] + [c_int] * 8 + [_P]),
+    "cy_adaptive_avgpool_bwd": (c_int, [_P, _P] + [c_int] * 8 + [_P]),
+    "cy_gather_rows_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "cy_gather_rows_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "cy_group_softmax_fwd": (c_int, [_P, _P, c_long, c_int, c_int, c_float, _P]),
+    "cy_group_softmax_bwd": (c_int, [_P, _P, _P, c_long, c_int, c_int, c_float, _P]),
+    "cy_joint_ws_bytes": (c_size_t, [c_int] * 5),
+    "cy_joint_fwd": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P, c_size_t, _P]),
+    "cy_joint_bwd": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 6 + [_P]),
+    "cy_iid_loss_ws_bytes": (c_size_t, [c_int, c_int]),
+    "cy_iid_loss": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
+    "cy_gn_ws_bytes": (c_size_t, [c_int, c_int]),
+    "cy_gn_silu_fwd": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_float,
+                               c_int, _P, c_size_t, _P]),
+    "cy_gn_silu_bwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int,
+                               c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "cy_bilinear_fwd": (c_int, [_P, _P] + [c_int] * 7 + [_P]),
 }
 
 # functions whose int return is a count / size, not a status

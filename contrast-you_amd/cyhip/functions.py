@@ -373,3 +373,169 @@ class AffineFn(torch.autograd.Function):
                                "the reference applies it to input images only")
         (theta,) = ctx.saved_tensors
         return ops.affine_bwd(g, theta), None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# dense contrastive projector, point sampling, cluster heads, discrete MI, GroupNorm block
+# ------------------------------------------------------------------------------------------------
+class DenseProjHiddenFn(torch.autograd.Function):
+    """mean over adaptive-pool bins of LeakyReLU(Conv1x1(x)) -> [bins, hid]: the fused front half of
+    DenseProjectionHead (contrastyou/projectors/heads.py:31-41,99-123); the second 1x1 conv commutes
+    with the average pool and is applied to the pooled rows."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w1: Tensor, b1: Tensor, size, bins: Optional[Tensor]):
+        ops.require_gpu(x, w1)
+        x = ops.to_nhwc(x)
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        w = w1.detach().reshape(w1.shape[0], -1).float().contiguous()
+        b = b1.detach().float().contiguous()
+        ctx.save_for_backward(x, w, b)
+        ctx.size, ctx.bins = tuple(size), bins
+        return ops.dense_proj_fwd(x, w, b, ctx.size, bins)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, w, b = ctx.saved_tensors
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx, dw, db = ops.dense_proj_bwd(x, w, b, ctx.size, ctx.bins, g.float().contiguous(), need_dx, need_dw)
+        if dw is not None:
+            dw = dw.view(dw.shape[0], dw.shape[1], 1, 1)
+        return dx, dw if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None, None, None
+
+
+class AdaptiveAvgPoolFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d(size) on an NHWC map -> f32 rows [N*sh*sw, C]"""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, size):
+        ops.require_gpu(x)
+        x = ops.to_nhwc(x)
+        ctx.shape, ctx.dtype, ctx.size = tuple(x.shape), x.dtype, tuple(size)
+        return ops.adaptive_avgpool_fwd(x, ctx.size)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return ops.adaptive_avgpool_bwd(g.float().contiguous(), ctx.shape, ctx.dtype, ctx.size), None
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """rows[idx] for distinct idx (the point sampling of semi_seg/hooks/infonce.py:31-46)"""
+
+    @staticmethod
+    def forward(ctx, src: Tensor, idx: Tensor):
+        src = src.float().contiguous()
+        ctx.save_for_backward(idx)
+        ctx.rows = src.shape[0]
+        return ops.gather_rows_fwd(src, idx)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (idx,) = ctx.saved_tensors
+        return ops.gather_rows_bwd(g.float().contiguous(), idx, ctx.rows), None
+
+
+class GroupSoftmaxFn(torch.autograd.Function):
+    """[M, S*k] logits -> [S, M, k] probabilities, softmax(logits / T) inside each sub-head
+    (SoftmaxWithT, contrastyou/projectors/nn.py:35-44)"""
+
+    @staticmethod
+    def forward(ctx, logits: Tensor, S: int, k: int, T: float):
+        logits = logits.float().contiguous()
+        probs = ops.group_softmax_fwd(logits, S, k, T)
+        ctx.save_for_backward(probs)
+        ctx.T = T
+        return probs
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (probs,) = ctx.saved_tensors
+        return ops.group_softmax_bwd(probs, g.float().contiguous(), ctx.T), None, None, None
+
+
+class IIDFn(torch.autograd.Function):
+    """joint of two probability maps + information loss in one autograd node.
+    x1, x2: f32 [N,H,W,k] contiguous (vectors: H=W=1).  mode 0/1: IIDSegmentationLoss with padding
+    0 / >0; mode 2: IIDLoss (contrastyou/losses/discreteMI.py:90-170,201-261).
+    Returns (loss, loss with lambda=1, normalised joint [T*T,k,k])."""
+
+    @staticmethod
+    def forward(ctx, x1: Tensor, x2: Tensor, mode: int, pad: int, symmetric: bool, lamda: float, eps: float):
+        ops.require_gpu(x1, x2)
+        N, H, W, k = x1.shape
+        normalise = mode == 0
+        J = ops.joint_fwd(x1, x2, N, H, W, k, pad, normalise)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        out2, P, dJ = ops.iid_loss(J, mode, symmetric, lamda, eps, want_grad=need)
+        ctx.save_for_backward(x1, x2, dJ)
+        ctx.cfg = (N, H, W, k, pad, normalise)
+        ctx.mark_non_differentiable(P)
+        return out2[0], out2[1].detach(), P
+
+    @staticmethod
+    def backward(ctx, g: Tensor, _g1, _gP):
+        x1, x2, dJ = ctx.saved_tensors
+        N, H, W, k, pad, normalise = ctx.cfg
+        gs = g.reshape(1).float().contiguous()
+        d1, d2 = ops.joint_bwd(x1, x2, dJ, gs, N, H, W, k, pad, normalise, ctx.needs_input_grad[0],
+                               ctx.needs_input_grad[1])
+        return d1, d2, None, None, None, None, None
+
+
+class GNSiLUFn(torch.autograd.Function):
+    """GroupNorm(G, C)(y + bias) -> SiLU on a raw (bias-free) conv output (arch/unet2.py:208-224)"""
+
+    @staticmethod
+    def forward(ctx, y: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, groups: int, eps: float):
+        y = ops.to_nhwc(y)
+        b = None if bias is None else bias.detach().float().contiguous()
+        gm, bt = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        out, mr = ops.gn_silu_fwd(y, b, gm, bt, groups, eps)
+        ctx.save_for_backward(y, b, gm, bt, mr)
+        ctx.groups = groups
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        y, b, gm, bt, mr = ctx.saved_tensors
+        g = ops.to_nhwc(g if g.dtype == y.dtype else g.to(y.dtype))
+        du, dg, dbt, dbias = ops.gn_silu_bwd(y, g, b, gm, bt, mr, ctx.groups)
+        return du, dbias, dg, dbt, None, None
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """bias-free 3x3 convolution (stride 1, padding 1) on the implicit-GEMM kernels; NHWC in/out.
+    Used by the GroupNorm block, whose conv bias is folded into the normalisation kernels."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor):
+        ops.require_gpu(x, w)
+        x = ops.to_nhwc(x)
+        wf, wd = packed_weights(w, x.dtype)
+        out, _ = ops.conv3x3_fwd(x, None, wf, w.shape[0], want_stats=False)
+        ctx.save_for_backward(x, w)
+        ctx.wd = wd
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, w = ctx.saved_tensors
+        g = ops.to_nhwc(g if g.dtype == x.dtype else g.to(x.dtype))
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx, _ = ops.conv3x3_fwd(g, None, ctx.wd, x.shape[1], want_stats=False)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv3x3_wgrad(x, None, g).to(w.dtype)
+        return dx, dw
+
+
+def bilinear_resize(x: Tensor, size) -> Tensor:
+    """F.interpolate(x, size=size, mode="bilinear") (align_corners=False) for inputs that carry no
+    gradient -- the reference resizes input images only (semi_seg/hooks/cc.py:132)"""
+    if x.requires_grad:
+        raise RuntimeError("bilinear_resize: the HIP kernel is forward-only (input images carry no gradient)")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    return ops.bilinear_fwd(x, tuple(size))

@@ -536,3 +536,166 @@ def radam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: flo
     require_gpu(p, g)
     _lib.call("cy_radam_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
               float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step), _stream())
+
+
+# --------------------------------------------------------------------------- dense projector / sampling
+def _bins_tensor(bins, device) -> Optional[Tensor]:
+    """host list/array of (image, bin row, bin col) -> int32 device tensor [nb,3] (sync-free upload)"""
+    if bins is None:
+        return None
+    if isinstance(bins, Tensor):
+        return bins if bins.is_cuda else pinned.upload(bins.to(torch.int32).contiguous(), device)
+    return pinned.upload(torch.as_tensor(bins, dtype=torch.int32).reshape(-1, 3).contiguous(), device)
+
+
+def dense_proj_fwd(x: Tensor, w1: Tensor, b1: Tensor, size: Tuple[int, int], bins: Optional[Tensor],
+                   slope: float = 0.01) -> Tensor:
+    """x NHWC [N,C,H,W]; w1 f32 [hid,C]; -> hpool f32 [nb, hid] = mean over each bin of lrelu(w1 x + b1)"""
+    require_gpu(x, w1, b1)
+    N, Cc, H, W = x.shape
+    hid = w1.shape[0]
+    nb = N * size[0] * size[1] if bins is None else bins.shape[0]
+    out = _f32(nb * hid, x.device).view(nb, hid)
+    _lib.call("cy_dense_proj_fwd", x.data_ptr(), w1.data_ptr(), b1.data_ptr(), _ptr(bins), nb,
+              out.data_ptr(), N, H, W, Cc, Cc, hid, size[0], size[1], slope, dtype_code(x.dtype), _stream())
+    return out
+
+
+def dense_proj_bwd(x: Tensor, w1: Tensor, b1: Tensor, size: Tuple[int, int], bins: Optional[Tensor],
+                   dhpool: Tensor, need_dx: bool, need_dw: bool, slope: float = 0.01):
+    N, Cc, H, W = x.shape
+    hid = w1.shape[0]
+    nb = dhpool.shape[0]
+    dx = None
+    if need_dx:
+        dx = torch.zeros((N, H, W, Cc), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
+    dw = _f32(hid * Cc, x.device).view(hid, Cc) if need_dw else None
+    db = _f32(hid, x.device) if need_dw else None
+    nbytes = _lib.load().cy_dense_proj_bwd_ws_bytes(nb, Cc, hid)
+    ws = _ws(nbytes, x.device)
+    _lib.call("cy_dense_proj_bwd", x.data_ptr(), w1.data_ptr(), b1.data_ptr(), _ptr(bins), nb,
+              dhpool.data_ptr(), _ptr(dx), _ptr(dw), _ptr(db), 0, N, H, W, Cc, Cc, hid, size[0], size[1],
+              slope, dtype_code(x.dtype), ws.data_ptr(), nbytes, _stream())
+    return dx, dw, db
+
+
+def adaptive_avgpool_fwd(x: Tensor, size: Tuple[int, int], bins: Optional[Tensor] = None) -> Tensor:
+    require_gpu(x)
+    N, Cc, H, W = x.shape
+    nb = N * size[0] * size[1] if bins is None else bins.shape[0]
+    out = _f32(nb * Cc, x.device).view(nb, Cc)
+    _lib.call("cy_adaptive_avgpool_fwd", x.data_ptr(), _ptr(bins), nb, out.data_ptr(), N, H, W, Cc, Cc,
+              size[0], size[1], dtype_code(x.dtype), _stream())
+    return out
+
+
+def adaptive_avgpool_bwd(dpool: Tensor, shape, dtype, size: Tuple[int, int]) -> Tensor:
+    N, Cc, H, W = shape
+    dx = empty_nhwc(N, Cc, H, W, dtype, dpool.device)
+    _lib.call("cy_adaptive_avgpool_bwd", dpool.data_ptr(), dx.data_ptr(), N, H, W, Cc, Cc, size[0], size[1],
+              dtype_code(dtype), _stream())
+    return dx
+
+
+def gather_rows_fwd(src: Tensor, idx: Tensor) -> Tensor:
+    require_gpu(src, idx)
+    M, D = idx.shape[0], src.shape[1]
+    out = _f32(M * D, src.device).view(M, D)
+    _lib.call("cy_gather_rows_fwd", src.data_ptr(), idx.data_ptr(), out.data_ptr(), M, D, _stream())
+    return out
+
+
+def gather_rows_bwd(dout: Tensor, idx: Tensor, rows: int) -> Tensor:
+    M, D = dout.shape
+    dsrc = torch.zeros((rows, D), dtype=torch.float32, device=dout.device)
+    _lib.call("cy_gather_rows_bwd", dout.data_ptr(), idx.data_ptr(), dsrc.data_ptr(), M, D, _stream())
+    return dsrc
+
+
+# --------------------------------------------------------------------------- cluster heads / discrete MI
+def group_softmax_fwd(logits: Tensor, S: int, k: int, T: float = 1.0) -> Tensor:
+    """logits f32 [M, S*k] -> probs f32 [S, M, k]"""
+    require_gpu(logits)
+    M = logits.shape[0]
+    probs = _f32(S * M * k, logits.device).view(S, M, k)
+    _lib.call("cy_group_softmax_fwd", logits.data_ptr(), probs.data_ptr(), M, S, k, 1.0 / T, _stream())
+    return probs
+
+
+def group_softmax_bwd(probs: Tensor, dprobs: Tensor, T: float = 1.0) -> Tensor:
+    S, M, k = probs.shape
+    dl = _f32(M * S * k, probs.device).view(M, S * k)
+    _lib.call("cy_group_softmax_bwd", probs.data_ptr(), dprobs.data_ptr(), dl.data_ptr(), M, S, k, 1.0 / T,
+              _stream())
+    return dl
+
+
+def joint_fwd(x1: Tensor, x2: Tensor, N: int, H: int, W: int, k: int, pad: int, normalise: bool) -> Tensor:
+    """x1, x2: f32 NHWC-contiguous [N,H,W,k] buffers -> J f32 [T*T, k, k]"""
+    require_gpu(x1, x2)
+    T = 2 * pad + 1
+    J = _f32(T * T * k * k, x1.device).view(T * T, k, k)
+    nbytes = _lib.load().cy_joint_ws_bytes(N, H, W, k, pad)
+    ws = _ws(nbytes, x1.device)
+    _lib.call("cy_joint_fwd", x1.data_ptr(), x2.data_ptr(), J.data_ptr(), N, H, W, k, pad, int(normalise),
+              ws.data_ptr(), nbytes, _stream())
+    return J
+
+
+def joint_bwd(x1: Tensor, x2: Tensor, dJ: Tensor, gscale: Tensor, N: int, H: int, W: int, k: int, pad: int,
+              normalise: bool, need1: bool, need2: bool):
+    d1 = torch.empty_like(x1) if need1 else None
+    d2 = torch.empty_like(x2) if need2 else None
+    _lib.call("cy_joint_bwd", x1.data_ptr(), x2.data_ptr(), dJ.data_ptr(), gscale.data_ptr(), _ptr(d1), _ptr(d2),
+              N, H, W, k, pad, int(normalise), _stream())
+    return d1, d2
+
+
+def iid_loss(J: Tensor, mode: int, symmetric: bool, lamda: float, eps: float, want_grad: bool = True):
+    """-> (out2 [2] = loss(lamda), loss(1); P [TT,k,k] normalised joint; dJ or None)"""
+    TT, k = J.shape[0], J.shape[1]
+    out2 = _f32(2, J.device)
+    P = torch.empty_like(J)
+    dJ = torch.empty_like(J) if want_grad else None
+    nbytes = _lib.load().cy_iid_loss_ws_bytes(TT, k)
+    ws = _ws(nbytes, J.device)
+    _lib.call("cy_iid_loss", J.data_ptr(), out2.data_ptr(), P.data_ptr(), _ptr(dJ), TT, k, mode, int(symmetric),
+              lamda, eps, ws.data_ptr(), nbytes, _stream())
+    return out2, P, dJ
+
+
+# --------------------------------------------------------------------------- GroupNorm + SiLU, bilinear
+def gn_silu_fwd(y: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, groups: int, eps: float):
+    require_gpu(y, gamma, beta)
+    N, Cc, H, W = y.shape
+    out = empty_nhwc(N, Cc, H, W, y.dtype, y.device)
+    mr = _f32(N * groups * 2, y.device)
+    nbytes = _lib.load().cy_gn_ws_bytes(N, Cc)
+    ws = _ws(nbytes, y.device)
+    _lib.call("cy_gn_silu_fwd", y.data_ptr(), Cc, _ptr(bias), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+              Cc, mr.data_ptr(), N, H * W, Cc, groups, eps, dtype_code(y.dtype), ws.data_ptr(), nbytes, _stream())
+    return out, mr
+
+
+def gn_silu_bwd(y: Tensor, dz: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, mr: Tensor,
+                groups: int):
+    N, Cc, H, W = y.shape
+    du = empty_nhwc(N, Cc, H, W, y.dtype, y.device)
+    dg, dbt = _f32(Cc, y.device), _f32(Cc, y.device)
+    dbias = _f32(Cc, y.device) if bias is not None else None
+    nbytes = _lib.load().cy_gn_ws_bytes(N, Cc)
+    ws = _ws(nbytes, y.device)
+    _lib.call("cy_gn_silu_bwd", y.data_ptr(), Cc, dz.data_ptr(), Cc, _ptr(bias), gamma.data_ptr(), beta.data_ptr(),
+              mr.data_ptr(), du.data_ptr(), Cc, dg.data_ptr(), dbt.data_ptr(), _ptr(dbias), 0, N, H * W, Cc, groups,
+              dtype_code(y.dtype), ws.data_ptr(), nbytes, _stream())
+    return du, dg, dbt, dbias
+
+
+def bilinear_fwd(x: Tensor, size: Tuple[int, int]) -> Tensor:
+    require_gpu(x)
+    x = to_nhwc(x)
+    N, Cc, H, W = x.shape
+    out = empty_nhwc(N, Cc, size[0], size[1], x.dtype, x.device)
+    _lib.call("cy_bilinear_fwd", x.data_ptr(), out.data_ptr(), N, H, W, Cc, size[0], size[1], dtype_code(x.dtype),
+              _stream())
+    return out

@@ -10,7 +10,9 @@ from contrastyou.hooks.base import CombineTrainerHook, TrainerHook
 from contrastyou.utils.utils import ntuple
 
 from .consistency import ConsistencyTrainerHook
+from .discretemi import DiscreteMITrainHook, decoder_names
 from .infonce import INFONCEHook
+from .midl import IIDSegmentationTrainerHook
 from .mt import MeanTeacherTrainerHook
 
 
@@ -61,3 +63,36 @@ def create_infonce_hooks(*, model: nn.Module, feature_names: Union[str, List[str
                            spatial_size=ss, global_negatives=global_negatives)
              for f, w, c, ss in zip(rep(feature_names), rep(weights), rep(contrast_ons), rep(spatial_size))]
     return CombineTrainerHook(*hooks)
+
+
+def create_discrete_mi_hooks(*, feature_names: List[str], weights: List[float], paddings: List[int],
+                             model: nn.Module):
+    """one DiscreteMITrainHook per feature; `paddings` lists the displacement radius of the DECODER
+    features only, in order (creator.py:56-67)"""
+    assert len(feature_names) == len(weights), (feature_names, weights)
+    decoder_features = [f for f in feature_names if f in decoder_names]
+    assert len(paddings) == len(decoder_features), (decoder_features, paddings)
+    pad_gen = iter(paddings)
+    paddings_ = [next(pad_gen) if f in decoder_features else None for f in feature_names]
+    hooks = [DiscreteMITrainHook(name=f"discreteMI/{f.lower()}", model=model, feature_name=f, weight=w, padding=p)
+             for f, w, p in zip(feature_names, weights, paddings_)]
+    return CombineTrainerHook(*hooks)
+
+
+def create_discrete_mi_consistency_hook(*, model: nn.Module, feature_names: Union[str, List[str]],
+                                        mi_weights: Union[float, List[float]], dense_paddings: List[int] = None,
+                                        consistency_weight: float):
+    """config/hooks/udaiic.yaml: IIC on feature maps + output consistency (creator.py:76-90)"""
+    n = 1 if isinstance(feature_names, str) else len(feature_names)
+    feature_names = ntuple(n)(feature_names)
+    mi_weights = ntuple(n)(mi_weights)
+    n_dense = len([f for f in feature_names if f in decoder_names])
+    dense_paddings = ntuple(n_dense)(dense_paddings) if n_dense else ()
+    mi = create_discrete_mi_hooks(feature_names=list(feature_names), weights=list(mi_weights),
+                                  paddings=list(dense_paddings), model=model)
+    return CombineTrainerHook(mi, create_consistency_hook(weight=consistency_weight))
+
+
+def create_iid_segmentation_hook(*, weight: float, mi_lambda: float = 1.0):
+    """config/hooks/iid.yaml: IIC between the two views' segmentation outputs"""
+    return IIDSegmentationTrainerHook(hook_name="midl_hook", weight=weight, mi_lambda=mi_lambda)

@@ -1,4 +1,6 @@
-"""InfoNCE regulariser on an encoder feature map (semi_seg/hooks/infonce.py:84-245).
+"""InfoNCE regulariser on an encoder feature map (semi_seg/hooks/infonce.py:84-245) and its dense
+variant on decoder feature maps (`_INFONCEDenseHook`, infonce.py:251-279; `region_extractor`,
+infonce.py:31-46).
 
 `INFONCEHook` (TrainerHook) owns the feature tap, the projection head and the SupCon criterion;
 once per epoch it hands out an `_INFONCEEpochHook` whose `_call_implementation`:
@@ -13,6 +15,7 @@ import typing as t
 from functools import partial
 from typing import List, Union
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -20,9 +23,30 @@ from contrastyou.arch.utils import SingleFeatureExtractor
 from contrastyou.hooks.base import EpocherHook, TrainerHook
 from contrastyou.losses.contrastive import SupConLoss1
 from contrastyou.meters import AverageValueMeter, MeterInterface
-from cyhip import parallel
+from contrastyou.utils.utils import fix_all_seed_for_transforms
+from cyhip import ops, parallel
+from cyhip.functions import GatherRowsFn
 
 from .utils import get_label
+
+
+def region_points(n: int, h: int, w: int, *, point_nums: int = 5, seed: int):
+    """the (row, col) samples of `region_extractor` for n maps of h x w: under the seeded RNGs, per
+    image `point_nums` distinct rows then `point_nums` distinct columns, zipped (infonce.py:39-46)"""
+    with fix_all_seed_for_transforms(seed):
+        return [list(zip((int(a) for a in np.random.choice(range(h), point_nums, replace=False)),
+                         (int(b) for b in np.random.choice(range(w), point_nums, replace=False))))
+                for _ in range(n)]
+
+
+def region_extractor(normalize_features: torch.Tensor, *, point_nums=5, seed: int) -> torch.Tensor:
+    """[n,D,h,w] -> [point_nums*n, D]: the sampled feature vectors, image-major (infonce.py:31-46);
+    one HIP row gather instead of 5n indexing kernels"""
+    n, d, h, w = normalize_features.shape
+    pts = region_points(n, h, w, point_nums=point_nums, seed=seed)
+    idx = np.asarray([(i * h + a) * w + b for i, im in enumerate(pts) for a, b in im], dtype=np.int32)
+    rows = normalize_features.permute(0, 2, 3, 1).reshape(n * h * w, d)
+    return GatherRowsFn.apply(rows, ops.pinned.upload(torch.from_numpy(idx), normalize_features.device))
 
 
 class INFONCEHook(TrainerHook):
@@ -47,17 +71,16 @@ class INFONCEHook(TrainerHook):
             assert (spatial_size is None) or (tuple(spatial_size) == (1, 1)), spatial_size
             spatial_size = (1, 1)
         else:
-            raise NotImplementedError("dense (decoder-feature) InfoNCE is the next scope row of this build "
-                                      "(SURVEY.md section 8f); encoder features only")
+            assert isinstance(spatial_size, t.Sequence) and isinstance(tuple(spatial_size)[0], int), spatial_size
         self._projector = self.init_projector(input_dim=input_dim, spatial_size=spatial_size)
         self._criterion = self.init_criterion()
         self._label_generator = partial(get_label, contrast_on=contrast_on, data_name=data_name)
 
     def __call__(self):
-        return _INFONCEEpochHook(name=self._hook_name, weight=self._weight, extractor=self._extractor,
-                                 projector=self._projector, criterion=self._criterion,
-                                 label_generator=self._label_generator,
-                                 global_negatives=self._global_negatives)
+        cls = _INFONCEEpochHook if self.is_encoder else _INFONCEDenseHook
+        return cls(name=self._hook_name, weight=self._weight, extractor=self._extractor,
+                   projector=self._projector, criterion=self._criterion, label_generator=self._label_generator,
+                   global_negatives=self._global_negatives)
 
     def init_criterion(self) -> SupConLoss1:
         self._criterion = SupConLoss1()
@@ -69,8 +92,8 @@ class INFONCEHook(TrainerHook):
 
     @property
     def projector_class(self):
-        from contrastyou.projectors.heads import ProjectionHead
-        return ProjectionHead
+        from contrastyou.projectors.heads import DenseProjectionHead, ProjectionHead
+        return ProjectionHead if self.is_encoder else DenseProjectionHead
 
     @property
     def is_encoder(self):
@@ -131,3 +154,29 @@ class _INFONCEEpochHook(EpocherHook):
         self._extractor.remove()
         self._criterion.validate()  # the reference's per-batch asserts, once per epoch
         self._criterion.defer_checks = False
+
+
+class _INFONCEDenseHook(_INFONCEEpochHook):
+    """InfoNCE between 5 sampled positions per image of the pooled, projected decoder feature maps
+    of the two views; every sampled vector is its own class (infonce.py:251-279).
+
+    The reference projects the full [2n,256,s,s] maps and then keeps 5 of the s*s positions; here
+    `DenseProjectionHead.project_points` evaluates exactly those bins (identical values -- the
+    samples depend on (seed, n, s) only), so the 1x1-conv MLP runs on ~1% of the pixels."""
+
+    def _call_implementation(self, *, affine_transformer, seed, unlabeled_tf_logits, unlabeled_logits_tf,
+                             partition_group, label_group, **kwargs):
+        n_unl = len(unlabeled_logits_tf)
+        feature_ = self._extractor.feature()[-n_unl * 2:]
+        unlabeled_features, unlabeled_tf_features = torch.chunk(feature_, 2, dim=0)
+        unlabeled_features_tf = affine_transformer(unlabeled_features, seed=seed)
+        sh, sw = self._projector._spatial_size
+        pts = region_points(n_unl, sh, sw, point_nums=5, seed=seed)  # same draw for both views (same seed)
+        rows = self._projector.project_points(torch.cat([unlabeled_features_tf, unlabeled_tf_features], dim=0),
+                                              pts + pts)
+        norm_features_tf_selected, norm_tf_features_selected = torch.chunk(rows, 2)
+        labels = list(range(norm_features_tf_selected.shape[0]))
+        loss = self._criterion(norm_features_tf_selected, norm_tf_features_selected, target=labels)
+        self.meters["loss"].add(loss.detach())
+        self._n += 1
+        return loss * self._weight

@@ -283,6 +283,95 @@ int cy_radam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float lr, float beta1, float beta2, float eps, float weight_decay, long step,
                   void* stream);
 
+/* ------------------------------------------------------------------------
+ * Dense (pixel-wise) contrastive projector
+ * (contrastyou/projectors/heads.py:31-41,99-123: Conv1x1(C,hid) -> LeakyReLU ->
+ * Conv1x1(hid,out) -> AdaptiveAvgPool2d((sh,sw)) -> L2 norm) and point
+ * sampling (semi_seg/hooks/infonce.py:31-46).
+ * The second 1x1 conv commutes with the average pool, so the fused kernel
+ * produces  hpool[bin][hid] = mean over the bin's pixels of
+ * lrelu(W1 x + b1)  straight from the NHWC feature map x [N][H][W] (pixel
+ * stride ldx, dtype); the [bins][hid] x [hid][out] product and the
+ * normalisation use cy_linear_* / cy_l2norm_*.
+ * bins: int32 [nb][3] = (image, bin row, bin col), distinct; NULL = all
+ * N*sh*sw bins in row-major order.  Bin extents follow torch's adaptive
+ * pooling: rows [floor(i*H/sh), ceil((i+1)*H/sh)).  Requires sh<=H, sw<=W.
+ * ------------------------------------------------------------------------ */
+int cy_dense_proj_fwd(const void* x, const float* w1, const float* b1, const int32_t* bins, int nb,
+                      float* hpool, int N, int H, int W, int C, int ldx, int hid, int sh, int sw,
+                      float slope, int dtype, void* stream);
+size_t cy_dense_proj_bwd_ws_bytes(int nb, int C, int hid);
+/* dx (dtype, NHWC, ldx) is ACCUMULATED into (zero it first; may be NULL);
+ * dw1 [hid][C], db1 [hid] f32, written or accumulated; hid <= 256. */
+int cy_dense_proj_bwd(const void* x, const float* w1, const float* b1, const int32_t* bins, int nb,
+                      const float* dhpool, void* dx, float* dw1, float* db1, int accumulate, int N,
+                      int H, int W, int C, int ldx, int hid, int sh, int sw, float slope, int dtype,
+                      void* ws, size_t ws_bytes, void* stream);
+/* nn.AdaptiveAvgPool2d((sh,sw)) on an NHWC map -> f32 [nb][C] (same bin list
+ * convention); backward for the all-bins case (gather form, deterministic). */
+int cy_adaptive_avgpool_fwd(const void* x, const int32_t* bins, int nb, float* out, int N, int H,
+                            int W, int C, int ldx, int sh, int sw, int dtype, void* stream);
+int cy_adaptive_avgpool_bwd(const float* dpool, void* dx, int N, int H, int W, int C, int ldx,
+                            int sh, int sw, int dtype, void* stream);
+/* out[m][:] = src[idx[m]][:] (f32 rows of length D); backward scatters rows
+ * (idx distinct). */
+int cy_gather_rows_fwd(const float* src, const int32_t* idx, float* out, int M, int D,
+                       void* stream);
+int cy_gather_rows_bwd(const float* dout, const int32_t* idx, float* dsrc, int M, int D,
+                       void* stream);
+
+/* ------------------------------------------------------------------------
+ * Cluster heads and discrete mutual-information losses
+ * (contrastyou/projectors/heads.py:44-78,125-173; contrastyou/losses/discreteMI.py:
+ * 90-170,201-261).  Probability maps are NHWC f32 [N][H][W][k], k <= 64.
+ * ------------------------------------------------------------------------ */
+/* logits [M][S*k] -> probs [S][M][k] = softmax(logits*invT) within each of the
+ * S sub-heads (SoftmaxWithT, projectors/nn.py:35-44); S=1 is a row softmax. */
+int cy_group_softmax_fwd(const float* logits, float* probs, long M, int S, int k, float invT,
+                         void* stream);
+int cy_group_softmax_bwd(const float* probs, const float* dprobs, float* dlogits, long M, int S,
+                         int k, float invT, void* stream);
+/* J[T*T][k][k], T = 2*pad+1:  J[(u,v)][i][j] = scale * sum_{n,a,b}
+ * x1[n][a+u-pad][b+v-pad][i] * x2[n][a][b][j] (zero outside the image);
+ * scale = 1/(N*H*W) if normalise else 1.  pad=0, normalise=1 is
+ * compute_joint_2D_with_padding_zeros; pad>0 is the F.conv2d of
+ * compute_joint_2D; H=W=1 gives compute_joint on [N][k] vectors. */
+size_t cy_joint_ws_bytes(int N, int H, int W, int k, int pad);
+int cy_joint_fwd(const float* x1, const float* x2, float* J, int N, int H, int W, int k, int pad,
+                 int normalise, void* ws, size_t ws_bytes, void* stream);
+/* dx1, dx2 (either may be NULL) = gscale[0] * adjoint of cy_joint_fwd applied to dJ */
+int cy_joint_bwd(const float* x1, const float* x2, const float* dJ, const float* gscale, float* dx1,
+                 float* dx2, int N, int H, int W, int k, int pad, int normalise, void* stream);
+/* loss on a joint.  mode 0: IIDSegmentationLoss padding 0; mode 1: padding>0
+ * (subtract min, +1e-8, per-displacement and global normalisation, loss/T^2);
+ * mode 2: IIDLoss on vectors (symmetrise if `symmetric`, normalise to 1).
+ * out2[0] = loss(lamda), out2[1] = loss(lamda=1); P (may be NULL) = the
+ * normalised joint; dJ (may be NULL) = dloss/dJ. */
+size_t cy_iid_loss_ws_bytes(int TT, int k);
+int cy_iid_loss(const float* J, float* out2, float* P, float* dJ, int TT, int k, int mode,
+                int symmetric, float lamda, float eps, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * UNet2.Block = Conv2d(3x3, bias) -> GroupNorm(G, C) -> SiLU
+ * (contrastyou/arch/unet2.py:208-224).  The conv runs on cy_conv3x3_* without
+ * bias; these kernels fold the bias into the normalisation:
+ * out = silu(gamma * ((y + bias) - mean_g) * rstd_g + beta), NHWC `dtype`.
+ * mean_rstd: f32 [N][G][2], written by fwd, read by bwd.
+ * ------------------------------------------------------------------------ */
+size_t cy_gn_ws_bytes(int N, int C);
+int cy_gn_silu_fwd(const void* y, int ldy, const float* bias, const float* gamma, const float* beta,
+                   void* out, int ldo, float* mean_rstd, int N, int HW, int C, int G, float eps,
+                   int dtype, void* ws, size_t ws_bytes, void* stream);
+/* du = dloss/d(conv output); dgamma, dbeta, dbias f32 [C] (NULL to skip). */
+int cy_gn_silu_bwd(const void* y, int ldy, const void* dz, int ldd, const float* bias,
+                   const float* gamma, const float* beta, const float* mean_rstd, void* du, int ldu,
+                   float* dgamma, float* dbeta, float* dbias, int accumulate, int N, int HW, int C,
+                   int G, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* F.interpolate(x, size=(h,w), mode="bilinear", align_corners=False) on an NHWC
+ * tensor (semi_seg/hooks/cc.py:132, ccblock.py:300). */
+int cy_bilinear_fwd(const void* x, void* out, int N, int H, int W, int C, int h, int w, int dtype,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,278 @@
+"""Parity of the SURVEY.md section-8 "next" rows on the GPU: dense InfoNCE projector + point
+sampling (a7, a8), cluster heads + discrete-MI losses (a17), GroupNorm+SiLU block (a18) and bilinear
+resize (a19).  Checked (through the C ABI via the module classes) against the vectors the reference
+itself produced (tests/golden/next_rows.npz) and against the oracle on larger seeded inputs.
+f32 tolerances are 1e-4 relative to the tensor's max magnitude unless stated; bf16 is stated per test."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+T = torch.from_numpy
+
+
+def cpu(t):
+    return t.detach().float().cpu()
+
+
+def close(a, b, rel=1e-4, what=""):
+    a = cpu(a).double()
+    b = (b.detach() if isinstance(b, torch.Tensor) else torch.as_tensor(b)).double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = b.abs().max().item() + 1e-30
+    err = (a - b).abs().max().item()
+    assert err <= rel * scale, f"{what}: max err {err:.3e} > {rel:.1e} * {scale:.3e}"
+
+
+def nhwc(t, dtype=None):
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(golden_dir / "next_rows.npz")
+
+
+# ------------------------------------------------------------------ a7: dense projection head
+def _dense_head(spatial=(4, 4), cin=16, hid=32, out=32, seed=4):
+    from contrastyou.projectors.heads import DenseProjectionHead
+    from oracle import losses as ol
+    head = DenseProjectionHead(input_dim=cin, hidden_dim=hid, output_dim=out, head_type="mlp", normalize=True,
+                               spatial_size=spatial)
+    head.load_state_dict(ol.init_dense_projector_sd(cin, hid, out, seed=seed), strict=True)
+    return head.to(DEV)
+
+
+def test_dense_projection_head_matches_reference_vectors(g):
+    head = _dense_head()
+    feat = nhwc(T(g["dp_feat"])).requires_grad_(True)
+    z = head(feat)
+    close(z, g["dp_z"], what="z")
+    coef = torch.linspace(-1, 1, z.numel()).view(z.shape).to(DEV)
+    (z * coef).sum().backward()
+    close(feat.grad, g["dp_dfeat"], 2e-4, "dfeat")
+    for n, p in head.named_parameters():
+        close(p.grad, g[f"dp_grad_{n}"], 2e-4, n)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+def test_dense_projector_points_equal_full_map_and_oracle(dtype, tol):
+    """224-style geometry in small: 45x45 map -> 8x8 bins (overlapping, ragged), C=32, hidden 256;
+    project_points(features, pts) == region_extractor(head(features)) in value and gradient, and
+    both match the oracle's conv -> conv -> pool -> normalise -> gather"""
+    from oracle import losses as ol
+    from oracle import next_rows as onr
+    from semi_seg.hooks.infonce import region_extractor, region_points
+    gen = torch.Generator().manual_seed(3)
+    n, c, hw, s = 4, 32, 45, 8
+    head = _dense_head((s, s), c, 256, 64, seed=5)
+    x = torch.randn(n, c, hw, hw, generator=gen)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    seed = 77
+    pts = region_points(n, s, s, point_nums=5, seed=seed)
+    assert pts == onr.region_points(n, s, s, seed)
+    coef = torch.linspace(-1, 1, n * 5 * 64).view(n * 5, 64)
+
+    xa = nhwc(x, dtype).requires_grad_(True)
+    rows = head.project_points(xa, pts)
+    (rows * coef.to(DEV)).sum().backward()
+    ga = {k: p.grad.clone() for k, p in head.named_parameters()}
+    head.zero_grad()
+
+    xb = nhwc(x, dtype).requires_grad_(True)
+    rows_full = region_extractor(head(xb), point_nums=5, seed=seed)
+    (rows_full * coef.to(DEV)).sum().backward()
+    close(rows, cpu(rows_full), 1e-5, "points vs full")
+    close(xa.grad, cpu(xb.grad), 1e-2 if dtype == torch.bfloat16 else 1e-5, "dx points vs full")
+    for k, p in head.named_parameters():
+        close(ga[k], cpu(p.grad), 1e-4, k)
+
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in head.state_dict().items()}
+    xo = x.clone().requires_grad_(True)
+    ro = onr.region_extractor(ol.dense_projection_head(sd, xo, (s, s)), seed)
+    (ro * coef).sum().backward()
+    close(rows, ro, tol, "rows vs oracle")
+    close(xa.grad, xo.grad, tol * 2, "dx vs oracle")
+    for k in sd:
+        close(ga[k], sd[k].grad, tol * 2, k)
+
+
+def test_dense_projector_multichunk_channels_and_linear_head():
+    """C = 64 (two staged channel chunks) with hidden 128; and the `linear` head (pool -> conv)"""
+    from contrastyou.projectors.heads import DenseProjectionHead
+    from oracle import losses as ol
+    gen = torch.Generator().manual_seed(9)
+    head = _dense_head((5, 3), 64, 128, 32, seed=6)
+    x = torch.randn(2, 64, 17, 12, generator=gen)
+    xa = nhwc(x).requires_grad_(True)
+    z = head(xa)
+    coef = torch.linspace(-1, 1, z.numel()).view(z.shape)
+    (z * coef.to(DEV)).sum().backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in head.state_dict().items()}
+    xo = x.clone().requires_grad_(True)
+    zo = ol.dense_projection_head(sd, xo, (5, 3))
+    (zo * coef).sum().backward()
+    close(z, zo, 1e-4, "z"), close(xa.grad, xo.grad, 2e-4, "dx")
+    for k, p in head.named_parameters():
+        close(p.grad, sd[k].grad, 2e-4, k)
+
+    lin = DenseProjectionHead(input_dim=16, output_dim=24, head_type="linear", normalize=True,
+                              spatial_size=(4, 4)).to(DEV)
+    x = torch.randn(2, 16, 13, 13, generator=gen)
+    xa = nhwc(x).requires_grad_(True)
+    z = lin(xa)
+    coef = torch.linspace(-1, 1, z.numel()).view(z.shape)
+    (z * coef.to(DEV)).sum().backward()
+    w, b = lin._projector[0].weight.detach().cpu(), lin._projector[0].bias.detach().cpu()
+    xo = x.clone().requires_grad_(True)
+    zo = torch.nn.functional.normalize(
+        torch.nn.functional.adaptive_avg_pool2d(torch.nn.functional.conv2d(xo, w, b), (4, 4)), dim=1)
+    (zo * coef).sum().backward()
+    close(z, zo, 1e-4, "linear z"), close(xa.grad, xo.grad, 2e-4, "linear dx")
+
+
+# ------------------------------------------------------------------ a17: cluster heads + MI losses
+def test_cluster_heads_match_reference_vectors(g):
+    from contrastyou.projectors.heads import ClusterHead, DenseClusterHead
+    from oracle import next_rows as onr
+    for dense, cls, tag in ((False, ClusterHead, "ch"), (True, DenseClusterHead, "dch")):
+        sds = onr.init_cluster_sds(16, 6, 3, dense, seed=9)
+        head = cls(input_dim=16, num_clusters=6, num_subheads=3, head_type="linear", T=1, normalize=False)
+        head.load_state_dict({f"_headers.{i}.{k}": v for i, sd in enumerate(sds) for k, v in sd.items()}, strict=True)
+        head = head.to(DEV)
+        probs = head(nhwc(T(g[f"{tag}_feat"])))
+        assert len(probs) == 3
+        for i, pr in enumerate(probs):
+            close(pr, g[f"{tag}_prob{i}"], 1e-5, f"{tag}{i}")
+
+
+def test_cluster_head_gradients_match_oracle():
+    from contrastyou.projectors.heads import DenseClusterHead
+    from oracle import next_rows as onr
+    gen = torch.Generator().manual_seed(12)
+    sds = onr.init_cluster_sds(32, 20, 5, True, seed=2)
+    head = DenseClusterHead(input_dim=32, num_clusters=20, num_subheads=5, head_type="linear", T=1, normalize=False)
+    head.load_state_dict({f"_headers.{i}.{k}": v for i, sd in enumerate(sds) for k, v in sd.items()}, strict=True)
+    head = head.to(DEV)
+    x = torch.randn(2, 32, 12, 10, generator=gen)
+    xa = nhwc(x).requires_grad_(True)
+    probs = head(xa)
+    coefs = [torch.randn(2, 20, 12, 10, generator=gen) for _ in range(5)]
+    sum((p * c.to(DEV)).sum() for p, c in zip(probs, coefs)).backward()
+    xo = x.clone().requires_grad_(True)
+    sdo = [{k: v.clone().requires_grad_(True) for k, v in sd.items()} for sd in sds]
+    po = onr.dense_cluster_head(sdo, xo)
+    sum((p * c).sum() for p, c in zip(po, coefs)).backward()
+    for p, q in zip(probs, po):
+        close(p, q, 1e-5, "prob")
+    close(xa.grad, xo.grad, 1e-4, "dx")
+    for i in range(5):
+        close(head._headers[i][0].weight.grad, sdo[i]["0.weight"].grad, 1e-4, f"dw{i}")
+        close(head._headers[i][0].bias.grad, sdo[i]["0.bias"].grad, 1e-4, f"db{i}")
+
+
+def test_iid_losses_match_reference_vectors(g):
+    from contrastyou.losses.discreteMI import IIDLoss, IIDSegmentationLoss, compute_joint
+    a = T(g["iid_a"]).to(DEV).requires_grad_(True)
+    b = T(g["iid_b"]).to(DEV).requires_grad_(True)
+    loss, loss0, pij = IIDLoss(lamb=1.5)(a, b)
+    close(loss, g["iid_loss"], 1e-5, "iid"), close(loss0, g["iid_loss_nolamb"], 1e-5, "iid nolamb")
+    close(pij, g["iid_joint"], 1e-5, "joint")
+    close(compute_joint(a.detach(), b.detach()), g["iid_joint"], 1e-5, "compute_joint")
+    loss.backward()
+    close(a.grad, g["iid_da"], 2e-4, "da"), close(b.grad, g["iid_db"], 2e-4, "db")
+    for pad in (0, 1, 2):
+        for sym in (False, True):
+            pa = nhwc(T(g["seg_a"])).requires_grad_(True)
+            pb = nhwc(T(g["seg_b"])).requires_grad_(True)
+            crit = IIDSegmentationLoss(lamda=1.2, padding=pad, symmetric=sym)
+            loss = crit(pa, pb)
+            t = f"seg_p{pad}_s{int(sym)}"
+            close(loss, g[f"{t}_loss"], 2e-5, t)
+            (loss * 3.0).backward()  # upstream scale must reach both inputs
+            close(pa.grad / 3.0, g[f"{t}_da"], 5e-4, t + " da")
+            close(pb.grad / 3.0, g[f"{t}_db"], 5e-4, t + " db")
+            assert crit.get_joint_matrix().shape == (5, 5)
+
+
+def test_joint_at_full_size_properties_and_oracle():
+    """the C2-sized joint (16 slices x 224 x 224, k = 20): against a CPU matmul, sums to one, and the
+    symmetric variant is symmetric; NCHW-strided inputs give the same result as NHWC ones"""
+    from contrastyou.losses.discreteMI import IIDSegmentationLoss, compute_joint_2D_with_padding_zeros
+    from oracle import next_rows as onr
+    gen = torch.Generator().manual_seed(1)
+    n, k, hw = 16, 20, 224
+    a = torch.randn(n, k, hw, hw, generator=gen).softmax(1)
+    b = (a + 0.5 * torch.randn(n, k, hw, hw, generator=gen)).softmax(1)
+    J = compute_joint_2D_with_padding_zeros(nhwc(a), nhwc(b), symmetric=False)
+    Jo = onr.joint_maps(a.double(), b.double(), 0, False)
+    close(J, Jo, 1e-5, "joint")
+    assert abs(float(J.sum()) - 1.0) < 1e-5
+    Js = compute_joint_2D_with_padding_zeros(a.to(DEV), b.to(DEV), symmetric=True)[0, 0]
+    assert torch.equal(Js, Js.t())
+    loss = IIDSegmentationLoss()(nhwc(a), nhwc(b))
+    close(loss, onr.iid_segmentation_loss(a.double(), b.double()), 1e-5, "loss")
+
+
+# ------------------------------------------------------------------ a18: GroupNorm + SiLU block
+def _block(cin, cout, seed, dtype=None):
+    from contrastyou.arch.unet2 import Block
+    from oracle import next_rows as onr
+    blk = Block(cin, cout, groups=8)
+    blk.load_state_dict(onr.init_gn_block(cin, cout, seed=seed), strict=True)
+    blk.compute_dtype = dtype
+    return blk.to(DEV)
+
+
+def test_gn_block_matches_reference_vectors(g):
+    blk = _block(16, 32, 13, torch.float32)
+    x = nhwc(T(g["gn_x"])).requires_grad_(True)
+    y = blk(x)
+    close(y, g["gn_y"], 1e-4, "y")
+    coef = torch.linspace(-1, 1, y.numel()).view(y.shape).to(DEV)
+    (y * coef).sum().backward()
+    close(x.grad, g["gn_dx"], 3e-4, "dx")
+    for n, p in blk.named_parameters():
+        close(p.grad, g[f"gn_grad_{n}"], 3e-4, n)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+def test_gn_block_larger_against_oracle(dtype, tol):
+    """UNet2's widest block shape in small: 64 -> 128 channels (16 channels per group), 3 x 28 x 28"""
+    from oracle import next_rows as onr
+    gen = torch.Generator().manual_seed(4)
+    blk = _block(64, 128, 21, dtype)
+    x = torch.randn(3, 64, 28, 28, generator=gen)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xa = nhwc(x, dtype).requires_grad_(True)
+    y = blk(xa)
+    coef = torch.randn(y.shape, generator=gen)
+    (y.float() * coef.to(DEV)).sum().backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    if dtype == torch.bfloat16:  # the conv consumes bf16-rounded weights
+        sd["proj.weight"] = sd["proj.weight"].detach().bfloat16().float().requires_grad_(True)
+    xo = x.clone().requires_grad_(True)
+    yo = onr.gn_silu_block(xo, sd["proj.weight"], sd["proj.bias"], sd["norm.weight"], sd["norm.bias"])
+    (yo * coef).sum().backward()
+    close(y, yo, tol, "y"), close(xa.grad, xo.grad, tol, "dx")
+    for k, p in blk.named_parameters():
+        close(p.grad, sd[k].grad, tol, k)
+
+
+# ------------------------------------------------------------------ a19: bilinear resize
+def test_bilinear_matches_reference_vectors(g):
+    from cyhip.functions import bilinear_resize
+    img = T(g["bl_img"]).to(DEV)
+    for hw in ((7, 7), (12, 10), (48, 40)):
+        close(bilinear_resize(img, hw), g[f"bl_{hw[0]}x{hw[1]}"], 1e-6, str(hw))
+    x = torch.rand(2, 8, 30, 22)
+    out = bilinear_resize(nhwc(x), (14, 14))
+    close(out, torch.nn.functional.interpolate(x, size=(14, 14), mode="bilinear"), 1e-6, "multi-channel")
+    with pytest.raises(RuntimeError):
+        bilinear_resize(img.clone().requires_grad_(True), (7, 7))
