@@ -7,6 +7,11 @@ nn.Parameter is a view into it) and all their gradients in another, so that
     (35 MB for the U-Net) instead of one per tensor,
   * an EMA teacher update is one kernel too (semi_seg.hooks.mt).
 Semantics follow torch.optim.RAdam (decoupled_weight_decay=False): see csrc/cy_misc.hip.
+Like torch's optimizer, a parameter that received no gradient since the last zero_grad() is
+skipped (no weight decay, no moment update, its step count does not advance) -- e.g. the decoder
+during encoder pre-training.  "Received a gradient" is tracked per parameter (autograd's
+post-accumulate hook, or the kernels' direct accumulation through ops.grad_sink); the step is one
+kernel launch per run of consecutive updated parameters with the same step count (normally one).
 """
 from __future__ import annotations
 
@@ -18,6 +23,10 @@ from torch import nn
 
 from cyhip import ops
 from cyhip.functions import bump_weights_epoch
+
+
+def _mark_touched(p):
+    p.__dict__["_cy_touched"] = True
 
 
 class FlatParams:
@@ -38,11 +47,29 @@ class FlatParams:
             self.data[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.data[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
+            p.register_post_accumulate_grad_hook(_mark_touched)
             off += n
         self.numel = total
+        self.offsets = [0]
+        for p in params:
+            self.offsets.append(self.offsets[-1] + p.numel())
+
+    def stale(self) -> bool:
+        """a parameter was moved / re-pointed (e.g. module.to(device)) after flattening"""
+        lo, hi = self.data.data_ptr(), self.data.data_ptr() + 4 * self.numel
+        return any(p.device != self.data.device or not (lo <= p.data_ptr() < hi or p.numel() == 0)
+                   for p in self.params)
+
+    def touched(self) -> List[bool]:
+        return [bool(p.__dict__.get("_cy_touched", False)) for p in self.params]
+
+    def clear_touched(self):
+        for p in self.params:
+            p.__dict__["_cy_touched"] = False
 
     def zero_grad(self):
         self.grad.zero_()
+        self.clear_touched()
         off = 0
         for p in self.params:  # re-attach views someone may have dropped (set_to_none)
             n = p.numel()
@@ -70,16 +97,32 @@ class FusedRAdam(torch.optim.Optimizer):
             self._flat.append(None)
 
     def _ensure_flat(self):
+        """(re)build the flat buffers lazily: at the first zero_grad()/step(), and again if the
+        parameters were moved to another device afterwards (moments follow them)"""
         for i, g in enumerate(self.param_groups):
-            if self._flat[i] is None:
-                fp = FlatParams(list(g["params"]))
-                self._flat[i] = fp
-                self._flat_state[i] = dict(step=0, exp_avg=torch.zeros_like(fp.data),
-                                           exp_avg_sq=torch.zeros_like(fp.data))
+            old = self._flat[i]
+            if old is not None and not old.stale():
+                continue
+            fp = FlatParams(list(g["params"]))
+            self._flat[i] = fp
+            st = self._flat_state.get(i)
+            if st is None:
+                st = dict(step=0, steps=[0] * len(fp.params), exp_avg=torch.zeros_like(fp.data),
+                          exp_avg_sq=torch.zeros_like(fp.data))
+            else:
+                st["exp_avg"] = st["exp_avg"].to(fp.data.device)
+                st["exp_avg_sq"] = st["exp_avg_sq"].to(fp.data.device)
+            self._flat_state[i] = st
+        pending, self._pending = getattr(self, "_pending", None), None
+        if pending is not None:
+            self._apply_state(pending)
         bump_weights_epoch()
 
+    def _needs_flat(self) -> bool:
+        return any(f is None or f.stale() for f in self._flat)
+
     def zero_grad(self, set_to_none: bool = False):
-        if any(f is None for f in self._flat):
+        if self._needs_flat():
             self._ensure_flat()
         for f in self._flat:
             f.zero_grad()
@@ -97,17 +140,28 @@ class FusedRAdam(torch.optim.Optimizer):
                 f.grad.div_(world)
 
     def state_dict(self):
-        """{"param_groups": [...], "flat": {group: {step, exp_avg, exp_avg_sq}}}"""
+        """{"param_groups": [...], "flat": {group: {step, steps, exp_avg, exp_avg_sq}}}"""
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        pending = getattr(self, "_pending", None)
+        if pending is not None:  # loaded but not stepped yet: hand the loaded moments back
+            return {"param_groups": groups, "flat": pending["flat"]}
         return {"param_groups": groups, "flat": {i: dict(st) for i, st in self._flat_state.items()}}
 
     def load_state_dict(self, state):
-        self._ensure_flat()
+        """hyper-parameters apply at once; the moments are copied when the flat buffers exist on the
+        parameters' final device (a Trainer loads checkpoints before `.to(device)`)"""
         for g, sg in zip(self.param_groups, state["param_groups"]):
             g.update(sg)
+        self._pending = state
+        if not self._needs_flat():
+            self._pending = None
+            self._apply_state(state)
+
+    def _apply_state(self, state):
         for i, st in state["flat"].items():
             mine = self._flat_state[int(i)]
             mine["step"] = int(st["step"])
+            mine["steps"] = [int(v) for v in st.get("steps", [int(st["step"])] * len(mine["steps"]))]
             mine["exp_avg"].copy_(st["exp_avg"])
             mine["exp_avg_sq"].copy_(st["exp_avg_sq"])
 
@@ -117,13 +171,26 @@ class FusedRAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if any(f is None for f in self._flat):
+        if self._needs_flat():
             self._ensure_flat()
         self.all_reduce_grads()
         for i, g in enumerate(self.param_groups):
             f, st = self._flat[i], self._flat_state[i]
             st["step"] += 1
-            ops.radam_step(f.data, f.grad, st["exp_avg"], st["exp_avg_sq"], g["lr"], g["betas"][0], g["betas"][1],
-                           g["eps"], g["weight_decay"], st["step"])
+            steps, touched = st["steps"], f.touched()
+            j, n = 0, len(steps)
+            while j < n:  # runs of consecutive updated parameters that share a step count
+                if not touched[j]:
+                    j += 1
+                    continue
+                e = j
+                while e + 1 < n and touched[e + 1] and steps[e + 1] == steps[j]:
+                    e += 1
+                a, b = f.offsets[j], f.offsets[e + 1]
+                ops.radam_step(f.data[a:b], f.grad[a:b], st["exp_avg"][a:b], st["exp_avg_sq"][a:b], g["lr"],
+                               g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], steps[j] + 1)
+                for q in range(j, e + 1):
+                    steps[q] += 1
+                j = e + 1
         bump_weights_epoch()
         return loss

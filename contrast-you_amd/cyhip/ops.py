@@ -197,6 +197,7 @@ def grad_sink(p: Tensor) -> Optional[Tensor]:
     """p.grad when the kernels can accumulate straight into it (f32, contiguous, on the GPU)"""
     g = p.grad
     if g is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous():
+        p.__dict__["_cy_touched"] = True  # read by FusedRAdam: this parameter received a gradient
         return g
     return None
 
