@@ -137,7 +137,9 @@ __global__ void __launch_bounds__(256)
 //   g[p][o] = dhpool[bin][o]/|bin| * lrelu'(pre[p][o]),
 // accumulates dW1[o][cb..cb+32) and db1[o] in registers across all bins of the block, and the
 // block reduces dx[p][c] = sum_o g[p][o] W1[o][c] through LDS.
-template <typename T>
+// Two instantiations keep the live register set small: DW = true produces dW1/db1 partials,
+// DW = false produces dx (each recomputes the cheap pre-activations).
+template <typename T, bool DW>
 __global__ void __launch_bounds__(256)
     dense_proj_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w1,
                           const float* __restrict__ b1, const int32_t* __restrict__ bins, int nb,
@@ -145,8 +147,8 @@ __global__ void __launch_bounds__(256)
                           float* __restrict__ part, int H, int W, int C, int ldx, int hid, int sh,
                           int sw, float slope, int colour) {
   __shared__ __attribute__((aligned(16))) float xs[DP_PT * DP_CB];
-  __shared__ float gs[DP_PT * 256];
-  __shared__ float ps[DP_PT * 8 * 32];
+  __shared__ __attribute__((aligned(16))) float gs[DW ? 4 : DP_PT * 256];
+  __shared__ float ps[DW ? 4 : DP_PT * 8 * 32];
   const int tid = threadIdx.x;
   const int o = tid;
   const bool ov = o < hid;
@@ -158,19 +160,21 @@ __global__ void __launch_bounds__(256)
   if (single) load_wrow(w1, o, ov, 0, C, wreg);
 
   for (int cb = 0; cb < C; cb += DP_CB) {
-    float dwacc[DP_CB];
+    float dwacc[DW ? DP_CB : 1];
 #pragma unroll
-    for (int c = 0; c < DP_CB; ++c) dwacc[c] = 0.f;
+    for (int c = 0; c < (DW ? DP_CB : 1); ++c) dwacc[c] = 0.f;
     float dbacc = 0.f;
-    float wcol[32];  // W1[og*32 + i][cb + cl]
+    float wcol[DW ? 1 : 32];  // W1[og*32 + i][cb + cl]
+    if constexpr (!DW) {
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int oo = og * 32 + i;
-      wcol[i] = (oo < hid && cb + cl < C) ? w1[(size_t)oo * C + cb + cl] : 0.f;
+      for (int i = 0; i < 32; ++i) {
+        const int oo = og * 32 + i;
+        wcol[i] = (oo < hid && cb + cl < C) ? w1[(size_t)oo * C + cb + cl] : 0.f;
+      }
     }
     for (int b = blockIdx.x; b < nb; b += gridDim.x) {
       const BinRect R = bin_rect(bins, b, sh, sw, H, W);
-      if (R.colour != colour) continue;  // uniform over the block
+      if (colour >= 0 && R.colour != colour) continue;  // uniform over the block
       const int bw = R.c1 - R.c0, npx = (R.r1 - R.r0) * bw;
       const float gb = ov ? dhpool[(size_t)b * hid + o] / (float)npx : 0.f;
       for (int pt0 = 0; pt0 < npx; pt0 += DP_PT) {
@@ -184,44 +188,51 @@ __global__ void __launch_bounds__(256)
           __syncthreads();
           fma_tile(xs, wreg, acc);
         }
-        if (!single) {  // bring channel block cb back for the dW products
+        if (DW && !single) {  // bring channel block cb back for the dW products
           __syncthreads();
           stage_pixels<T>(x, ldx, R, bw, npx, H, W, pt0, cb, C, xs, tid);
           __syncthreads();
         }
-        float g[DP_PT];
+        // g overwrites the pre-activations (one live register tile)
 #pragma unroll
         for (int p = 0; p < DP_PT; ++p) {
-          g[p] = (pt0 + p < npx) ? gb * (acc[p] > 0.f ? 1.f : slope) : 0.f;
-          gs[p * 256 + tid] = g[p];
+          acc[p] = (pt0 + p < npx) ? gb * (acc[p] > 0.f ? 1.f : slope) : 0.f;
+          if constexpr (!DW) gs[p * 256 + tid] = acc[p];
         }
-        if (cb == 0) {
+        if constexpr (DW) {
+          if (cb == 0) {
 #pragma unroll
-          for (int p = 0; p < DP_PT; ++p) dbacc += g[p];
-        }
-#pragma unroll
-        for (int p = 0; p < DP_PT; ++p) {
-#pragma unroll
-          for (int c4 = 0; c4 < DP_CB / 4; ++c4) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + p * DP_CB + c4 * 4);
-            dwacc[4 * c4] = fmaf(g[p], xv[0], dwacc[4 * c4]);
-            dwacc[4 * c4 + 1] = fmaf(g[p], xv[1], dwacc[4 * c4 + 1]);
-            dwacc[4 * c4 + 2] = fmaf(g[p], xv[2], dwacc[4 * c4 + 2]);
-            dwacc[4 * c4 + 3] = fmaf(g[p], xv[3], dwacc[4 * c4 + 3]);
-          }
-        }
-        __syncthreads();
-        if (dx) {
-          float pp[DP_PT];
-#pragma unroll
-          for (int p = 0; p < DP_PT; ++p) pp[p] = 0.f;
-#pragma unroll
-          for (int i = 0; i < 32; ++i) {
-#pragma unroll
-            for (int p = 0; p < DP_PT; ++p) pp[p] = fmaf(gs[p * 256 + og * 32 + i], wcol[i], pp[p]);
+            for (int p = 0; p < DP_PT; ++p) dbacc += acc[p];
           }
 #pragma unroll
-          for (int p = 0; p < DP_PT; ++p) ps[(p * 8 + og) * 32 + cl] = pp[p];
+          for (int p = 0; p < DP_PT; ++p) {
+#pragma unroll
+            for (int c4 = 0; c4 < DP_CB / 4; ++c4) {
+              const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + p * DP_CB + c4 * 4);
+              dwacc[4 * c4] = fmaf(acc[p], xv[0], dwacc[4 * c4]);
+              dwacc[4 * c4 + 1] = fmaf(acc[p], xv[1], dwacc[4 * c4 + 1]);
+              dwacc[4 * c4 + 2] = fmaf(acc[p], xv[2], dwacc[4 * c4 + 2]);
+              dwacc[4 * c4 + 3] = fmaf(acc[p], xv[3], dwacc[4 * c4 + 3]);
+            }
+          }
+        } else {
+          __syncthreads();
+          // partial over this thread's 32 hidden units, for channel cb+cl, of every pixel of the tile
+#pragma unroll
+          for (int p = 0; p < DP_PT; ++p) acc[p] = 0.f;
+#pragma unroll
+          for (int i4 = 0; i4 < 8; ++i4) {
+#pragma unroll
+            for (int p = 0; p < DP_PT; ++p) {
+              const f32x4 gv = *reinterpret_cast<const f32x4*>(gs + p * 256 + og * 32 + i4 * 4);
+              acc[p] = fmaf(gv[0], wcol[4 * i4], acc[p]);
+              acc[p] = fmaf(gv[1], wcol[4 * i4 + 1], acc[p]);
+              acc[p] = fmaf(gv[2], wcol[4 * i4 + 2], acc[p]);
+              acc[p] = fmaf(gv[3], wcol[4 * i4 + 3], acc[p]);
+            }
+          }
+#pragma unroll
+          for (int p = 0; p < DP_PT; ++p) ps[(p * 8 + og) * 32 + cl] = acc[p];
           __syncthreads();
 #pragma unroll
           for (int pr = 0; pr < DP_PT; pr += 8) {
@@ -237,11 +248,13 @@ __global__ void __launch_bounds__(256)
         }
       }
     }
-    if (ov) {
+    if constexpr (DW) {
+      if (ov) {
 #pragma unroll
-      for (int c = 0; c < DP_CB; ++c)
-        if (cb + c < C) mypart[(size_t)o * C + cb + c] = dwacc[c];
-      if (cb == 0) mypart[(size_t)hid * C + o] = dbacc;
+        for (int c = 0; c < DP_CB; ++c)
+          if (cb + c < C) mypart[(size_t)o * C + cb + c] = dwacc[c];
+        if (cb == 0) mypart[(size_t)hid * C + o] = dbacc;
+      }
     }
   }
 }
@@ -351,7 +364,7 @@ int cy_dense_proj_fwd(const void* x, const float* w1, const float* b1, const int
 }
 
 size_t cy_dense_proj_bwd_ws_bytes(int nb, int C, int hid) {
-  return (size_t)4 * dp_bwd_blocks(nb) * ((size_t)hid * C + hid) * sizeof(float);
+  return (size_t)dp_bwd_blocks(nb) * ((size_t)hid * C + hid) * sizeof(float);
 }
 
 int cy_dense_proj_bwd(const void* x, const float* w1, const float* b1, const int32_t* bins, int nb,
@@ -368,21 +381,32 @@ int cy_dense_proj_bwd(const void* x, const float* w1, const float* b1, const int
   hipStream_t st = (hipStream_t)stream;
   const int G = dp_bwd_blocks(nb);
   const size_t slot = (size_t)hid * C + hid;
-  for (int colour = 0; colour < 4; ++colour) {
-    float* part = (float*)ws + (size_t)colour * G * slot;
+  // dW1/db1: one launch over all bins (no pixel is written); dx: one launch per colour class
+  if (dw1 || db1) {
     if (dtype == CY_BF16)
-      hipLaunchKernelGGL(dense_proj_bwd_kernel<bf16>, dim3(G), dim3(256), 0, st, (const bf16*)x, w1,
-                         b1, bins, nb, dhpool, (bf16*)dx, part, H, W, C, ldx, hid, sh, sw, slope,
-                         colour);
+      hipLaunchKernelGGL((dense_proj_bwd_kernel<bf16, true>), dim3(G), dim3(256), 0, st, (const bf16*)x,
+                         w1, b1, bins, nb, dhpool, (bf16*)nullptr, (float*)ws, H, W, C, ldx, hid, sh, sw,
+                         slope, -1);
     else
-      hipLaunchKernelGGL(dense_proj_bwd_kernel<float>, dim3(G), dim3(256), 0, st, (const float*)x,
-                         w1, b1, bins, nb, dhpool, (float*)dx, part, H, W, C, ldx, hid, sh, sw,
-                         slope, colour);
+      hipLaunchKernelGGL((dense_proj_bwd_kernel<float, true>), dim3(G), dim3(256), 0, st,
+                         (const float*)x, w1, b1, bins, nb, dhpool, (float*)nullptr, (float*)ws, H, W, C,
+                         ldx, hid, sh, sw, slope, -1);
+    CY_CHECK_LAUNCH();
+  }
+  for (int colour = 0; dx && colour < 4; ++colour) {
+    if (dtype == CY_BF16)
+      hipLaunchKernelGGL((dense_proj_bwd_kernel<bf16, false>), dim3(G), dim3(256), 0, st,
+                         (const bf16*)x, w1, b1, bins, nb, dhpool, (bf16*)dx, (float*)ws, H, W, C, ldx,
+                         hid, sh, sw, slope, colour);
+    else
+      hipLaunchKernelGGL((dense_proj_bwd_kernel<float, false>), dim3(G), dim3(256), 0, st,
+                         (const float*)x, w1, b1, bins, nb, dhpool, (float*)dx, (float*)ws, H, W, C, ldx,
+                         hid, sh, sw, slope, colour);
     CY_CHECK_LAUNCH();
   }
   if (dw1 || db1) {
     hipLaunchKernelGGL(slot_reduce_kernel, dim3(cy_cdiv((long)slot, 256)), dim3(256), 0, st,
-                       (const float*)ws, dw1, db1, 4 * G, hid * C, hid, accumulate);
+                       (const float*)ws, dw1, db1, G, hid * C, hid, accumulate);
     CY_CHECK_LAUNCH();
   }
   return CY_OK;

@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256)
     head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                     const float* __restrict__ b, float* __restrict__ logits, long npix, int C,
                     int K) {
-  extern __shared__ float sw[];  // [K][C] + [K]
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [K][C] + [K]
   for (int i = threadIdx.x; i < K * C; i += 256) sw[i] = w[i];
   for (int i = threadIdx.x; i < K; i += 256) sw[K * C + i] = b ? b[i] : 0.f;
   __syncthreads();
@@ -49,9 +49,13 @@ __global__ void __launch_bounds__(256)
       load8h<T>(x + p * C + c0, f);
 #pragma unroll
       for (int k = 0; k < KM; ++k) {
-        if (k < K) {
+        if (k < K) {  // weights as two 16-byte LDS broadcasts per 8 FMAs
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(sw + k * C + c0);
+          const f32x4 wb = *reinterpret_cast<const f32x4*>(sw + k * C + c0 + 4);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[k] = fmaf(f[j], sw[k * C + c0 + j], acc[k]);
+          for (int j = 0; j < 4; ++j) acc[k] = fmaf(f[j], wa[j], acc[k]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[k] = fmaf(f[4 + j], wb[j], acc[k]);
         }
       }
     }
@@ -86,8 +90,46 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// partial dW[k][c], db[k] per block:  ws[block][K*C + K]
+// wide-K variant (stacked cluster heads): one thread per (pixel, 32-channel group) reads its
+// dl row as 16-byte vectors (contiguous per thread) instead of K scalar loads shared by 4 lanes
 template <typename T>
+__global__ void __launch_bounds__(256)
+    head_bwd_dx_wide_kernel(const float* __restrict__ dl, const float* __restrict__ w,
+                            T* __restrict__ dx, long npix, int C, int K) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [K][C]
+  for (int i = threadIdx.x; i < K * C; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const int G = C / 32;
+  const long total = npix * G;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const int g = (int)(e % G);
+    const long p = e / G;
+    float o[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) o[j] = 0.f;
+    const float* dp = dl + p * K;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(dp + k0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float* wr = sw + (k0 + kk) * C + g * 32;
+#pragma unroll
+        for (int j4 = 0; j4 < 8; ++j4) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + 4 * j4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[4 * j4 + j] = fmaf(d4[kk], wv[j], o[4 * j4 + j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j8 = 0; j8 < 4; ++j8) store8h<T>(dx + p * C + g * 32 + j8 * 8, o + 8 * j8);
+  }
+}
+
+// partial dW[k][c], db[k] per block:  ws[block][K*C + K]
+// KG output channels are accumulated per pass over the pixels (x and dl are re-read K/KG times):
+// 4 for the few segmentation classes, 16 for the 100 stacked cluster-head outputs.
+template <typename T, int KG>
 __global__ void __launch_bounds__(256)
     head_bwd_dw_kernel(const T* __restrict__ x, const float* __restrict__ dl,
                        float* __restrict__ ws, long npix, int C, int K) {
@@ -102,10 +144,10 @@ __global__ void __launch_bounds__(256)
   const long p0 = (long)blockIdx.x * per;
   const long p1 = p0 + per < npix ? p0 + per : npix;
   float* wsb = ws + (size_t)blockIdx.x * (K * C + K);
-  for (int k0 = 0; k0 < K; k0 += 4) {  // 4 classes at a time: 32 accumulators
-    float acc[4][8], accb[4];
+  for (int k0 = 0; k0 < K; k0 += KG) {
+    float acc[KG][8], accb[KG];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < KG; ++k) {
       accb[k] = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
@@ -114,44 +156,54 @@ __global__ void __launch_bounds__(256)
       for (long p = p0 + prow; p < p1; p += rows) {
         float f[8];
         load8h<T>(x + p * C + g * 8, f);
+        float d[KG];
+        if (k0 + KG <= K && (K & 3) == 0) {  // whole group in range: 16-byte loads of the dl row
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (k0 + k < K) {
-            const float d = dl[p * K + k0 + k];
-            accb[k] += d;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[k][j] = fmaf(d, f[j], acc[k][j]);
+          for (int k4 = 0; k4 < KG / 4; ++k4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dl + p * K + k0 + 4 * k4);
+            d[4 * k4] = v[0], d[4 * k4 + 1] = v[1], d[4 * k4 + 2] = v[2], d[4 * k4 + 3] = v[3];
           }
+        } else {
+#pragma unroll
+          for (int k = 0; k < KG; ++k) d[k] = (k0 + k < K) ? dl[p * K + k0 + k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < KG; ++k) {
+          accb[k] += d[k];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[k][j] = fmaf(d[k], f[j], acc[k][j]);
         }
       }
     }
-    __syncthreads();
-    if (active) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+    for (int kb = 0; kb < KG; kb += 4) {  // block reduction over the pixel rows, 4 outputs at a time
+      __syncthreads();
+      if (active) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sred[((prow * gpp + g) * 4 + k) * 8 + j] = acc[k][j];
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sred[((prow * gpp + g) * 4 + k) * 8 + j] = acc[kb + k][j];
+        }
+        if (g == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) sred[rows * gpp * 32 + prow * 4 + k] = accb[kb + k];
+        }
       }
-      if (g == 0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sred[rows * gpp * 32 + prow * 4 + k] = accb[k];
+      __syncthreads();
+      for (int e = tid; e < 4 * gpp * 8; e += 256) {
+        const int k = e / (gpp * 8), cl = e % (gpp * 8);
+        const int gg = cl / 8, j = cl % 8;
+        if (k0 + kb + k < K && cl < C) {
+          float s = 0.f;
+          for (int q = 0; q < rows; ++q) s += sred[((q * gpp + gg) * 4 + k) * 8 + j];
+          wsb[(k0 + kb + k) * C + cl] = s;
+        }
       }
-    }
-    __syncthreads();
-    // reduce over rows: outputs (k, c) for this k-group
-    for (int e = tid; e < 4 * gpp * 8; e += 256) {
-      const int k = e / (gpp * 8), cl = e % (gpp * 8);
-      const int gg = cl / 8, j = cl % 8;
-      if (k0 + k < K && cl < C) {
+      if (tid < 4 && k0 + kb + tid < K) {
         float s = 0.f;
-        for (int q = 0; q < rows; ++q) s += sred[((q * gpp + gg) * 4 + k) * 8 + j];
-        wsb[(k0 + k) * C + cl] = s;
+        for (int q = 0; q < rows; ++q) s += sred[rows * gpp * 32 + q * 4 + tid];
+        wsb[K * C + k0 + kb + tid] = s;
       }
-    }
-    if (tid < 4 && k0 + tid < K) {
-      float s = 0.f;
-      for (int q = 0; q < rows; ++q) s += sred[rows * gpp * 32 + q * 4 + tid];
-      wsb[K * C + k0 + tid] = s;
     }
   }
 }
@@ -419,7 +471,16 @@ int cy_head1x1_bwd(const void* x, const float* w, const float* dlogits, void* dx
     long b = (total + 255) / 256;
     if (b > 4096) b = 4096;
     const size_t smem = (size_t)K * C * sizeof(float);
-    if (x_dtype == CY_BF16)
+    if (K > KMAX && K % 4 == 0 && C % 32 == 0) {
+      long bw = (npix * (C / 32) + 255) / 256;
+      if (bw > 8192) bw = 8192;
+      if (x_dtype == CY_BF16)
+        hipLaunchKernelGGL(head_bwd_dx_wide_kernel<bf16>, dim3((int)bw), dim3(256), smem, st, dlogits,
+                           w, (bf16*)dx, npix, C, K);
+      else
+        hipLaunchKernelGGL(head_bwd_dx_wide_kernel<float>, dim3((int)bw), dim3(256), smem, st, dlogits,
+                           w, (float*)dx, npix, C, K);
+    } else if (x_dtype == CY_BF16)
       hipLaunchKernelGGL(head_bwd_dx_kernel<bf16>, dim3((int)b), dim3(256), smem, st, dlogits, w,
                          (bf16*)dx, npix, C, K);
     else
@@ -435,12 +496,22 @@ int cy_head1x1_bwd(const void* x, const float* w, const float* dlogits, void* dx
     if (G > 256) return CY_ERR_SHAPE;
     const int rows = 256 / gpp;
     const size_t smem = (size_t)(rows * gpp * 32 + rows * 4) * sizeof(float);
-    if (x_dtype == CY_BF16)
-      hipLaunchKernelGGL(head_bwd_dw_kernel<bf16>, dim3(nblk), dim3(256), smem, st, (const bf16*)x,
-                         dlogits, (float*)ws, npix, C, K);
-    else
-      hipLaunchKernelGGL(head_bwd_dw_kernel<float>, dim3(nblk), dim3(256), smem, st,
-                         (const float*)x, dlogits, (float*)ws, npix, C, K);
+    const bool h = x_dtype == CY_BF16;
+    if (K <= KMAX) {
+      if (h)
+        hipLaunchKernelGGL((head_bwd_dw_kernel<bf16, 4>), dim3(nblk), dim3(256), smem, st,
+                           (const bf16*)x, dlogits, (float*)ws, npix, C, K);
+      else
+        hipLaunchKernelGGL((head_bwd_dw_kernel<float, 4>), dim3(nblk), dim3(256), smem, st,
+                           (const float*)x, dlogits, (float*)ws, npix, C, K);
+    } else {
+      if (h)
+        hipLaunchKernelGGL((head_bwd_dw_kernel<bf16, 16>), dim3(nblk), dim3(256), smem, st,
+                           (const bf16*)x, dlogits, (float*)ws, npix, C, K);
+      else
+        hipLaunchKernelGGL((head_bwd_dw_kernel<float, 16>), dim3(nblk), dim3(256), smem, st,
+                           (const float*)x, dlogits, (float*)ws, npix, C, K);
+    }
     CY_CHECK_LAUNCH();
     hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3(cy_cdiv(K * C + K, 256)), dim3(256), 0, st,
                        (const float*)ws, dw, db, nblk, K * C, K);

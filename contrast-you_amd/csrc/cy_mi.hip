@@ -24,22 +24,38 @@ inline int grid_for(long n) {
 }
 
 // ---------------------------------------------------------------- grouped softmax
-// in  [M][S*k] logits  ->  out [S][M][k] probabilities of softmax(logits * invT) per group
+// in  [M][S*k] logits  ->  out [S][M][k] probabilities of softmax(logits * invT) per group.
+// A block owns GS_PB consecutive rows: the [GS_PB][S*k] logit tile is one contiguous span of
+// memory and each [GS_PB][k] output tile is another, so all global traffic is coalesced; the
+// (row, group) -> thread transposition happens in LDS (row pitch S*k+1: conflict-free).
+constexpr int GS_PB = 64;
+
 __global__ void __launch_bounds__(256)
     group_softmax_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, long M, int S,
                              int k, float invT) {
-  const long total = M * S;
-  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
-    const int s = (int)(e % S);
-    const long m = e / S;
-    const float* src = in + m * (long)(S * k) + (long)s * k;
+  extern __shared__ float tile[];  // [GS_PB][S*k + 1]
+  const int SK = S * k, pitch = SK + 1;
+  const long m0 = (long)blockIdx.x * GS_PB;
+  const int rows = (int)min((long)GS_PB, M - m0);
+  const float* src = in + m0 * SK;
+  for (int e = threadIdx.x; e < rows * SK; e += 256) tile[(e / SK) * pitch + e % SK] = src[e] * invT;
+  __syncthreads();
+  for (int e = threadIdx.x; e < rows * S; e += 256) {
+    float* v = tile + (e % rows) * pitch + (e / rows) * k;
     float mx = -INFINITY;
-    for (int i = 0; i < k; ++i) mx = fmaxf(mx, src[i] * invT);
+    for (int i = 0; i < k; ++i) mx = fmaxf(mx, v[i]);
     float sum = 0.f;
-    for (int i = 0; i < k; ++i) sum += __expf(src[i] * invT - mx);
+    for (int i = 0; i < k; ++i) {
+      v[i] = __expf(v[i] - mx);
+      sum += v[i];
+    }
     const float r = 1.f / sum;
-    float* dst = out + ((long)s * M + m) * k;
-    for (int i = 0; i < k; ++i) dst[i] = __expf(src[i] * invT - mx) * r;
+    for (int i = 0; i < k; ++i) v[i] *= r;
+  }
+  __syncthreads();
+  for (int s = 0; s < S; ++s) {
+    float* dst = out + ((long)s * M + m0) * k;
+    for (int e = threadIdx.x; e < rows * k; e += 256) dst[e] = tile[(e / k) * pitch + s * k + e % k];
   }
 }
 
@@ -47,17 +63,30 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     group_softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
                              float* __restrict__ dlogits, long M, int S, int k, float invT) {
-  const long total = M * S;
-  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
-    const int s = (int)(e % S);
-    const long m = e / S;
-    const float* pp = p + ((long)s * M + m) * k;
-    const float* dd = dp + ((long)s * M + m) * k;
-    float dot = 0.f;
-    for (int i = 0; i < k; ++i) dot = fmaf(pp[i], dd[i], dot);
-    float* dst = dlogits + m * (long)(S * k) + (long)s * k;
-    for (int i = 0; i < k; ++i) dst[i] = invT * pp[i] * (dd[i] - dot);
+  extern __shared__ float tile[];  // p then dp: 2 x [GS_PB][S*k + 1]
+  const int SK = S * k, pitch = SK + 1;
+  float* tp = tile;
+  float* td = tile + GS_PB * pitch;
+  const long m0 = (long)blockIdx.x * GS_PB;
+  const int rows = (int)min((long)GS_PB, M - m0);
+  for (int s = 0; s < S; ++s) {
+    const float* sp = p + ((long)s * M + m0) * k;
+    const float* sd = dp + ((long)s * M + m0) * k;
+    for (int e = threadIdx.x; e < rows * k; e += 256) {
+      tp[(e / k) * pitch + s * k + e % k] = sp[e];
+      td[(e / k) * pitch + s * k + e % k] = sd[e];
+    }
   }
+  __syncthreads();
+  for (int e = threadIdx.x; e < rows * S; e += 256) {
+    const int off = (e % rows) * pitch + (e / rows) * k;
+    float dot = 0.f;
+    for (int i = 0; i < k; ++i) dot = fmaf(tp[off + i], td[off + i], dot);
+    for (int i = 0; i < k; ++i) td[off + i] = invT * tp[off + i] * (td[off + i] - dot);
+  }
+  __syncthreads();
+  float* dst = dlogits + m0 * SK;
+  for (int e = threadIdx.x; e < rows * SK; e += 256) dst[e] = td[(e / SK) * pitch + e % SK];
 }
 
 // ---------------------------------------------------------------- joint forward
@@ -323,8 +352,8 @@ __global__ void __launch_bounds__(256)
 }
 
 inline int joint_blocks(long npix) {
-  long b = (npix + 4095) / 4096;
-  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+  long b = (npix + 1023) / 1024;  // >= 3 blocks per CU at the config sizes
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
 }  // namespace
@@ -334,7 +363,9 @@ extern "C" {
 int cy_group_softmax_fwd(const float* logits, float* probs, long M, int S, int k, float invT,
                          void* stream) {
   if (!logits || !probs || M <= 0 || S <= 0 || k <= 0) return CY_ERR_ARG;
-  hipLaunchKernelGGL(group_softmax_fwd_kernel, dim3(grid_for(M * S)), dim3(256), 0,
+  const size_t smem = (size_t)GS_PB * (S * k + 1) * sizeof(float);
+  if (smem > 64 * 1024) return CY_ERR_SHAPE;
+  hipLaunchKernelGGL(group_softmax_fwd_kernel, dim3(cy_cdiv(M, GS_PB)), dim3(256), smem,
                      (hipStream_t)stream, logits, probs, M, S, k, invT);
   CY_CHECK_LAUNCH();
   return CY_OK;
@@ -343,7 +374,9 @@ int cy_group_softmax_fwd(const float* logits, float* probs, long M, int S, int k
 int cy_group_softmax_bwd(const float* probs, const float* dprobs, float* dlogits, long M, int S,
                          int k, float invT, void* stream) {
   if (!probs || !dprobs || !dlogits || M <= 0 || S <= 0 || k <= 0) return CY_ERR_ARG;
-  hipLaunchKernelGGL(group_softmax_bwd_kernel, dim3(grid_for(M * S)), dim3(256), 0,
+  const size_t smem = (size_t)2 * GS_PB * (S * k + 1) * sizeof(float);
+  if (smem > 64 * 1024) return CY_ERR_SHAPE;
+  hipLaunchKernelGGL(group_softmax_bwd_kernel, dim3(cy_cdiv(M, GS_PB)), dim3(256), smem,
                      (hipStream_t)stream, probs, dprobs, dlogits, M, S, k, invT);
   CY_CHECK_LAUNCH();
   return CY_OK;
