@@ -118,6 +118,18 @@ __global__ void __launch_bounds__(256)
   const long p1 = p0 + per < npix ? p0 + per : npix;
   for (long pt = p0; pt < p1; pt += J_P) {
     __syncthreads();
+    if (pad == 0 && kp == k) {  // the tile is one contiguous span of both maps: 16-byte copies
+      const long lim = (p1 - pt) * k;  // floats of this tile that exist
+      for (int e4 = tid; e4 < J_P * k / 4; e4 += 256) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (4L * e4 < lim) {
+          a = *reinterpret_cast<const f32x4*>(x1 + pt * k + 4 * e4);
+          b = *reinterpret_cast<const f32x4*>(x2 + pt * k + 4 * e4);
+        }
+        *reinterpret_cast<f32x4*>(xs1 + 4 * e4) = a;
+        *reinterpret_cast<f32x4*>(xs2 + 4 * e4) = b;
+      }
+    } else
     for (int e = tid; e < J_P * kp; e += 256) {
       const int p = e / kp, c = e - p * kp;
       const long pix = pt + p;
@@ -166,15 +178,26 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// J[e] = scale * sum_b part[d][b][r]: 4 elements per block, 64 slices of the block partials each,
+// fixed slice order (deterministic)
 __global__ void __launch_bounds__(256)
     joint_reduce_kernel(const float* __restrict__ part, float* __restrict__ J, int TT, int nblk,
-                         int kk, double scale) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= TT * kk) return;
-  const int d = e / kk, r = e - d * kk;
+                        int kk, double scale) {
+  __shared__ double sred[64][4];
+  const int el = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const int e = blockIdx.x * 4 + el;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[((size_t)d * nblk + b) * kk + r];
-  J[e] = (float)(s * scale);
+  if (e < TT * kk) {
+    const int d = e / kk, r = e - d * kk;
+    for (int b = sl; b < nblk; b += 64) s += (double)part[((size_t)d * nblk + b) * kk + r];
+  }
+  sred[sl][el] = s;
+  __syncthreads();
+  if (sl == 0 && e < TT * kk) {
+    double t = 0.0;
+    for (int q = 0; q < 64; ++q) t += sred[q][el];
+    J[e] = (float)(t * scale);
+  }
 }
 
 // ---------------------------------------------------------------- joint backward
@@ -210,6 +233,54 @@ __global__ void __launch_bounds__(256)
       }
     }
     dx[e] = g * s;
+  }
+}
+
+// k % 4 == 0: one thread per (pixel, 4 output channels), 16-byte global and LDS accesses
+__global__ void __launch_bounds__(256)
+    joint_bwd4_kernel(const float* __restrict__ other, const float* __restrict__ dJ,
+                      const float* __restrict__ gscale, float* __restrict__ dx, int N, int H, int W,
+                      int k, int pad, float scale, int which) {
+  extern __shared__ __attribute__((aligned(16))) float sdj[];  // [T*T][k][k]
+  const int T = 2 * pad + 1, TT = T * T, k4 = k >> 2;
+  for (int e = threadIdx.x; e < TT * k * k; e += 256) sdj[e] = dJ[e];
+  __syncthreads();
+  const float g = gscale[0] * scale;
+  const long total = (long)N * H * W * k4;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const int c = (int)(e % k4) * 4;
+    const long pix = e / k4;
+    const int w = (int)(pix % W);
+    const int h = (int)((pix / W) % H);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < TT; ++d) {
+      const int du = d / T - pad, dv = d % T - pad;
+      const int hh = which ? h + du : h - du, ww = which ? w + dv : w - dv;
+      if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+      const long q = which ? pix + (long)du * W + dv : pix - (long)du * W - dv;
+      const float* o = other + q * k;
+      const float* m = sdj + d * k * k;
+      for (int j4 = 0; j4 < k4; ++j4) {
+        const f32x4 ov = *reinterpret_cast<const f32x4*>(o + 4 * j4);
+        if (which) {  // s[c..c+3] += sum_i M[i][c..c+3] * o[i]
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const f32x4 mv = *reinterpret_cast<const f32x4*>(m + (4 * j4 + t) * k + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] = fmaf(mv[u], ov[t], s[u]);
+          }
+        } else {  // s[c+u] += sum_j M[c+u][j] * o[j]
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const f32x4 mv = *reinterpret_cast<const f32x4*>(m + (c + u) * k + 4 * j4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s[u] = fmaf(mv[t], ov[t], s[u]);
+          }
+        }
+      }
+    }
+    f32x4 r = {g * s[0], g * s[1], g * s[2], g * s[3]};
+    *reinterpret_cast<f32x4*>(dx + pix * k + c) = r;
   }
 }
 
@@ -402,7 +473,7 @@ int cy_joint_fwd(const float* x1, const float* x2, float* J, int N, int H, int W
   hipLaunchKernelGGL(joint_fwd_kernel, dim3(nblk, T * T), dim3(256), smem, st, x1, x2, (float*)ws,
                      N, H, W, k, pad);
   CY_CHECK_LAUNCH();
-  hipLaunchKernelGGL(joint_reduce_kernel, dim3(cy_cdiv((long)T * T * k * k, 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(joint_reduce_kernel, dim3(cy_cdiv((long)T * T * k * k, 4)), dim3(256), 0, st,
                      (const float*)ws, J, T * T, nblk, k * k,
                      normalise ? 1.0 / (double)npix : 1.0);
   CY_CHECK_LAUNCH();
@@ -419,15 +490,18 @@ int cy_joint_bwd(const float* x1, const float* x2, const float* dJ, const float*
   hipStream_t st = (hipStream_t)stream;
   const long npix = (long)N * H * W;
   const float scale = normalise ? (float)(1.0 / (double)npix) : 1.f;
-  const int grid = grid_for(npix * k);
-  if (dx1) {
-    hipLaunchKernelGGL(joint_bwd_kernel, dim3(grid), dim3(256), smem, st, x2, dJ, gscale, dx1, N, H,
-                       W, k, pad, scale, 0);
-    CY_CHECK_LAUNCH();
-  }
-  if (dx2) {
-    hipLaunchKernelGGL(joint_bwd_kernel, dim3(grid), dim3(256), smem, st, x1, dJ, gscale, dx2, N, H,
-                       W, k, pad, scale, 1);
+  const bool v4 = (k & 3) == 0;
+  const int grid = grid_for(v4 ? npix * (k / 4) : npix * k);
+  for (int which = 0; which < 2; ++which) {
+    float* dst = which ? dx2 : dx1;
+    const float* other = which ? x1 : x2;
+    if (!dst) continue;
+    if (v4)
+      hipLaunchKernelGGL(joint_bwd4_kernel, dim3(grid), dim3(256), smem, st, other, dJ, gscale, dst, N,
+                         H, W, k, pad, scale, which);
+    else
+      hipLaunchKernelGGL(joint_bwd_kernel, dim3(grid), dim3(256), smem, st, other, dJ, gscale, dst, N,
+                         H, W, k, pad, scale, which);
     CY_CHECK_LAUNCH();
   }
   return CY_OK;
