@@ -195,14 +195,20 @@ __global__ void __launch_bounds__(256)
 template <typename T>
 __global__ void __launch_bounds__(256)
     avgpool_fwd_kernel(const T* __restrict__ x, float* __restrict__ pooled, int HW, int C) {
-  // grid: (N, ceil(C/256)); thread = channel; loops over pixels (coalesced across channels)
+  // grid: (N, ceil(C/256)); thread = channel, 4 independent partial sums over pixel phases so that
+  // four loads are in flight (a single chain is latency-bound: 196 dependent steps at Conv5)
   const int n = blockIdx.x;
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
   const T* xp = x + (size_t)n * HW * C + c;
-  float s = 0.f;
-  for (int p = 0; p < HW; ++p) s += to_f32<T>(xp[(size_t)p * C]);
-  pooled[(size_t)n * C + c] = s / (float)HW;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  int p = 0;
+  for (; p + 4 <= HW; p += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += to_f32<T>(xp[(size_t)(p + u) * C]);
+  }
+  for (; p < HW; ++p) s[0] += to_f32<T>(xp[(size_t)p * C]);
+  pooled[(size_t)n * C + c] = ((s[0] + s[1]) + (s[2] + s[3])) / (float)HW;
 }
 
 template <typename T>
@@ -252,11 +258,18 @@ __global__ void __launch_bounds__(256)
   const long e = blockIdx.x * 256L + threadIdx.x;
   if (e >= (long)M * I) return;
   const int m = (int)(e / I), i = (int)(e % I);
-  float s = 0.f;
-  for (int o = 0; o < O; ++o)
-    s = fmaf(act_grad(y[(size_t)m * O + o], dy[(size_t)m * O + o], act, slope),
-             w[(size_t)o * I + i], s);
-  dx[e] = s;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};  // four independent chains keep four weight loads in flight
+  int o = 0;
+  for (; o + 4 <= O; o += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      s[u] = fmaf(act_grad(y[(size_t)m * O + o + u], dy[(size_t)m * O + o + u], act, slope),
+                  w[(size_t)(o + u) * I + i], s[u]);
+  }
+  for (; o < O; ++o)
+    s[0] = fmaf(act_grad(y[(size_t)m * O + o], dy[(size_t)m * O + o], act, slope), w[(size_t)o * I + i],
+                s[0]);
+  dx[e] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
 __global__ void __launch_bounds__(256)

@@ -211,14 +211,23 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     head_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                            float* __restrict__ db, int nblk, int KC, int K) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= KC + K) return;
+  // 4 outputs per block, 64 slices of the block partials each, fixed slice order
+  __shared__ double sred[64][4];
+  const int el = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const int i = blockIdx.x * 4 + el;
   double s = 0.0;
-  for (int q = 0; q < nblk; ++q) s += (double)ws[(size_t)q * (KC + K) + i];
-  if (i < KC) {
-    if (dw) dw[i] = (float)s;
-  } else if (db) {
-    db[i - KC] = (float)s;
+  if (i < KC + K)
+    for (int q = sl; q < nblk; q += 64) s += (double)ws[(size_t)q * (KC + K) + i];
+  sred[sl][el] = s;
+  __syncthreads();
+  if (sl == 0 && i < KC + K) {
+    double t = 0.0;
+    for (int q = 0; q < 64; ++q) t += sred[q][el];
+    if (i < KC) {
+      if (dw) dw[i] = (float)t;
+    } else if (db) {
+      db[i - KC] = (float)t;
+    }
   }
 }
 
@@ -513,7 +522,7 @@ int cy_head1x1_bwd(const void* x, const float* w, const float* dlogits, void* dx
                            (const float*)x, dlogits, (float*)ws, npix, C, K);
     }
     CY_CHECK_LAUNCH();
-    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3(cy_cdiv(K * C + K, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3(cy_cdiv(K * C + K, 4)), dim3(256), 0, st,
                        (const float*)ws, dw, db, nblk, K * C, K);
     CY_CHECK_LAUNCH();
   }

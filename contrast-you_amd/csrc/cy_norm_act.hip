@@ -31,14 +31,17 @@ __global__ void __launch_bounds__(1024)
   sred[0][sl][cl] = s1;
   sred[1][sl][cl] = s2;
   __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {  // fixed-shape tree over the slices (deterministic)
+    if (sl < o) {
+      sred[0][sl][cl] += sred[0][sl + o][cl];
+      sred[1][sl][cl] += sred[1][sl + o][cl];
+    }
+    __syncthreads();
+  }
   if (sl == 0 && c < C) {
     double mean, var;
     if (use_batch_stats) {
-      double t1 = 0.0, t2 = 0.0;
-      for (int q = 0; q < 256; ++q) {
-        t1 += sred[0][q][cl];
-        t2 += sred[1][q][cl];
-      }
+      const double t1 = sred[0][0][cl], t2 = sred[1][0][cl];
       mean = t1 / count;
       var = t2 / count - mean * mean;
       if (var < 0.0) var = 0.0;
@@ -206,12 +209,15 @@ __global__ void __launch_bounds__(256)
   sred[0][sl][cl] = s1;
   sred[1][sl][cl] = s2;
   __syncthreads();
-  if (sl == 0 && c < C) {
-    double t1 = 0.0, t2 = 0.0;
-    for (int q = 0; q < 64; ++q) {
-      t1 += sred[0][q][cl];
-      t2 += sred[1][q][cl];
+  for (int o = 32; o > 0; o >>= 1) {
+    if (sl < o) {
+      sred[0][sl][cl] += sred[0][sl + o][cl];
+      sred[1][sl][cl] += sred[1][sl + o][cl];
     }
+    __syncthreads();
+  }
+  if (sl == 0 && c < C) {
+    const double t1 = sred[0][0][cl], t2 = sred[1][0][cl];
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)t1 : (float)t1;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)t2 : (float)t2;
     // dy = scale*dz + k1*y + k0   (k1 = k0 = 0 when BN used running statistics)
