@@ -14,7 +14,8 @@ optimizer step (+ gradient all-reduce over RCCL when N > 1).  Inputs are residen
 
 Extra JSON objects (see DESIGN.md "Measurement"):
   roofline     -- dominant conv kernel family: algorithmic FLOP / HIP-event time of its launches,
-                  collected in a separate instrumented pass of the same step AFTER the timed region
+                  collected in a separate single-stream instrumented pass of the same step AFTER the
+                  timed region
   cpu_baseline -- the oracle's CPU restatement of the same step (kind "port") on a bounded sample
 """
 from __future__ import annotations
@@ -105,11 +106,19 @@ def run_epoch(ctx, device, num_batches: int, epoch: int):
 
 
 def kernel_roofline(ctx, device, steps: int = 3):
-    """instrumented pass: HIP events around every conv3x3 launch (on the launch stream)"""
+    """instrumented pass: HIP events around every conv3x3 launch (on the launch stream).  The timed
+    region overlaps weight-gradient kernels with the rest of the backward pass on a second stream;
+    a kernel's roofline fraction is a property of the kernel, so this pass runs the same step with
+    every launch on ONE stream (an overlapped kernel's begin-to-end time includes its neighbour's
+    share of the CUs).  The committed rocprofv3 stats use the same setting (CY_ASYNC_WGRAD=0)."""
     from cyhip import ops
     ops.PROFILE = []
-    run_epoch(ctx, device, steps, 99)
-    torch.cuda.synchronize()
+    was_async, ops.ASYNC_WGRAD = ops.ASYNC_WGRAD, False
+    try:
+        run_epoch(ctx, device, steps, 99)
+        torch.cuda.synchronize()
+    finally:
+        ops.ASYNC_WGRAD = was_async
     rec, ops.PROFILE = ops.PROFILE, None
     fam, fam_bytes = {}, {}
     for kind, flops, e0, e1, *rest in rec:

@@ -134,6 +134,34 @@ __global__ void __launch_bounds__(256, 2)
     }
   };
 
+  // One tap of one channel chunk: KS k-steps of M_REP x N_REP MFMAs.  The LDS fragments of k-step
+  // ks+1 are requested BEFORE the MFMAs of k-step ks are issued (two register sets, order pinned by
+  // sched_barrier), so LDS latency hides behind M_REP*N_REP MFMAs instead of one.
+  auto mma_tap = [&](const unsigned char* sBc, const unsigned char* const* apix, const int* aswz) {
+    typename M::Frag af[2][M_REP], bf[2][N_REP];
+#pragma unroll
+    for (int n = 0; n < N_REP; ++n) bf[0][n] = M::load(sBc + brow[n] * PITCHB, h, bswz[n]);
+#pragma unroll
+    for (int m = 0; m < M_REP; ++m) af[0][m] = M::load(apix[m], h, aswz[m]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < KS) {
+        const int fi = 2 * (ks + 1) + h;
+#pragma unroll
+        for (int n = 0; n < N_REP; ++n) bf[nxt][n] = M::load(sBc + brow[n] * PITCHB, fi, bswz[n]);
+#pragma unroll
+        for (int m = 0; m < M_REP; ++m) af[nxt][m] = M::load(apix[m], fi, aswz[m]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+        for (int n = 0; n < N_REP; ++n) M::mma(af[cur][m], bf[cur][n], acc[m][n]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   if constexpr (ALLT) {
     // Small-N layers (Cout <= 64): all nine weight taps of a chunk sit in LDS at once, so a
     // chunk is {stage A + B, barrier, 9 taps x KS k-steps of MFMA, barrier}: no per-tap barrier.
@@ -176,19 +204,7 @@ __global__ void __launch_bounds__(256, 2)
           apix[m] = sA + p * PITCHB;
           aswz[m] = lds_swz<PITCHB>(p);
         }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int fi = 2 * ks + h;
-          typename M::Frag bf[N_REP];
-#pragma unroll
-          for (int n = 0; n < N_REP; ++n) bf[n] = M::load(sBc + brow[n] * PITCHB, fi, bswz[n]);
-#pragma unroll
-          for (int m = 0; m < M_REP; ++m) {
-            typename M::Frag af = M::load(apix[m], fi, aswz[m]);
-#pragma unroll
-            for (int n = 0; n < N_REP; ++n) M::mma(af, bf[n], acc[m][n]);
-          }
-        }
+        mma_tap(sBc, apix, aswz);
       }
     }
     __syncthreads();
@@ -220,19 +236,7 @@ __global__ void __launch_bounds__(256, 2)
         apix[m] = sA + p * PITCHB;
         aswz[m] = lds_swz<PITCHB>(p);
       }
-  #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int fi = 2 * ks + h;
-        typename M::Frag bf[N_REP];
-  #pragma unroll
-        for (int n = 0; n < N_REP; ++n) bf[n] = M::load(sBc + brow[n] * PITCHB, fi, bswz[n]);
-  #pragma unroll
-        for (int m = 0; m < M_REP; ++m) {
-          typename M::Frag af = M::load(apix[m], fi, aswz[m]);
-  #pragma unroll
-          for (int n = 0; n < N_REP; ++n) M::mma(af, bf[n], acc[m][n]);
-        }
-      }
+      mma_tap(sBc, apix, aswz);
 
       if (has_next) store_b(sB + ((it + 1 - it0) & 1) * C::B_BYTES);
       if (tap == 8 && has_next) {

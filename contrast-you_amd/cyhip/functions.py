@@ -182,17 +182,28 @@ class ConvChainFn(torch.autograd.Function):
             if i > 0:
                 ps, ph = coefs[i - 1][0], coefs[i - 1][1]
                 if need_w:
-                    dw = ops.conv3x3_wgrad(ys[i - 1], None, dy, scale=ps, shift=ph, out=wsink)
-                    grads_p[3 * i] = None if wsink is not None else dw
+                    if wsink is not None and ops.ASYNC_WGRAD:
+                        with ops.on_side_stream(ys[i - 1], dy, ps, ph):
+                            ops.conv3x3_wgrad(ys[i - 1], None, dy, scale=ps, shift=ph, out=wsink)
+                    else:
+                        dw = ops.conv3x3_wgrad(ys[i - 1], None, dy, scale=ps, shift=ph, out=wsink)
+                        grads_p[3 * i] = None if wsink is not None else dw
                 _, wd = packed_weights(w, dt)
                 da, _ = ops.conv3x3_fwd(dy, None, wd, w.shape[1], want_stats=False)
             else:
                 if need_w:
-                    if cfg.first:
-                        dw = ops.conv_first_wgrad(x1, dy, out=wsink)
+                    if wsink is not None and ops.ASYNC_WGRAD:
+                        with ops.on_side_stream(x1, x2, dy):
+                            if cfg.first:
+                                ops.conv_first_wgrad(x1, dy, out=wsink)
+                            else:
+                                ops.conv3x3_wgrad(x1, x2, dy, mode=cfg.mode, out=wsink)
                     else:
-                        dw = ops.conv3x3_wgrad(x1, x2, dy, mode=cfg.mode, out=wsink)
-                    grads_p[0] = None if wsink is not None else dw
+                        if cfg.first:
+                            dw = ops.conv_first_wgrad(x1, dy, out=wsink)
+                        else:
+                            dw = ops.conv3x3_wgrad(x1, x2, dy, mode=cfg.mode, out=wsink)
+                        grads_p[0] = None if wsink is not None else dw
                 need_x1 = need[1]
                 need_x2 = ctx.has_x2 and need[2]
                 if need_x1 or need_x2:

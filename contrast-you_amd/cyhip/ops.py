@@ -193,6 +193,75 @@ def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, 
     return out, stats
 
 
+# ---- side stream for weight gradients ------------------------------------------------------------
+# A layer's weight-gradient kernels do not feed the rest of the backward pass (only the optimizer
+# reads them), and at the configured batch sizes neither they nor the data-gradient kernels fill
+# 256 CUs on their own.  They are therefore enqueued on a second HIP stream and overlap with the
+# main stream's data-gradient / BN-backward kernels; the optimizer joins the stream before it reads
+# the gradients.  CY_ASYNC_WGRAD=0 keeps everything on one stream.
+import os as _os
+
+ASYNC_WGRAD = _os.environ.get("CY_ASYNC_WGRAD", "1") != "0"
+_side_streams = {}
+_side_pending = set()
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    st = _side_streams.get(idx)
+    if st is None:
+        st = _side_streams[idx] = torch.cuda.Stream(device=idx)
+    return st
+
+
+class on_side_stream:
+    """run the enclosed launches on the side stream, after everything already enqueued on the
+    current stream; `reads` are tensors the side kernels read (kept alive for the allocator)"""
+
+    def __init__(self, *reads: Optional[Tensor]):
+        self.reads = [t for t in reads if t is not None]
+
+    def __enter__(self):
+        dev = self.reads[0].device
+        self.side = side_stream(dev)
+        self.side.wait_stream(torch.cuda.current_stream(dev))
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self.side
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        for t in self.reads:
+            t.record_stream(self.side)
+        _side_pending.add(self.side)
+        global _join_queued
+        if not _join_queued:  # join when this backward pass ends: .grad is then safe to read on the main stream
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_join_after_backward)
+                _join_queued = True
+            except RuntimeError:  # not inside a backward pass
+                join_side_streams()
+        return False
+
+
+_join_queued = False
+
+
+def _join_after_backward() -> None:
+    global _join_queued
+    _join_queued = False
+    join_side_streams()
+
+
+def join_side_streams() -> None:
+    """make the current stream wait for all side-stream work enqueued so far"""
+    while _side_pending:
+        st = _side_pending.pop()
+        torch.cuda.current_stream(st.device).wait_stream(st)
+
+
 def grad_sink(p: Tensor) -> Optional[Tensor]:
     """p.grad when the kernels can accumulate straight into it (f32, contiguous, on the GPU)"""
     g = p.grad
