@@ -12,7 +12,7 @@ from torch import nn
 
 __all__ = ["fix_all_seed", "fix_all_seed_for_transforms", "fix_all_seed_within_context", "class_name",
            "get_lrs_from_optimizer", "disable_tracking_bn_stats", "get_model", "get_dataset",
-           "average_iter", "ntuple", "ignore_exception"]
+           "average_iter", "ntuple", "ignore_exception", "extract_model_state_dict"]
 
 
 def fix_all_seed(seed):
@@ -126,3 +126,12 @@ def ignore_exception(*exc):
         yield
     except (exc or (Exception,)):
         pass
+
+
+def extract_model_state_dict(trainer_checkpoint_path: str, *, keyword="_model"):
+    """model weights out of a trainer checkpoint (`last.pth` / `best.pth`): the `_model.*` entries of
+    its `module_state` section (contrastyou/utils/utils.py:88-90).  Loaded with `weights_only=True`:
+    nothing in the file is executed; a checkpoint that pickles custom objects is refused by torch."""
+    state = torch.load(trainer_checkpoint_path, map_location="cpu", weights_only=True)
+    prefix = keyword + "."
+    return {k[len(prefix):]: v for k, v in state["module_state"].items() if k.startswith(prefix)}

@@ -228,6 +228,12 @@ def test_semi_trainer_two_epochs_schedule_checkpoint_resume(tmp_path):
     rows = (tmp_path / "storage.csv").read_text().strip().splitlines()
     assert len(rows) == 3 and "tra/semi/sup_loss," in rows[0] and "val/eval/dice/DSC_mean" in rows[0]
 
+    # main.py:51-58: a later run seeds its model from a trainer checkpoint
+    from contrastyou.utils import extract_model_state_dict
+    fresh = UNet(input_dim=1, num_classes=4, max_channel=128)
+    fresh.load_state_dict(extract_model_state_dict(str(tmp_path / "last.pth")), strict=True)
+    assert all(torch.equal(v.cpu(), tr._model.state_dict()[k].cpu()) for k, v in fresh.state_dict().items())
+
     tr2, hook2 = make(tmp_path)
     with tr2.register_hook(hook2):
         tr2.init()
