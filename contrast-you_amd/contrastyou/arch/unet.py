@@ -146,6 +146,7 @@ class UNet(nn.Module):
             raise KeyError(f"`return_until` should be in {', '.join(self.layer_dimension.keys())},"
                            f" given {until}  ")
         ops.require_gpu(x)
+        ops.note_home_stream(x.device)
         if x.dim() != 4 or x.shape[1] != self._input_dim:
             raise ValueError(f"expected [N,{self._input_dim},H,W], got {tuple(x.shape)}")
         if x.shape[2] % 16 or x.shape[3] % 16:

@@ -122,7 +122,7 @@ class FusedRAdam(torch.optim.Optimizer):
         return any(f is None or f.stale() for f in self._flat)
 
     def zero_grad(self, set_to_none: bool = False):
-        ops.join_side_streams()
+        ops.join_side_streams(torch.cuda.current_stream() if torch.cuda.is_available() else None)
         if self._needs_flat():
             self._ensure_flat()
         for f in self._flat:
@@ -174,7 +174,8 @@ class FusedRAdam(torch.optim.Optimizer):
                 loss = closure()
         if self._needs_flat():
             self._ensure_flat()
-        ops.join_side_streams()  # weight gradients are produced on a side stream
+        if torch.cuda.is_available():  # weight gradients are produced on a side stream
+            ops.join_side_streams(torch.cuda.current_stream())
         self.all_reduce_grads()
         for i, g in enumerate(self.param_groups):
             f, st = self._flat[i], self._flat_state[i]

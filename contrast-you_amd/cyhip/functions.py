@@ -37,7 +37,8 @@ class defer_batch_counters:
         global _nbt_pending
         pending, _nbt_pending = _nbt_pending, self._outer
         if pending and exc[0] is None:
-            torch._foreach_add_(pending, 1)
+            with ops.ordered("bn_batch_counters"):
+                torch._foreach_add_(pending, 1)
         return False
 
 
@@ -50,15 +51,20 @@ def packed_weights(w: Tensor, dtype: torch.dtype):
     """(forward image, dgrad image) of a 3x3 weight, cached ON the parameter object until the
     weight changes.  (A global dict keyed by id(w) would hand a new parameter that reuses a dead
     one's id and storage address the dead one's packed weights.)"""
-    tag = (w._version, _weights_epoch, w.data_ptr())
+    tag = (w._version, _weights_epoch, w.data_ptr(), torch.cuda.is_current_stream_capturing())
     cache = w.__dict__.get("_cy_pack")
     if cache is None:
         cache = w.__dict__["_cy_pack"] = {}
     hit = cache.get(dtype)
+    cur = torch.cuda.current_stream(w.device)
     if hit is not None and hit[0] == tag:
+        if hit[4] != cur:  # packed on another stream (two-stream forward, side-stream wgrad): wait for it
+            cur.wait_event(hit[3])
         return hit[1], hit[2]
     wf, wd = ops.pack_weights(w, dtype, want_dgrad=True)
-    cache[dtype] = (tag, wf, wd)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    cache[dtype] = (tag, wf, wd, ev, cur)
     return wf, wd
 
 
@@ -239,6 +245,7 @@ class HeadFn(torch.autograd.Function):
         x = ops.to_nhwc(x)
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.bias = b  # the parameter object (for its .grad sink), not saved data
         return ops.head_fwd(x, w, b)
 
     @staticmethod
@@ -249,6 +256,16 @@ class HeadFn(torch.autograd.Function):
         dx, dw, db = ops.head_bwd(x, w, dlogits, need_dx, need_dw)
         if dw is not None:
             dw = dw.to(w.dtype)
+            # like the conv / BN parameters: accumulate straight into live .grad buffers (ordered across
+            # streams), so that autograd never has to merge the two passes' contributions itself
+            wsink = ops.grad_sink(w) if ctx.needs_input_grad[1] else None
+            bsink = ops.grad_sink(ctx.bias) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            if wsink is not None and (bsink is not None or not ctx.has_bias):
+                with ops.ordered(("head_grad", wsink.data_ptr())):
+                    wsink.add_(dw.view_as(wsink))
+                    if bsink is not None:
+                        bsink.add_(db.view_as(bsink))
+                return dx, None, None
         return dx, dw if ctx.needs_input_grad[1] else None, db if ctx.has_bias else None
 
 

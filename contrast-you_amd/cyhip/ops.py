@@ -136,12 +136,29 @@ def pack_weights(w: Tensor, dtype: torch.dtype, want_dgrad: bool = True):
     return wf, wd
 
 
-def _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, ld1, ld2, ldo, split_c=0, ldo2=0) -> ConvDesc:
-    d = ConvDesc()
-    d.N, d.H, d.W, d.C1, d.C2, d.Cout = N, H, W, C1, C2, Cout
-    d.mode1, d.prologue, d.in_dtype, d.out_dtype = mode, prologue, dt, dt
-    d.ld1, d.ld2, d.ldo, d.split_c, d.ldo2 = ld1, ld2, ldo, split_c, ldo2
-    return d
+_desc_cache = {}
+
+
+class _Plan:
+    """a conv descriptor with the plan numbers the library derives from it (queried once per shape:
+    the host issue path is the step's critical resource)"""
+    __slots__ = ("d", "ref", "npart", "fwd_ws", "wgrad_ws")
+
+    def __init__(self, d: ConvDesc):
+        self.d, self.ref = d, C.byref(d)
+        self.npart = self.fwd_ws = self.wgrad_ws = None
+
+
+def _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, ld1, ld2, ldo, split_c=0, ldo2=0) -> _Plan:
+    key = (N, H, W, C1, C2, Cout, mode, prologue, dt, ld1, ld2, ldo, split_c, ldo2)
+    p = _desc_cache.get(key)
+    if p is None:
+        d = ConvDesc()
+        d.N, d.H, d.W, d.C1, d.C2, d.Cout = N, H, W, C1, C2, Cout
+        d.mode1, d.prologue, d.in_dtype, d.out_dtype = mode, prologue, dt, dt
+        d.ld1, d.ld2, d.ldo, d.split_c, d.ldo2 = ld1, ld2, ldo, split_c, ldo2
+        p = _desc_cache[key] = _Plan(d)
+    return p
 
 
 def _out_hw(src1: Tensor, mode: int) -> Tuple[int, int]:
@@ -177,12 +194,15 @@ def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, 
         d = _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, C1, C2, Cout)
     stats = None
     if want_stats:
-        npart = _lib.call("cy_conv3x3_num_partials", C.byref(d))
-        stats = _f32(npart * 2 * Cout, dev).view(npart, 2, Cout)
-    nbytes = _lib.load().cy_conv3x3_fwd_ws_bytes(C.byref(d))
+        if d.npart is None:
+            d.npart = _lib.call("cy_conv3x3_num_partials", d.ref)
+        stats = _f32(d.npart * 2 * Cout, dev).view(d.npart, 2, Cout)
+    if d.fwd_ws is None:
+        d.fwd_ws = _lib.load().cy_conv3x3_fwd_ws_bytes(d.ref)
+    nbytes = d.fwd_ws
     ws = _ws(nbytes, dev) if nbytes else None
     ev = _prof_begin()
-    _lib.call("cy_conv3x3_fwd", C.byref(d), src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
+    _lib.call("cy_conv3x3_fwd", d.ref, src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
               wf.data_ptr(), out.data_ptr(), _ptr(out2), _ptr(stats), _ptr(ws), nbytes, _stream())
     if ev is not None:  # algorithmic bytes: every input and output element once, packed weights once
         esz = src1.element_size()
@@ -202,18 +222,29 @@ def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, 
 import os as _os
 
 ASYNC_WGRAD = _os.environ.get("CY_ASYNC_WGRAD", "1") != "0"
+CAPTURING = False  # True while a HIP graph of the step is being captured (cyhip.graphed)
 _side_streams = {}
 _side_pending = set()
 
 
-def side_stream(device) -> "torch.cuda.Stream":
+def side_stream(device, role: str = "wgrad") -> "torch.cuda.Stream":
+    """the per-device auxiliary stream of a role: "wgrad" (weight gradients) or "pass2" (second
+    network pass of a two-stage step)"""
     idx = torch.device(device).index
     if idx is None:
         idx = torch.cuda.current_device()
-    st = _side_streams.get(idx)
+    st = _side_streams.get((idx, role))
     if st is None:
-        st = _side_streams[idx] = torch.cuda.Stream(device=idx)
+        st = _side_streams[(idx, role)] = torch.cuda.Stream(device=idx)
     return st
+
+
+def note_side_work(stream) -> None:
+    """register work on an auxiliary stream that the end-of-backward / optimizer join must wait for
+    (call BEFORE enqueueing it: from here on in-place updates of shared buffers are event-ordered)"""
+    global _multi_stream_live
+    _multi_stream_live = True
+    _side_pending.add(stream)
 
 
 class on_side_stream:
@@ -233,8 +264,9 @@ class on_side_stream:
 
     def __exit__(self, *exc):
         self.ctx.__exit__(*exc)
-        for t in self.reads:
-            t.record_stream(self.side)
+        if not CAPTURING:  # inside a graph capture lifetimes are the graph's; record_stream is not capturable
+            for t in self.reads:
+                t.record_stream(self.side)
         _side_pending.add(self.side)
         global _join_queued
         if not _join_queued:  # join when this backward pass ends: .grad is then safe to read on the main stream
@@ -255,15 +287,71 @@ def _join_after_backward() -> None:
     join_side_streams()
 
 
-def join_side_streams() -> None:
-    """make the current stream wait for all side-stream work enqueued so far"""
+_home_stream = {}  # device index -> the stream the step itself runs on
+
+
+def note_home_stream(device) -> None:
+    """remember the stream the network is driven from (called by the forward pass); the joins below
+    target it explicitly because autograd's end-of-backward callbacks may run on a thread whose
+    current stream is the legacy default stream"""
+    cur = torch.cuda.current_stream(device)
+    if cur not in _side_streams.values():
+        _home_stream[cur.device.index] = cur
+
+
+def join_side_streams(onto: Optional["torch.cuda.Stream"] = None) -> None:
+    """make `onto` (default: the home stream of the device) wait for all side-stream work enqueued so far"""
     while _side_pending:
         st = _side_pending.pop()
-        torch.cuda.current_stream(st.device).wait_stream(st)
+        tgt = onto if onto is not None else _home_stream.get(st.device.index)
+        if tgt is None:
+            tgt = torch.cuda.current_stream(st.device)
+        tgt.wait_stream(st)
+
+
+# ---- cross-stream ordering of read-modify-write kernels -----------------------------------------
+# With the two network passes of a step on two streams (SemiSupervisedEpocher two-stage forward) the
+# kernels that update a shared buffer in place -- BN running statistics, accumulated BN parameter
+# gradients, batch counters -- must keep the reference's order: every such launch waits for the last
+# launch on the same buffer (if that was on another stream) and leaves an event behind.  The order is
+# the host's enqueue order, so results stay deterministic.
+TWO_STREAM = _os.environ.get("CY_TWO_STREAM", "1") != "0"
+_order_events = {}
+_multi_stream_live = False  # set by the first fork onto a "pass2" stream; single-stream runs pay nothing
+
+
+class ordered:
+    """`with ordered(key):` -- serialise in-place updates of the buffer identified by `key` across streams"""
+
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        if _multi_stream_live:
+            rec = _order_events.get(self.key)
+            if rec is not None:
+                cur = torch.cuda.current_stream()
+                # an event recorded outside a graph capture cannot be waited on inside one (and vice
+                # versa); captures are fenced by full stream synchronisation, so skipping is safe
+                if rec[1] != cur and rec[2] == torch.cuda.is_current_stream_capturing():
+                    cur.wait_event(rec[0])
+        return self
+
+    def __exit__(self, *exc):
+        if _multi_stream_live:
+            rec = _order_events.get(self.key)
+            cur = torch.cuda.current_stream()
+            cap = torch.cuda.is_current_stream_capturing()
+            ev = rec[0] if (rec is not None and rec[2] == cap) else torch.cuda.Event()
+            ev.record(cur)
+            _order_events[self.key] = (ev, cur, cap)
+        return False
 
 
 def grad_sink(p: Tensor) -> Optional[Tensor]:
     """p.grad when the kernels can accumulate straight into it (f32, contiguous, on the GPU)"""
+    if p is None or not p.is_leaf:
+        return None
     g = p.grad
     if g is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous():
         p.__dict__["_cy_touched"] = True  # read by FusedRAdam: this parameter received a gradient
@@ -281,11 +369,13 @@ def conv3x3_wgrad(src1: Tensor, src2: Optional[Tensor], dy: Tensor, *, mode: int
     Cout, H, W = dy.shape[1], dy.shape[2], dy.shape[3]
     dt = dtype_code(src1.dtype)
     d = _desc(N, H, W, C1, C2, Cout, mode, 1 if scale is not None else 0, dt, C1, C2, Cout)
-    nbytes = _lib.load().cy_conv3x3_wgrad_ws_bytes(C.byref(d))
+    if d.wgrad_ws is None:
+        d.wgrad_ws = _lib.load().cy_conv3x3_wgrad_ws_bytes(d.ref)
+    nbytes = d.wgrad_ws
     ws = _ws(nbytes, src1.device)
     dw = out if out is not None else torch.empty((Cout, C1 + C2, 3, 3), dtype=torch.float32, device=src1.device)
     ev = _prof_begin()
-    _lib.call("cy_conv3x3_wgrad", C.byref(d), src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
+    _lib.call("cy_conv3x3_wgrad", d.ref, src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
               dy.data_ptr(), dw.data_ptr(), 0 if out is None else 1, ws.data_ptr(), nbytes, _stream())
     if ev is not None:
         esz = src1.element_size()
@@ -330,10 +420,17 @@ def bn_finalize(partials: Optional[Tensor], count: int, gamma: Optional[Tensor],
                 eps: float, use_batch_stats: bool, update_running: bool, Cc: int, device):
     out = _f32(4 * Cc, device).view(4, Cc)
     npart = 0 if partials is None else partials.shape[0]
-    _lib.call("cy_bn_finalize", _ptr(partials), npart, Cc, float(count), _ptr(gamma), _ptr(beta),
-              _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
-              int(use_batch_stats), int(update_running), out[0].data_ptr(), out[1].data_ptr(),
-              out[2].data_ptr(), out[3].data_ptr(), _stream())
+    def launch():
+        _lib.call("cy_bn_finalize", _ptr(partials), npart, Cc, float(count), _ptr(gamma), _ptr(beta),
+                  _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
+                  int(use_batch_stats), int(update_running), out[0].data_ptr(), out[1].data_ptr(),
+                  out[2].data_ptr(), out[3].data_ptr(), _stream())
+
+    if running_mean is not None and (update_running or not use_batch_stats):
+        with ordered(("bn_running", running_mean.data_ptr())):  # reads or updates the running statistics
+            launch()
+    else:
+        launch()
     return out[0], out[1], out[2], out[3]  # scale, shift, mean, invstd
 
 
@@ -374,9 +471,16 @@ def bn_relu_bwd(da: Tensor, y: Tensor, scale: Tensor, shift: Tensor, mean: Tenso
         pg, pb = dgamma, dbeta
     else:
         pg = pb = None
-    _lib.call("cy_bn_bwd_finalize", part.data_ptr(), npart, Cc, scale.data_ptr(), mean.data_ptr(),
-              invstd.data_ptr(), float(npix), int(batch_stats), _ptr(pg), _ptr(pb), int(acc), coef.data_ptr(),
-              _stream())
+    def finalize():
+        _lib.call("cy_bn_bwd_finalize", part.data_ptr(), npart, Cc, scale.data_ptr(), mean.data_ptr(),
+                  invstd.data_ptr(), float(npix), int(batch_stats), _ptr(pg), _ptr(pb), int(acc), coef.data_ptr(),
+                  _stream())
+
+    if acc:
+        with ordered(("bn_grad", pg.data_ptr())):  # in-place accumulation into the parameters' .grad
+            finalize()
+    else:
+        finalize()
     dy = empty_nhwc(N, Cc, H, W, y.dtype, dev)
     _lib.call("cy_bn_relu_bwd_apply", da.data_ptr(), Cc, y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
               coef.data_ptr(), dy.data_ptr(), npix, Cc, dt, _stream())

@@ -23,6 +23,7 @@ from torch import Tensor, nn
 from contrastyou.epochers.base import EpocherBase as _EpocherBase
 from contrastyou.meters import AverageValueMeter, MeterInterface, UniversalDice
 from contrastyou.utils.general import class2one_hot
+from cyhip import graphed, ops
 from contrastyou.utils.utils import (class_name, disable_tracking_bn_stats, get_dataset, get_lrs_from_optimizer,
                                      get_model)
 from semi_seg.augment import AffineAugment
@@ -245,6 +246,8 @@ class SemiSupervisedEpocher(EpocherBase):
     def _forward_pass(self, labeled_image, unlabeled_image, unlabeled_image_tf):
         n_l, n_unl = len(labeled_image), len(unlabeled_image)
         if self._two_stage:
+            if ops.TWO_STREAM and labeled_image.is_cuda:
+                return self._forward_two_streams(labeled_image, unlabeled_image, unlabeled_image_tf)
             label_logits = self._model(labeled_image)
             with self._bn_context(self._model):
                 unlabeled_logits, unlabeled_tf_logits = torch.split(
@@ -252,6 +255,36 @@ class SemiSupervisedEpocher(EpocherBase):
             return label_logits, unlabeled_logits, unlabeled_tf_logits
         logits = self._model(torch.cat([labeled_image, unlabeled_image, unlabeled_image_tf], dim=0))
         return torch.split(logits, [n_l, n_unl, n_unl], dim=0)
+
+    def _forward_two_streams(self, labeled_image, unlabeled_image, unlabeled_image_tf):
+        """The two passes of the two-stage forward are independent networks evaluations (epocher.py:
+        351-357) and neither fills the GPU at these batch sizes, so the unlabeled pass is enqueued on
+        a second stream and overlaps with the labeled pass (autograd replays each pass's backward on
+        its own stream, so the backward passes overlap too).  Order-sensitive shared state -- BN
+        running statistics and batch counters, accumulated BN gradients -- is serialised in the
+        reference's order (labeled pass first) by cyhip.ops.ordered; `CY_TWO_STREAM=0` disables."""
+        n_unl = len(unlabeled_image)
+        dev = labeled_image.device
+        xb = torch.cat([unlabeled_image, unlabeled_image_tf], dim=0)
+        if hasattr(self._model, "arch_elements"):
+            # both passes, forward and backward, as HIP graphs (the step is host-bound): cyhip/graphed.py
+            res = graphed.two_pass(self._model, self._bn_context, labeled_image, xb, self._disable_bn,
+                                   self._autocast_dtype if self.use_mixed_train else None)
+            if res is not None:
+                label_logits, both = res
+                unlabeled_logits, unlabeled_tf_logits = torch.split(both, [n_unl, n_unl], dim=0)
+                return label_logits, unlabeled_logits, unlabeled_tf_logits
+        main = torch.cuda.current_stream(dev)
+        side = ops.side_stream(dev, "pass2")
+        side.wait_stream(main)  # inputs, zeroed gradients, the previous step's optimizer update
+        ops.note_side_work(side)
+        label_logits = self._model(labeled_image)
+        with torch.cuda.stream(side), self._bn_context(self._model):
+            both = self._model(xb)
+        main.wait_stream(side)
+        both.record_stream(main)
+        unlabeled_logits, unlabeled_tf_logits = torch.split(both, [n_unl, n_unl], dim=0)
+        return label_logits, unlabeled_logits, unlabeled_tf_logits
 
     @property
     def _bn_context(self):

@@ -246,3 +246,58 @@ def test_semi_trainer_two_epochs_schedule_checkpoint_resume(tmp_path):
         tr2.start_training()  # runs epoch 3
     assert tr2._cur_epoch == 3
     assert len((tmp_path / "storage.csv").read_text().strip().splitlines()) == 4
+
+
+def test_hip_graph_replay_of_the_two_passes_equals_eager_steps():
+    """cyhip.graphed: step 1 probes gradient flow eagerly, step 2 captures, steps 3-4 replay; weights,
+    BN statistics and meters after four steps must equal four eager steps from the same state"""
+    from contrastyou.amp import BF16Scaler
+    from contrastyou.arch import UNet
+    from contrastyou.hooks.base import TrainerHook
+    from contrastyou.losses.kl import KL_div
+    from contrastyou.optim import RAdam
+    from cyhip import graphed
+    from oracle import unet as ou
+    from semi_seg.epochers import SemiSupervisedEpocher
+    from semi_seg.hooks import create_consistency_hook, create_infonce_hooks
+    from contrastyou.hooks.base import CombineTrainerHook
+
+    g = torch.Generator().manual_seed(21)
+    n, hw, steps = 4, 32, 4
+    sd0 = ou.init_state_dict(1, 4, 128, seed=14)
+    lab = [blob_batch(n, hw, 4, g) for _ in range(steps)]
+    unl = [blob_batch(n, hw, 4, g) for _ in range(steps)]
+
+    def run(use_graph: bool):
+        graphed.GRAPH_STEP = use_graph
+        type(TrainerHook).names.clear()
+        model = UNet(input_dim=1, num_classes=4, max_channel=128, momentum=0.1)
+        model.load_state_dict(sd0)
+        model.to(DEV)
+        torch.manual_seed(3)
+        hook = CombineTrainerHook(
+            create_infonce_hooks(model=model, feature_names="Conv5", weights=1.0, contrast_ons="partition",
+                                 spatial_size=1, data_name="acdc"),
+            create_consistency_hook(weight=0.5)).to(DEV)
+        opt = RAdam([{"params": list(model.parameters())}, {"params": list(hook.parameters())}], lr=3e-3,
+                    weight_decay=1e-4)
+        ep = SemiSupervisedEpocher(model=model, optimizer=opt, labeled_loader=Loader(lab), unlabeled_loader=Loader(unl),
+                                   sup_criterion=KL_div(), num_batches=steps, cur_epoch=0, device=DEV, two_stage=True,
+                                   disable_bn=False, scaler=BF16Scaler(), accumulate_iter=1)
+        ep.init()
+        random.seed(9)
+        with ep.register_hook(hook()):
+            ep.run()
+        torch.cuda.synchronize()
+        replayed = any(isinstance(v, graphed.GraphedTwoPass) for v in model.__dict__.get("_cy_graphed", {}).values())
+        return {k: v.detach().float().cpu() for k, v in model.state_dict().items()}, ep.get_metric(), replayed
+
+    try:
+        sd_e, m_e, rep_e = run(False)
+        sd_g, m_g, rep_g = run(True)
+    finally:
+        graphed.GRAPH_STEP = False
+    assert rep_g and not rep_e, "the second run must have captured and replayed the passes"
+    for k in sd_e:  # same kernels in the same order on the same data: equal to the last bit
+        assert torch.equal(sd_e[k], sd_g[k]), k
+    assert m_e["semi"]["sup_loss"] == m_g["semi"]["sup_loss"] and m_e["semi"]["reg_loss"] == m_g["semi"]["reg_loss"]

@@ -30,3 +30,4 @@ bench.run_epoch(ctx, dev, 10, 2)
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)
