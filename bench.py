@@ -110,15 +110,17 @@ def kernel_roofline(ctx, device, steps: int = 3):
     region overlaps weight-gradient kernels with the rest of the backward pass on a second stream;
     a kernel's roofline fraction is a property of the kernel, so this pass runs the same step with
     every launch on ONE stream (an overlapped kernel's begin-to-end time includes its neighbour's
-    share of the CUs).  The committed rocprofv3 stats use the same setting (CY_ASYNC_WGRAD=0)."""
+    share of the CUs).  The committed rocprofv3 stats use the same setting
+    (CY_ASYNC_WGRAD=0 CY_TWO_STREAM=0)."""
     from cyhip import ops
     ops.PROFILE = []
-    was_async, ops.ASYNC_WGRAD = ops.ASYNC_WGRAD, False
+    was = (ops.ASYNC_WGRAD, ops.TWO_STREAM)
+    ops.ASYNC_WGRAD = ops.TWO_STREAM = False
     try:
         run_epoch(ctx, device, steps, 99)
         torch.cuda.synchronize()
     finally:
-        ops.ASYNC_WGRAD = was_async
+        ops.ASYNC_WGRAD, ops.TWO_STREAM = was
     rec, ops.PROFILE = ops.PROFILE, None
     fam, fam_bytes = {}, {}
     for kind, flops, e0, e1, *rest in rec:
