@@ -194,8 +194,8 @@ def cpu_baseline(hw: int, max_channel: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--n-labeled", type=int, default=16)
     ap.add_argument("--n-unlabeled", type=int, default=16)
     ap.add_argument("--hw", type=int, default=224)

@@ -18,6 +18,8 @@
 // 16-byte NHWC chunks after a wave-private LDS transpose.
 #include "cy_conv_tile.h"
 
+#include <cstdlib>
+
 namespace {
 
 template <typename T, typename TO, int TH, int TW, int BN, int WGM, int WGN, int PITCHB, bool ALLT>
@@ -509,6 +511,10 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes) {
     Z = cy_cdiv(384, blocks);
     if (Z > ncc) Z = ncc;
     if (Z > 8) Z = 8;
+  }
+  if (const char* ov = getenv("CY_KSPLIT")) {  // tuning override (tools/bench_layers.py)
+    const int z = atoi(ov);
+    if (z >= 1 && Cout % 8 == 0) Z = z > ncc ? ncc : z;
   }
   p.ksplit = Z;
   long fb = (npix + 63) / 64;
