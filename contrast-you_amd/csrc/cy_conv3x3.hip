@@ -251,22 +251,34 @@ __global__ void __launch_bounds__(256, 2)
 
   // ---------------- epilogue ----------------
   if (a.ksplit > 1) {
-    // raw f32 partial sums; conv_splitk_finish_kernel adds the splits, rounds, stores, takes stats
+    // raw f32 partial sums; conv_splitk_finish_kernel adds the splits, rounds, stores, takes stats.
+    // Same wave-private LDS transpose as the final epilogue below, so that a lane stores 16 bytes
+    // (4 couts of one pixel) instead of 16 scattered dwords per accumulator.
     float* wsz = a.ws + (size_t)blockIdx.z * ((size_t)a.NH * a.W) * a.Cout;
+    float* scr = reinterpret_cast<float*>(smem) + wave * (32 * 36);
 #pragma unroll
     for (int n = 0; n < N_REP; ++n) {
-      const int co = n0 + (wn * N_REP + n) * 32 + r;
+      const int cobase = n0 + (wn * N_REP + n) * 32;
 #pragma unroll
       for (int m = 0; m < M_REP; ++m) {
         const int ibase = (wm * M_REP + m) * 32;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int i = ibase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        for (int reg = 0; reg < 16; ++reg)
+          scr[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 36 + r] = acc[m][n][reg];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int itx = 0; itx < 4; ++itx) {
+          const int idx = lane + itx * 64;
+          const int pix = idx >> 3, cch = idx & 7;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(scr + pix * 36 + cch * 4);
+          const int i = ibase + pix;
           const int ty = i / TW, tx = i - ty * TW;
           const int R = R0 + ty, w = w0 + tx;
+          const int co = cobase + cch * 4;
           if (R < a.NH && w < a.W && co < a.Cout)
-            wsz[((size_t)R * a.W + w) * a.Cout + co] = acc[m][n][reg];
+            *reinterpret_cast<f32x4*>(wsz + ((size_t)R * a.W + w) * a.Cout + co) = v;
         }
+        __builtin_amdgcn_wave_barrier();
       }
     }
     return;
@@ -517,7 +529,7 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes) {
     if (z >= 1 && Cout % 8 == 0) Z = z > ncc ? ncc : z;
   }
   p.ksplit = Z;
-  long fb = (npix + 63) / 64;
+  long fb = (npix + 15) / 16;  // split-K layers are small (<= 12.5k pixels): many short workgroups
   if (fb > 1024) fb = 1024;
   p.finish_blocks = (int)fb;
   p.partials = Z > 1 ? p.finish_blocks : tiles;
