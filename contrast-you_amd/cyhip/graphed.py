@@ -24,7 +24,7 @@ autograd node that raises if a later loss does try to differentiate through them
 Conditions (checked per call; otherwise the eager two-stream path runs): every model parameter has
 a live f32 `.grad` buffer that the kernels accumulate into (FusedRAdam's flat buffers), so that no
 parameter gradient flows through autograd; bench instrumentation is off.  `CY_GRAPH_STEP=0`
-disables the capture.
+disables the capture; a failed capture warns once and training continues eagerly.
 """
 from __future__ import annotations
 
@@ -39,11 +39,10 @@ from torch import Tensor, nn
 from . import functions as F
 from . import ops
 
-# Opt-in (CY_GRAPH_STEP=1): on this round's kernels the replayed step takes 9.6 ms against 9.4 ms for
-# the eager two-stream step -- the GPU's own critical path (busy time 9.8 ms/step under rocprofv3) is
-# now as long as the host's issue time, so removing the host from the loop buys nothing until the
-# kernels get faster; from then on every kernel-side gain shows up only on the graph path.
-GRAPH_STEP = os.environ.get("CY_GRAPH_STEP", "0") == "1"
+# On by default (CY_GRAPH_STEP=0 turns it off): the eager two-stream step is host-bound at 9.2-9.5
+# ms/step and varies with the host; the replayed step is bound by the GPU's critical path (9.07 ms
+# with this round's kernels) and every kernel-side gain shows up on it directly.
+GRAPH_STEP = os.environ.get("CY_GRAPH_STEP", "1") != "0"
 
 
 class _TwoPass(nn.Module):

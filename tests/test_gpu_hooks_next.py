@@ -292,11 +292,12 @@ def test_hip_graph_replay_of_the_two_passes_equals_eager_steps():
         replayed = any(isinstance(v, graphed.GraphedTwoPass) for v in model.__dict__.get("_cy_graphed", {}).values())
         return {k: v.detach().float().cpu() for k, v in model.state_dict().items()}, ep.get_metric(), replayed
 
+    default = graphed.GRAPH_STEP
     try:
         sd_e, m_e, rep_e = run(False)
         sd_g, m_g, rep_g = run(True)
     finally:
-        graphed.GRAPH_STEP = False
+        graphed.GRAPH_STEP = default
     assert rep_g and not rep_e, "the second run must have captured and replayed the passes"
     for k in sd_e:  # same kernels in the same order on the same data: equal to the last bit
         assert torch.equal(sd_e[k], sd_g[k]), k
