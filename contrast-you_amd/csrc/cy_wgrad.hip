@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(256)
     first_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
                        float* __restrict__ ws, int N, int Cin, int H, int W, int Cout) {
   // thread = (pixel lane, group of 8 couts); accumulates 9 taps x 8 couts for one ci at a time
-  __shared__ float sred[256 * 8];
+  __shared__ float sred[4 * 9 * 64];  // [wave][tap][cout], Cout <= 64
   const int CG = Cout / 8;
   const int rows = 256 / CG;
   const int tid = threadIdx.x;
@@ -411,38 +411,53 @@ __global__ void __launch_bounds__(256)
         for (int j = 0; j < 8; ++j) acc[t][j] = fmaf(xv, d[j], acc[t][j]);
       }
     }
-    // block reduction over prow, one tap at a time
+    // block reduction over the pixel lanes: xor-shuffles across the lanes of a wave that share a
+    // cout group (CG is a power of two), then the four waves through LDS
+    const int wave = tid >> 6, lane = tid & 63;
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sred[tid * 8 + j] = acc[t][j];
-      __syncthreads();
-      if (tid < Cout) {
-        const int g = tid / 8, j = tid % 8;
-        float s = 0.f;
-        for (int q = 0; q < rows; ++q) s += sred[(q * CG + g) * 8 + j];
-        // ws[block][co][ci][tap]
-        ws[(((size_t)blockIdx.x * Cout + tid) * Cin + ci) * 9 + t] = s;
+      for (int j = 0; j < 8; ++j) {
+        float v = acc[t][j];
+        for (int o = CG; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        if (lane < CG) sred[((wave * 9 + t) * CG + lane) * 8 + j] = v;
       }
+    }
+    __syncthreads();
+    for (int e = tid; e < 9 * Cout; e += 256) {
+      const int t = e / Cout, co = e - t * Cout;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s += sred[((q * 9 + t) * CG + (co >> 3)) * 8 + (co & 7)];
+      // ws[block][co][ci][tap]
+      ws[(((size_t)blockIdx.x * Cout + co) * Cin + ci) * 9 + t] = s;
     }
   }
 }
 
+// dw[i] (+)= sum over the block partials: 4 outputs per workgroup, 64 slices each, fixed order
 __global__ void __launch_bounds__(256)
     first_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nblk,
                               int total, int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < total) {
-    float s = 0.f;
-    for (int q = 0; q < nblk; ++q) s += ws[(size_t)q * total + i];
-    dw[i] = accumulate ? dw[i] + s : s;
+  __shared__ float sr[64][4];
+  const int el = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const int i = blockIdx.x * 4 + el;
+  float s = 0.f;
+  if (i < total)
+    for (int q = sl; q < nblk; q += 64) s += ws[(size_t)q * total + i];
+  sr[sl][el] = s;
+  __syncthreads();
+  if (sl == 0 && i < total) {
+    float t = 0.f;
+    for (int q = 0; q < 64; ++q) t += sr[q][el];
+    dw[i] = accumulate ? dw[i] + t : t;
   }
 }
 
 int first_wgrad_blocks(long npix) {
   long b = (npix + 1023) / 1024;
-  if (b > 256) b = 256;
+  if (b > 1024) b = 1024;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -533,7 +548,7 @@ int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int accumu
     return CY_ERR_DTYPE;
   CY_CHECK_LAUNCH();
   const int total = Cout * Cin * 9;
-  hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(cy_cdiv(total, 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(cy_cdiv(total, 4)), dim3(256), 0, st,
                      (const float*)ws, dw, nblk, total, accumulate);
   CY_CHECK_LAUNCH();
   return CY_OK;
