@@ -1,8 +1,7 @@
-"""Architecture protocol + ordering helpers shared by hooks and trainers.
-
-Interface parity with contrastyou/arch/_base.py:8-84 of the reference (`_Network` protocol,
-`sort_arch`, `_check_params`, `_complete_arch_start2end`); the implementation here is a plain
-index lookup over `model.arch_elements`.
+"""Block-name arithmetic shared by hooks and trainers, and the protocol a segmentation network
+offers to them (the `_Network` protocol, `sort_arch`, `_check_params`, `_complete_arch_start2end`
+of contrastyou/arch/_base.py:8-84).  Everything reduces to the position of a name in
+`model.arch_elements`.
 """
 from __future__ import annotations
 
@@ -11,15 +10,49 @@ from typing import ContextManager, Dict, List, Optional, Protocol, Sequence
 from torch import nn
 
 
+def arch_order(name: str, *, model) -> int:
+    """0-based position of a block in the forward order of `model` (KeyError for unknown names)"""
+    order = list(model.arch_elements)
+    if name not in order:
+        raise KeyError(name)
+    return order.index(name)
+
+
+def sort_arch(name_list: List[str], reverse: bool = False, *, model) -> List[str]:
+    """`name_list` in forward order (or backward with reverse=True)"""
+    return sorted(name_list, key=lambda block: arch_order(block, model=model), reverse=reverse)
+
+
+def _complete_arch_start2end(start: str, end: str, include_start=True, include_end=True, *, model) -> List[str]:
+    """the blocks from `start` to `end` in forward order, ends included or not"""
+    first, last = arch_order(start, model=model), arch_order(end, model=model)
+    assert first <= last, (start, end)
+    first += 0 if include_start else 1
+    last -= 0 if include_end else 1
+    return list(model.arch_elements)[first: last + 1]
+
+
+def _check_params(start, end, include_start, include_end, *, model) -> None:
+    """argument validation of UNet.switch_grad / switch_bn_track: an open end must be inclusive,
+    names must exist, and `start` may not lie behind `end`"""
+    if start is None and not include_start:
+        raise ValueError("include_start should be True given start=None")
+    if end is None and not include_end:
+        raise ValueError("include_end should be True given end=None")
+    named = [v for v in (start, end) if isinstance(v, str)]
+    for block in named:
+        if block not in model.arch_elements:
+            raise ValueError(block)
+    if len(named) == 2 and arch_order(start, model=model) > arch_order(end, model=model):
+        raise ValueError((start, end))
+
+
 class _Network(Protocol):
+    """what hooks and trainers rely on (see contrastyou.arch.unet.UNet)"""
+    arch_elements: Sequence[str]                  # all block names in forward order
     encoder_names: Sequence[str]
     decoder_names: Sequence[str]
-    arch_elements: Sequence[str]
-    layer_dimension: Dict[str, Optional[int]]
-
-    def switch_grad(self, **kwargs) -> ContextManager: ...
-
-    def switch_bn_track(self, **kwargs) -> ContextManager: ...
+    layer_dimension: Dict[str, Optional[int]]     # channel multiplier per block
 
     @property
     def num_classes(self) -> int: ...
@@ -28,38 +61,6 @@ class _Network(Protocol):
 
     def get_module(self, name: str) -> nn.Module: ...
 
+    def switch_grad(self, **kwargs) -> ContextManager: ...
 
-def arch_order(name: str, *, model) -> int:
-    """position of a block name in model.arch_elements (KeyError if unknown)"""
-    try:
-        return list(model.arch_elements).index(name)
-    except ValueError:
-        raise KeyError(name) from None
-
-
-def sort_arch(name_list: List[str], reverse: bool = False, *, model) -> List[str]:
-    return sorted(name_list, key=lambda n: arch_order(n, model=model), reverse=reverse)
-
-
-def _check_params(start, end, include_start, include_end, *, model) -> None:
-    if start is None and include_start is False:
-        raise ValueError("include_start should be True given start=None")
-    if end is None and include_end is False:
-        raise ValueError("include_end should be True given end=None")
-    for v in (start, end):
-        if isinstance(v, str) and v not in model.arch_elements:
-            raise ValueError(v)
-    if isinstance(start, str) and isinstance(end, str):
-        if arch_order(start, model=model) > arch_order(end, model=model):
-            raise ValueError((start, end))
-
-
-def _complete_arch_start2end(start: str, end: str, include_start=True, include_end=True, *, model) -> List[str]:
-    """all block names between start and end in architecture order"""
-    lo, hi = arch_order(start, model=model), arch_order(end, model=model)
-    assert lo <= hi, (start, end)
-    if not include_start:
-        lo += 1
-    if not include_end:
-        hi -= 1
-    return list(model.arch_elements)[lo: hi + 1]
+    def switch_bn_track(self, **kwargs) -> ContextManager: ...

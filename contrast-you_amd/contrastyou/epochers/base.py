@@ -1,6 +1,11 @@
-"""`EpocherBase` (contrastyou/epochers/base.py:43-168): one epoch of work with meters, a progress
-indicator and per-epoch hooks.  Same constructor kwargs and lifecycle
-(`init()` -> `with register_hook(*hooks): run()` -> `get_metric()/get_score()`).
+"""`EpocherBase`: one epoch of work -- a model, a meter registry, a progress indicator and the
+per-epoch hooks (the role of contrastyou/epochers/base.py:43-168).  Life cycle, as in the reference:
+
+    epocher = SomeEpocher(model=..., num_batches=..., scaler=..., accumulate_iter=...)
+    epocher.init(trainer)                      # meters + indicator exist from here on
+    with epocher.register_hook(*epoch_hooks):  # optional
+        epocher.run()
+    epocher.get_metric(), epocher.get_score()
 """
 from __future__ import annotations
 
@@ -22,11 +27,12 @@ class TrainerNotSetError(Exception):
 
 
 class _Indicator:
-    """minimal stand-in for the reference's customised tqdm: iterates range(n) and remembers the
-    last statistics; prints nothing unless `verbose`."""
+    """what the epochers need from the reference's customised tqdm: iteration over the batch
+    indices, a description, the latest statistics; silent unless asked to be verbose"""
 
     def __init__(self, n: int, disable: bool = True):
-        self._n, self._disable, self._desc, self._last = n, disable, "", None
+        self._n, self._disable = n, disable
+        self._desc, self._last = "", None
 
     def __iter__(self):
         return iter(range(self._n))
@@ -37,58 +43,68 @@ class _Indicator:
     def set_postfix_statics2(self, report, force_update=False):
         self._last = report
 
+    def log_result(self):
+        if self._last is not None and not self._disable:
+            print(self._desc, dict(self._last))
+
     def close(self):
         pass
 
-    def log_result(self):
-        if not self._disable and self._last is not None:
-            print(self._desc, dict(self._last))
-
 
 class EpocherBase(AMPScaler, DDPMixin, metaclass=ABCMeta):
-    meter_focus = "tra"
+    meter_focus = "tra"  # name of the epocher's own meter group
 
     def __init__(self, *, model: nn.Module, num_batches: int, cur_epoch=0, device="cpu", scaler,
                  accumulate_iter: int, **kwargs) -> None:
         super().__init__(scaler=scaler, accumulate_iter=accumulate_iter)
-        self._initialized = False
         self._model = model
-        self._device = device if isinstance(device, torch.device) else torch.device(device)
-        self._num_batches = num_batches
-        self._cur_epoch = cur_epoch
+        self._device = torch.device(device)
+        self._num_batches, self._cur_epoch = num_batches, cur_epoch
         self._trainer = None
         self._hooks: List = []
-        self.meters = None
-        self.indicator = None
+        self._initialized = False
+        self.meters: MeterInterface = None  # type: ignore[assignment]
+        self.indicator: _Indicator = None   # type: ignore[assignment]
         self.verbose = False
 
+    # ---- read-only facts ------------------------------------------------------------------------
+    device = property(lambda self: self._device)
+    cur_epoch = property(lambda self: self._cur_epoch)
+    num_batches = property(lambda self: self._num_batches)
+
+    # ---- the owning trainer (held weakly) ---------------------------------------------------------
     @property
     def trainer(self):
-        if self._trainer is not None:
-            return self._trainer
-        raise TrainerNotSetError(f"{self.__class__.__name__} should call `set_trainer` first")
+        if self._trainer is None:
+            raise TrainerNotSetError(f"{self.__class__.__name__} should call `set_trainer` first")
+        return self._trainer
 
     @trainer.setter
     def trainer(self, trainer):
         self._trainer = weakref.proxy(trainer)
 
-    def set_trainer(self, trainer):
-        self._trainer = weakref.proxy(trainer)
+    set_trainer = trainer.fset
 
+    # ---- life cycle -------------------------------------------------------------------------------
     def init(self, trainer=None):
         self.meters = MeterInterface(default_focus=self.meter_focus)
         self.configure_meters(self.meters)
-        self.indicator = _Indicator(self._num_batches, disable=not (self.on_master and self.verbose))
-        self._initialized = True
+        self.indicator = _Indicator(self._num_batches, disable=not (self.verbose and self.on_master))
         if trainer is not None:
             self.trainer = trainer
+        self._initialized = True
+
+    @abstractmethod
+    def configure_meters(self, meters: MeterInterface) -> MeterInterface:
+        meters.register_meter("lr", AverageValueListMeter())
+        return meters
 
     @contextmanager
     def register_hook(self, *hook):
         assert self._initialized, f"{class_name(self)} must be initialized by calling {class_name(self)}.init()."
         for h in hook:
+            h.epocher = self  # wires meters and lets the hook register its own
             self._hooks.append(h)
-            h.epocher = self
         yield
         self.close_hook()
 
@@ -97,44 +113,28 @@ class EpocherBase(AMPScaler, DDPMixin, metaclass=ABCMeta):
             h.close()
 
     @abstractmethod
-    def configure_meters(self, meters: MeterInterface) -> MeterInterface:
-        meters.register_meter("lr", AverageValueListMeter())
-        return meters
-
-    @abstractmethod
     def _run(self, **kwargs):
         raise NotImplementedError()
 
     def run(self, **kwargs):
         self.to(self.device)
         self.indicator.set_desc_from_epocher(self)
-        with self.meters:
+        with self.meters:  # reset on entry, join on exit
             result = self._run(**kwargs)
         self.indicator.close()
         self.indicator.log_result()
         return result
 
+    def to(self, device: Union[torch.device, str] = torch.device("cpu")):
+        device = torch.device(device)
+        for member in vars(self).values():
+            if isinstance(member, nn.Module):
+                member.to(device)
+        self._device = device
+
+    # ---- results ----------------------------------------------------------------------------------
     def get_metric(self) -> Dict[str, Dict[str, float]]:
         return dict(self.meters.statistics())
 
     def get_score(self) -> float:
         raise NotImplementedError()
-
-    def to(self, device: Union[torch.device, str] = torch.device("cpu")):
-        device = torch.device(device) if isinstance(device, str) else device
-        for m in self.__dict__.values():
-            if isinstance(m, nn.Module):
-                m.to(device)
-        self._device = device
-
-    @property
-    def device(self):
-        return self._device
-
-    @property
-    def cur_epoch(self):
-        return self._cur_epoch
-
-    @property
-    def num_batches(self):
-        return self._num_batches

@@ -1,61 +1,80 @@
-"""Running averages (contrastyou/meters/averagemeter.py).  Values may be 0-dim DEVICE tensors:
-they are accumulated on the device and only read back in summary(), so adding a loss does not
-force a host sync per batch (the reference calls `.item()` at every add)."""
+"""Running means (the meters of contrastyou/meters/averagemeter.py).
+
+Difference from the reference: a value may be a 0-dim DEVICE tensor.  It is then accumulated on the
+device (f64) and read back only when `summary()` is called, so metering a loss does not force a host
+synchronisation per batch (the reference calls `.item()` on every add).
+"""
 from __future__ import annotations
 
-import typing as t
-from collections import defaultdict
+import math
+from typing import Dict, Iterable
 
-import numpy as np
 import torch
 
 from .metric import Metric
 
 
+def _as_accumulable(v):
+    """python number stays; a tensor becomes a detached 0-dim f64 (or integer) tensor"""
+    if not isinstance(v, torch.Tensor):
+        return v
+    v = v.detach()
+    if v.dim() > 0:
+        v = v.reshape(-1)[0]
+    return v.double() if v.is_floating_point() else v
+
+
 class AverageValueMeter(Metric):
+    """weighted running mean of scalars"""
+
     def __init__(self):
         super().__init__()
-        self.reset()
+        self.sum, self.n = 0, 0
 
     def reset(self):
-        self.sum = 0
-        self.n = 0
+        self.sum, self.n = 0, 0
 
     def _add(self, value, n=1):
-        if isinstance(value, torch.Tensor):
-            value = value.detach()
-            if value.dim():
-                value = value.reshape(-1)[0]
-            value = value.double() if value.is_floating_point() else value
-        self.sum = self.sum + value * n
+        self.sum = self.sum + _as_accumulable(value) * n
         self.n += n
 
-    def _summary(self):
+    def _summary(self) -> float:
         if self.n == 0:
-            return np.nan
-        s = self.sum
-        return float(s.item() / self.n) if isinstance(s, torch.Tensor) else float(s / self.n)
+            return math.nan
+        total = self.sum.item() if isinstance(self.sum, torch.Tensor) else self.sum
+        return float(total / self.n)
 
 
 class AverageValueDictionaryMeter(Metric):
+    """one running mean per keyword"""
+
     def __init__(self) -> None:
         super().__init__()
-        self._meter_dicts: t.Dict[str, AverageValueMeter] = defaultdict(AverageValueMeter)
+        self._meter_dicts: Dict[str, AverageValueMeter] = {}
+
+    def _slot(self, key: str) -> AverageValueMeter:
+        m = self._meter_dicts.get(key)
+        if m is None:
+            m = self._meter_dicts[key] = AverageValueMeter()
+        return m
 
     def reset(self):
-        for v in self._meter_dicts.values():
-            v.reset()
+        for m in self._meter_dicts.values():
+            m.reset()
 
-    def _add(self, **kwargs):
-        for k, v in kwargs.items():
-            self._meter_dicts[k].add(v)
+    def _add(self, **named):
+        for key, value in named.items():
+            self._slot(key).add(value)
 
     def _summary(self):
-        return {k: v.summary() for k, v in self._meter_dicts.items()}
+        return {key: m.summary() for key, m in self._meter_dicts.items()}
 
 
 class AverageValueListMeter(AverageValueDictionaryMeter):
-    def _add(self, list_value: t.Iterable[float] = None, **kwargs):
-        assert isinstance(list_value, t.Iterable)
-        for i, v in enumerate(list_value):
-            self._meter_dicts[str(i)].add(v)
+    """one running mean per list position (e.g. the learning rate of every parameter group)"""
+
+    def _add(self, list_value: Iterable[float] = None, **_):
+        if not isinstance(list_value, Iterable):
+            raise TypeError(f"expected an iterable of values, got {type(list_value).__name__}")
+        for position, value in enumerate(list_value):
+            self._slot(str(position)).add(value)

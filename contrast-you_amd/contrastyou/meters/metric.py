@@ -1,39 +1,35 @@
-"""Metric base class (contrastyou/meters/metric.py of the reference)."""
+"""The meter protocol used by MeterInterface: `add` feeds a meter, `summary` reports it, `reset`
+clears it, `join`/`close` are life-cycle no-ops by default (interface of the reference's
+contrastyou/meters/metric.py).  Concrete meters fill in `reset`, `_add` and `_summary`."""
 from __future__ import annotations
 
-import typing as t
-from abc import abstractmethod
 
-RETURN_TYPE = t.TypeVar("RETURN_TYPE")
+class Metric:
 
+    def __init__(self, **_unused) -> None:
+        self.__armed = True  # a subclass that forgets super().__init__() is caught on first use
 
-class Metric(t.Generic[RETURN_TYPE]):
-    _initialized = False
-
-    def __init__(self, **kwargs) -> None:
-        self._initialized = True
-
-    @abstractmethod
+    # -- to be provided by concrete meters --------------------------------------------------
     def reset(self):
-        ...
+        raise NotImplementedError(type(self).__name__ + ".reset")
 
-    def add(self, *args, **kwargs):
-        assert self._initialized, f"{self.__class__.__name__} must be initialized by overriding __init__"
-        return self._add(*args, **kwargs)
+    def _add(self, *values, **named):
+        raise NotImplementedError(type(self).__name__ + "._add")
 
-    @abstractmethod
-    def _add(self, *args, **kwargs):
-        ...
+    def _summary(self):
+        raise NotImplementedError(type(self).__name__ + "._summary")
 
-    def summary(self) -> RETURN_TYPE:
+    # -- public surface ---------------------------------------------------------------------
+    def add(self, *values, **named):
+        if not getattr(self, "_Metric__armed", False):
+            raise AssertionError(f"{type(self).__name__}.__init__ must call Metric.__init__")
+        return self._add(*values, **named)
+
+    def summary(self):
         return self._summary()
 
-    @abstractmethod
-    def _summary(self) -> RETURN_TYPE:
-        ...
-
     def join(self):
-        return
+        """hook for meters that collect from worker processes; nothing to do here"""
 
     def close(self):
-        return
+        """release resources; nothing to do here"""

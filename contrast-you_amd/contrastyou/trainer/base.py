@@ -1,27 +1,33 @@
-"""`Trainer`: owns model, optimizer, scheduler and trainer hooks; runs
-`tra_epoch -> eval_epoch(val) -> eval_epoch(test) -> scheduler.step -> save last/best` per epoch.
+"""`Trainer`: the epoch loop around the epochers.
 
-Interface parity with contrastyou/trainer/base.py:27-191 (+ _hooks.py, _io.py, _amp.py, _ddp.py):
-same constructor kwargs, `register_hook` (context manager, must precede `init()`), `init()`,
-`start_training()`, `tra_epoch()/eval_epoch()`, `save_to()/load_state_dict_from_path()/
-resume_from_path()`, `inference_model`/`switch_inference_model`, and the checkpoint schema
-{"module_state": {"_model.*", "_hooks.N.*"}, "buffer_state": {_save_dir, _max_epoch, _num_batches,
-config, _cur_epoch, _start_epoch, _best_score}, "other_state": {_optimizer, _scheduler, scaler,
-_storage}} so `last.pth`/`best.pth` interchange with the reference.
+It owns the model, the optimizer built from `config["Optim"]` (model parameters in group 0, the
+registered hooks' parameters in group 1), the warm-up + cosine schedule built from
+`config["Scheduler"]`, the trainer hooks, a per-epoch csv `Storage`, and the checkpoint files:
 
-Build-side differences: the optimizer named in config["Optim"] resolves in `contrastyou.optim`
-(RAdam = FusedRAdam over flat buffers); the scaler is `BF16Scaler` when `enable_scale` (bf16
-autocast, nothing to scale) and a disabled GradScaler otherwise; the tensorboard writer is
-optional (absent in this image) and metrics always go to `Storage` (csv per epoch).
+    trainer = SomeTrainer(model=..., criterion=..., config=..., save_dir=..., ...)
+    with trainer.register_hook(*hooks):          # must come before init()
+        trainer.init()
+        trainer.resume_from_path(ckpt_dir)       # optional
+        trainer.start_training()                 # per epoch: train, eval val/test, lr step, last/best.pth
+
+Interface and checkpoint layout follow the reference (contrastyou/trainer/base.py:27-191 with its
+_hooks / _io / _amp / _ddp mixins): a checkpoint is
+`{"module_state": {"_model.*", "_inference_model.*", "_hooks.N.*"}, "buffer_state": {_save_dir,
+_max_epoch, _num_batches, config, _cur_epoch, _start_epoch, _best_score}, "other_state":
+{_optimizer, _scheduler, scaler, _storage}}`.
+
+Build-side choices: optimizer names resolve in `contrastyou.optim` (RAdam = the fused flat-buffer
+RAdam); `enable_scale=True` means bf16 autocast with a pass-through scaler (`BF16Scaler`), False a
+disabled GradScaler; there is no tensorboard writer (not installed here) -- metrics always go to
+`storage.csv`; checkpoints are read with `torch.load(weights_only=True)`.
 """
 from __future__ import annotations
 
 import os
 from abc import abstractmethod
 from contextlib import contextmanager, nullcontext
-from itertools import chain
 from pathlib import Path
-from typing import Any, Dict, Optional
+from typing import Any, Dict, List, Optional
 
 import torch
 from torch import nn
@@ -35,61 +41,79 @@ from ..nn import Buffer, ModuleBase
 from ..optim import GradualWarmupScheduler
 from ._utils import safe_save
 
-_OPTIM_SKIP = ("name", "pre_lr", "ft_lr")
+_NOT_OPTIMIZER_ARGS = {"name", "pre_lr", "ft_lr"}  # keys of config["Optim"] that are not constructor kwargs
+_CKPT_SUFFIXES = (".pth", ".pt")
+
+
+def _plain(obj):
+    """nested mappings / sequences -> plain dicts / lists of python scalars, so that the stored config
+    is yaml-dumpable and loadable with weights_only=True whatever config class produced it"""
+    if obj is None or isinstance(obj, (bool, int, float, str)):
+        return obj
+    if hasattr(obj, "items"):
+        return {str(k): _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_plain(v) for v in obj]
+    return obj.item() if hasattr(obj, "item") else str(obj)
 
 
 class Trainer(DDPMixin, ModuleBase):
     RUN_PATH = os.environ.get("CONTRASTYOU_RUN_PATH", str(Path.cwd() / "runs"))
-    activate_hooks = True
+    activate_hooks = True  # FineTune-style trainers switch the hooks off
 
     def __init__(self, *, model: nn.Module, criterion, tra_loader, val_loader, save_dir: str, max_epoch: int = 100,
                  num_batches: int = 100, device="cpu", config: Dict[str, Any], enable_scale: bool = False,
                  accumulate_iter: int = 1, **kwargs) -> None:
         super().__init__()
-        self._initialized = False
-        self._hooks = nn.ModuleList()
+        # modules (checkpointed under module_state)
         self._model = self._inference_model = model
+        self._hooks = nn.ModuleList()
+        # plain references
         self.register_non_trackable_buffer("_criterion", criterion)
-        self._tra_loader = tra_loader
-        self._val_loader = val_loader
+        self._tra_loader, self._val_loader = tra_loader, val_loader
+        self._device, self._config = device, config
+        # persistent python state (checkpointed under buffer_state)
         self._save_dir = Buffer(str(save_dir))
         self._max_epoch = Buffer(int(max_epoch))
         self._num_batches = Buffer(int(num_batches))
-        self._device = device
         self.config = Buffer(_plain(config))
-        self._config = config
-
-        self._enable_scale = enable_scale
-        self._accumulate_iter = accumulate_iter
-        self.scaler = BF16Scaler() if enable_scale else torch.amp.GradScaler("cuda", enabled=False)
-
-        if config is not None:
-            self.dump_config(self._persist_buffer["config"])
-        self._storage = Storage(save_dir=self.save_dir)
-        self._writer = None  # tensorboard is optional; see contrastyou.writer in the reference
-
-        self._optimizer = None
-        self._scheduler = None
         self._cur_epoch = Buffer(0)
         self._start_epoch = Buffer(0)
         self._best_score = Buffer(0.0)
+        # objects with their own state_dict (checkpointed under other_state)
+        self.scaler = BF16Scaler() if enable_scale else torch.amp.GradScaler("cuda", enabled=False)
+        self._storage = Storage(save_dir=self.save_dir)
+        self._optimizer: Optional[torch.optim.Optimizer] = None
+        self._scheduler: Optional[GradualWarmupScheduler] = None
+        self._writer = None
+        self._enable_scale, self._accumulate_iter = enable_scale, accumulate_iter
+        self._initialized = False
+        if config is not None:
+            self.dump_config(self._persist_buffer["config"])
 
-    # ---- hooks (trainer/_hooks.py:21-42) ----------------------------------------------------
+    device = property(lambda self: self._device)
+    save_dir = property(lambda self: str(self._save_dir))
+    absolute_save_dir = property(lambda self: str(self._save_dir))
+    relative_save_dir = property(lambda self: str(Path(str(self._save_dir)).relative_to(self.RUN_PATH)))
+    success = property(lambda self: ".success" in os.listdir(str(self._save_dir)))
+    inference_model = property(lambda self: self._inference_model)
+
+    # ======================================================================== hooks + set-up
     @contextmanager
     def register_hook(self, *hook: TrainerHook):
+        """adopt trainer hooks; their parameters join the optimizer built by the following init()"""
         if self._initialized:
             raise RuntimeError("`register_hook must be called before `init()``")
         for h in hook:
-            self._hooks.append(h)
             h.to(self.device)
             h.register_trainer(self)
+            self._hooks.append(h)
         for h in self._hooks:
             h.after_initialize()
         yield
         for h in hook:
             h.close()
 
-    # ---- optimizer / scheduler (trainer/base.py:59-89) --------------------------------------
     def init(self):
         if self._initialized:
             raise RuntimeError(f"{self.__class__.__name__} has been initialized.")
@@ -98,24 +122,24 @@ class Trainer(DDPMixin, ModuleBase):
         self._initialized = True
 
     def _init_optimizer(self) -> torch.optim.Optimizer:
-        params = self._config["Optim"]
-        kw = {k: v for k, v in params.items() if k not in _OPTIM_SKIP}
-        optimizer = optim.__dict__[params["name"]](
-            params=[p for p in self._model.parameters() if p.requires_grad], **kw)
-        hook_params = list(chain(*(x.parameters() for x in self._hooks)))
+        spec = self._config["Optim"]
+        kwargs = {k: v for k, v in spec.items() if k not in _NOT_OPTIMIZER_ARGS}
+        factory = getattr(optim, spec["name"])
+        optimizer = factory(params=[p for p in self._model.parameters() if p.requires_grad], **kwargs)
+        hook_params: List[nn.Parameter] = [p for h in self._hooks for p in h.parameters()]
         if hook_params:
-            optimizer.add_param_group({"params": hook_params, **kw})
+            optimizer.add_param_group(dict(params=hook_params, **kwargs))
         return optimizer
 
     def _init_scheduler(self, optimizer, scheduler_params) -> Optional[GradualWarmupScheduler]:
         if scheduler_params is None:
             return None
-        cosine = torch.optim.lr_scheduler.CosineAnnealingLR(
-            optimizer, T_max=self._max_epoch - int(scheduler_params["warmup_max"]), eta_min=1e-7)
-        return GradualWarmupScheduler(optimizer, scheduler_params["multiplier"],
-                                      total_epoch=scheduler_params["warmup_max"], after_scheduler=cosine)
+        warmup = int(scheduler_params["warmup_max"])
+        cosine = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=self._max_epoch - warmup, eta_min=1e-7)
+        return GradualWarmupScheduler(optimizer, scheduler_params["multiplier"], total_epoch=warmup,
+                                      after_scheduler=cosine)
 
-    # ---- the epoch loop (trainer/base.py:91-125) --------------------------------------------
+    # ======================================================================== the epoch loop
     def start_training(self, **kwargs):
         if not self._initialized:
             raise RuntimeError(f"{self.__class__.__name__} should call `init()` first")
@@ -125,57 +149,50 @@ class Trainer(DDPMixin, ModuleBase):
             Path(self.absolute_save_dir, ".success").touch()
 
     def _start_training(self, **kwargs):
-        start_epoch = max(self._cur_epoch + 1, self._start_epoch)
-        for self._cur_epoch in range(start_epoch, self._max_epoch + 1):
-            cur_score = 0.0
-            with self._storage:
+        first = max(self._cur_epoch + 1, self._start_epoch)
+        for self._cur_epoch in range(first, self._max_epoch + 1):
+            score, improved = 0.0, False
+            with self._storage:  # writes storage.csv when the block ends
                 train_metrics = self.tra_epoch()
                 if self.on_master:
-                    eval_metrics, cur_score = self.eval_epoch(model=self.inference_model, loader=self._val_loader)
+                    eval_metrics, score = self.eval_epoch(model=self.inference_model, loader=self._val_loader)
                     test_metrics, _ = self.eval_epoch(model=self.inference_model, loader=self._test_loader)
                     self._storage.add_from_meter_interface(tra=train_metrics, val=eval_metrics, test=test_metrics,
                                                            epoch=self._cur_epoch)
                 if self._scheduler is not None:
                     self._scheduler.step()
-                best_case_sofa = self._best_score < cur_score
-                if best_case_sofa:
-                    self._best_score = cur_score
+                if score > self._best_score:
+                    self._best_score, improved = score, True
             if self.on_master:
                 self.save_to(save_name="last.pth")
-                if best_case_sofa:
+                if improved:
                     self.save_to(save_name="best.pth")
 
     def tra_epoch(self, **kwargs):
-        epocher = self._create_initialized_tra_epoch(**kwargs)
-        return self._run_tra_epoch(epocher)
-
-    def _run_tra_epoch(self, epocher: EpocherBase):
-        use_hook = self.activate_hooks and len(self._hooks) > 0
-        with epocher.register_hook(*[h() for h in self._hooks]) if use_hook else nullcontext():
-            epocher.run()
-        return epocher.get_metric()
-
-    @abstractmethod
-    def _create_initialized_tra_epoch(self, **kwargs) -> EpocherBase:
-        ...
+        return self._run_tra_epoch(self._create_initialized_tra_epoch(**kwargs))
 
     def eval_epoch(self, *, model, loader, **kwargs):
-        epocher = self._create_initialized_eval_epoch(model=model, loader=loader, **kwargs)
-        return self._run_eval_epoch(epocher)
+        return self._run_eval_epoch(self._create_initialized_eval_epoch(model=model, loader=loader, **kwargs))
 
-    @abstractmethod
-    def _create_initialized_eval_epoch(self, *, model, loader, **kwargs) -> EpocherBase:
-        ...
+    def _run_tra_epoch(self, epocher: EpocherBase):
+        epoch_hooks = [h() for h in self._hooks] if (self.activate_hooks and len(self._hooks) > 0) else []
+        with epocher.register_hook(*epoch_hooks) if epoch_hooks else nullcontext():
+            epocher.run()
+        return epocher.get_metric()
 
     def _run_eval_epoch(self, epocher):
         epocher.run()
         return epocher.get_metric(), epocher.get_score()
 
-    # ---- inference model switch (trainer/base.py:155-169) -----------------------------------
-    @property
-    def inference_model(self):
-        return self._inference_model
+    @abstractmethod
+    def _create_initialized_tra_epoch(self, **kwargs) -> EpocherBase:
+        ...
 
+    @abstractmethod
+    def _create_initialized_eval_epoch(self, *, model, loader, **kwargs) -> EpocherBase:
+        ...
+
+    # ---- which model is evaluated (mean teacher evaluates the teacher) -----------------------------
     def set_model4inference(self, model: nn.Module):
         self._inference_model = model
 
@@ -188,69 +205,37 @@ class Trainer(DDPMixin, ModuleBase):
         finally:
             self.set_model4inference(previous)
 
-    # ---- io (trainer/_io.py:24-68) ----------------------------------------------------------
-    def load_state_dict_from_path(self, path: str, name="last.pth", strict=True) -> None:
-        path_ = Path(path)
-        assert path_.exists(), path
-        if path_.is_dir() and (path_ / name).exists():
-            path_ = path_ / name
-        elif not (path_.is_file() and path_.suffix in (".pth", ".pt")):
-            raise FileNotFoundError(path_)
-        state_dict = torch.load(str(path_), map_location="cpu", weights_only=True)
-        self.load_state_dict(state_dict, strict)
-
+    # ======================================================================== files
     def save_to(self, *, save_dir: str = None, save_name: str):
-        assert Path(save_name).suffix in (".pth", ".pt"), save_name
-        save_dir_ = Path(save_dir or self.save_dir)
-        save_dir_.mkdir(parents=True, exist_ok=True)
-        safe_save(self.state_dict(), str(save_dir_ / save_name))
+        assert Path(save_name).suffix in _CKPT_SUFFIXES, save_name
+        target = Path(save_dir or self.save_dir)
+        target.mkdir(parents=True, exist_ok=True)
+        safe_save(self.state_dict(), str(target / save_name))
 
-    def resume_from_checkpoint(self, checkpoint: Dict[str, Dict], strict=True):
-        self.load_state_dict(checkpoint, strict=strict)
+    def load_state_dict_from_path(self, path: str, name="last.pth", strict=True) -> None:
+        where = Path(path)
+        assert where.exists(), path
+        if where.is_dir():
+            where = where / name
+        if not (where.is_file() and where.suffix in _CKPT_SUFFIXES):
+            raise FileNotFoundError(where)
+        self.load_state_dict(torch.load(str(where), map_location="cpu", weights_only=True), strict)
 
     def resume_from_path(self, path: str, name="last.pth", strict=True):
         return self.load_state_dict_from_path(str(path), name, strict)
 
+    def resume_from_checkpoint(self, checkpoint: Dict[str, Dict], strict=True):
+        self.load_state_dict(checkpoint, strict=strict)
+
     def dump_config(self, config, path=None, save_name="config.yaml"):
+        """write the config next to the checkpoints; a second run in the same directory gets
+        config_<k>.yaml instead of overwriting"""
         import yaml
-        path_ = Path(path) if path else Path(self.save_dir)
-        if not path_.is_absolute():
-            path_ = Path(self.RUN_PATH) / path_
-        path_.mkdir(parents=True, exist_ok=True)
-        if (path_ / save_name).exists():
-            save_name = f"{save_name.split('.')[0]}_{len(sorted(path_.glob('*.yaml')))}.yaml"
-        with open(path_ / save_name, "w") as f:
+        folder = Path(path) if path else Path(self.save_dir)
+        if not folder.is_absolute():
+            folder = Path(self.RUN_PATH) / folder
+        folder.mkdir(parents=True, exist_ok=True)
+        if (folder / save_name).exists():
+            save_name = f"{Path(save_name).stem}_{len(list(folder.glob('*.yaml')))}.yaml"
+        with open(folder / save_name, "w") as f:
             yaml.safe_dump(_plain(config), f)
-
-    @property
-    def save_dir(self) -> str:
-        return str(self._save_dir)
-
-    @property
-    def absolute_save_dir(self) -> str:
-        return self.save_dir
-
-    @property
-    def relative_save_dir(self):
-        return str(Path(self.absolute_save_dir).relative_to(self.RUN_PATH))
-
-    @property
-    def success(self):
-        return ".success" in os.listdir(self.absolute_save_dir)
-
-    @property
-    def device(self):
-        return self._device
-
-
-def _plain(obj):
-    """nested mappings/sequences -> plain dict/list of python scalars (yaml- and weights_only-safe)"""
-    if obj is None or isinstance(obj, (bool, int, float, str)):
-        return obj
-    if hasattr(obj, "items"):
-        return {str(k): _plain(v) for k, v in obj.items()}
-    if isinstance(obj, (list, tuple)):
-        return [_plain(v) for v in obj]
-    if hasattr(obj, "item"):
-        return obj.item()
-    return str(obj)
