@@ -156,6 +156,7 @@ class ConvChainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout: Tensor):
+        ops.ensure_backward_join()
         cfg, nconv, dt = ctx.cfg, ctx.nconv, ctx.dt
         t = list(ctx.saved_tensors)
         x1 = t.pop(0)

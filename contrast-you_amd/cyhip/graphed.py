@@ -39,8 +39,8 @@ from torch import Tensor, nn
 from . import functions as F
 from . import ops
 
-# On by default (CY_GRAPH_STEP=0 turns it off): the eager two-stream step is host-bound at 9.2-9.5
-# ms/step and varies with the host; the replayed step is bound by the GPU's critical path (9.07 ms
+# On by default (CY_GRAPH_STEP=0 turns it off): the eager three-stream step is host-bound at 9.2-9.5
+# ms/step and varies with the host; the replayed step is bound by the GPU's critical path (8.5 ms
 # with this round's kernels) and every kernel-side gain shows up on it directly.
 GRAPH_STEP = os.environ.get("CY_GRAPH_STEP", "1") != "0"
 
@@ -64,12 +64,17 @@ class _TwoPass(nn.Module):
         handles = [self.model.get_module(n).register_forward_hook(lambda m, i, o: grabbed.append(o))
                    for n in self._taps]
         try:
-            side.wait_stream(main)
-            ops.note_side_work(side)
-            ya = self.model(xa)
-            with torch.cuda.stream(side), self._bn_context(self.model):
-                yb = self.model(xb)
-            main.wait_stream(side)
+            if ops.TWO_STREAM:
+                side.wait_stream(main)
+                ops.note_side_work(side)
+                ya = self.model(xa)
+                with torch.cuda.stream(side), self._bn_context(self.model):
+                    yb = self.model(xb)
+                main.wait_stream(side)
+            else:
+                ya = self.model(xa)
+                with self._bn_context(self.model):
+                    yb = self.model(xb)
         finally:
             for h in handles:
                 h.remove()
@@ -131,6 +136,10 @@ class GraphedTwoPass:
         for p in params:
             p.__dict__["_cy_touched"] = False
         ops.CAPTURING = True
+        # inside a graph the weight-gradient kernels stay on their pass's branch: the runtime overlaps
+        # the two long pass branches well, but per-layer forks to a third branch cost more in
+        # dependency edges than they overlap (8.5 vs 9.1 ms/step, same box)
+        async_wgrad, ops.ASYNC_WGRAD = ops.ASYNC_WGRAD, False
         F.bump_weights_epoch()  # the weight packing kernels must be part of the captured forward
         try:
             ctx = (torch.autocast("cuda", dtype=autocast_dtype, cache_enabled=False) if autocast_dtype is not None
@@ -140,6 +149,7 @@ class GraphedTwoPass:
             self._touched = [p for p in params if p.__dict__.get("_cy_touched")]
         finally:
             ops.CAPTURING = False
+            ops.ASYNC_WGRAD = async_wgrad
             F.bump_weights_epoch()
             for n, hooks in stash.items():
                 model.get_module(n)._forward_hooks = hooks
@@ -175,6 +185,7 @@ def _key(model: nn.Module, xa: Tensor, xb: Tensor, disable_bn: bool, autocast_dt
     req = tuple(p.requires_grad for p in model.parameters())
     return (tuple(xa.shape), tuple(xb.shape), xa.dtype, xb.dtype, p0.data_ptr(),
             p0.grad.data_ptr() if p0.grad is not None else 0, tuple(_tapped_blocks(model)), flags, req,
+            ops.TWO_STREAM,
             bool(disable_bn), model.training, autocast_dtype, getattr(model, "compute_dtype", None))
 
 
@@ -202,7 +213,7 @@ def two_pass(model: nn.Module, bn_context, xa: Tensor, xb: Tensor, disable_bn: b
     """the two passes of the step: graph replay when a capture for this configuration exists, an eager
     two-stream probe step before that; None when capture is not applicable (the caller runs eagerly)"""
     global _failed
-    if not GRAPH_STEP or _failed or ops.PROFILE is not None or not ops.ASYNC_WGRAD or not ops.TWO_STREAM:
+    if not GRAPH_STEP or _failed or ops.PROFILE is not None:
         return None
     if not _sinks_ready(model) or not torch.is_grad_enabled():
         return None

@@ -281,6 +281,18 @@ class on_side_stream:
 _join_queued = False
 
 
+def ensure_backward_join() -> None:
+    """called by backward nodes: if auxiliary streams carry work of this step (second-pass stream,
+    weight-gradient stream), make sure they are joined when the backward pass ends"""
+    global _join_queued
+    if _side_pending and not _join_queued:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_after_backward)
+            _join_queued = True
+        except RuntimeError:
+            pass
+
+
 def _join_after_backward() -> None:
     global _join_queued
     _join_queued = False

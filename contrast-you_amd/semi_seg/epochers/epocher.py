@@ -219,7 +219,7 @@ class SemiSupervisedEpocher(EpocherBase):
             logits = self._model(torch.cat([labeled_image, unlabeled_image, unlabeled_image_tf], dim=0))
             return torch.split(logits, [n_l, n_unl, n_unl], dim=0)
         views = torch.cat([unlabeled_image, unlabeled_image_tf], dim=0)
-        if ops.TWO_STREAM and labeled_image.is_cuda:
+        if (ops.TWO_STREAM or graphed.GRAPH_STEP) and labeled_image.is_cuda:
             label_logits, both = self._forward_two_streams(labeled_image, views)
         else:
             label_logits = self._model(labeled_image)
@@ -241,6 +241,10 @@ class SemiSupervisedEpocher(EpocherBase):
                                         self._autocast_dtype if self.use_mixed_train else None)
             if replayed is not None:
                 return replayed
+        if not ops.TWO_STREAM:
+            label_logits = self._model(labeled_image)
+            with self._bn_context(self._model):
+                return label_logits, self._model(views)
         dev = labeled_image.device
         main, side = torch.cuda.current_stream(dev), ops.side_stream(dev, "pass2")
         side.wait_stream(main)  # inputs, zeroed gradients, the previous step's optimizer update
