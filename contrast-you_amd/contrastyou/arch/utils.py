@@ -116,6 +116,22 @@ class SingleFeatureExtractor:
             raise RuntimeError("no feature has been recorded.")
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
+    def tail(self, rows: int) -> torch.Tensor:
+        """`feature()[-rows:]`, built from the last recordings alone when they hold exactly `rows`
+        rows (the unlabeled pass of a two-stage step): earlier recordings are then neither copied nor
+        tied into the autograd graph of the result"""
+        outs = self._collector.feature
+        if not outs:
+            raise RuntimeError("no feature has been recorded.")
+        have, first = 0, len(outs)
+        while first > 0 and have < rows:
+            first -= 1
+            have += outs[first].shape[0]
+        if have != rows:
+            return self.feature()[-rows:]
+        picked = outs[first:]
+        return picked[0] if len(picked) == 1 else torch.cat(picked, dim=0)
+
 
 class FeatureExtractor:
     """several taps driven together; iterating yields their features in the order of the names"""

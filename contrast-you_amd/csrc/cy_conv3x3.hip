@@ -683,8 +683,15 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------
 extern "C" {
 
-int cy_abi_version(void) { return 4; }
+int cy_abi_version(void) { return 5; }
 const char* cy_build_arch(void) { return "gfx950"; }
+
+unsigned long long cy_stream_capture_id(void* stream) {
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo((hipStream_t)stream, &status, &id) != hipSuccess) return 0;
+  return status == hipStreamCaptureStatusActive ? (id ? id : 1ull) : 0ull;
+}
 
 int cy_conv3x3_packed_dims(int Cout, int Cin, int* co_pad, int* ci_pad) {
   if (Cout <= 0 || Cin <= 0) return CY_ERR_ARG;

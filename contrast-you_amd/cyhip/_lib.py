@@ -11,7 +11,7 @@ from pathlib import Path
 
 CY_F32, CY_BF16 = 0, 1
 CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2 = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _ERRORS = {-1: "CY_ERR_ARG (bad/NULL argument)", -2: "CY_ERR_SHAPE (unsupported shape)",
            -3: "CY_ERR_DTYPE (unsupported dtype)", -4: "CY_ERR_LAUNCH (HIP launch failed)",
@@ -42,6 +42,7 @@ _PCD = POINTER(ConvDesc)
 _SIGS = {
     "cy_abi_version": (c_int, []),
     "cy_build_arch": (c_char_p, []),
+    "cy_stream_capture_id": (C.c_ulonglong, [_P]),
     "cy_conv3x3_packed_dims": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "cy_conv3x3_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "cy_conv3x3_num_partials": (c_int, [_PCD]),

@@ -58,13 +58,15 @@ def packed_weights(w: Tensor, dtype: torch.dtype):
     hit = cache.get(dtype)
     cur = torch.cuda.current_stream(w.device)
     if hit is not None and hit[0] == tag:
-        if hit[4] != cur:  # packed on another stream (two-stream forward, side-stream wgrad): wait for it
+        # packed on another stream (two-stream forward, side-stream wgrad): wait for it -- unless the
+        # event belongs to another graph capture (captures are fenced by full synchronisation)
+        if hit[4] != cur and hit[5] == ops._capture_id(cur):
             cur.wait_event(hit[3])
         return hit[1], hit[2]
     wf, wd = ops.pack_weights(w, dtype, want_dgrad=True)
     ev = torch.cuda.Event()
     ev.record(cur)
-    cache[dtype] = (tag, wf, wd, ev, cur)
+    cache[dtype] = (tag, wf, wd, ev, cur, ops._capture_id(cur))
     return wf, wd
 
 

@@ -128,11 +128,8 @@ class GraphedTwoPass:
         self._wrapper.train(model.training)
         params = [p for p in model.parameters() if p.requires_grad]
         state = {k: v.clone() for k, v in model.state_dict().items()}
-        stash = OrderedDict()
-        for n in self.taps:  # the real taps must not see warm-up / capture tensors
-            m = model.get_module(n)
-            stash[n] = m._forward_hooks
-            m._forward_hooks = OrderedDict()
+        silence = _silenced_taps(model, self.taps)  # the real taps must not see warm-up / capture tensors
+        silence.__enter__()
         for p in params:
             p.__dict__["_cy_touched"] = False
         ops.CAPTURING = True
@@ -151,8 +148,7 @@ class GraphedTwoPass:
             ops.CAPTURING = False
             ops.ASYNC_WGRAD = async_wgrad
             F.bump_weights_epoch()
-            for n, hooks in stash.items():
-                model.get_module(n)._forward_hooks = hooks
+            silence.__exit__()
             # warm-up and capture ran the passes for real (also when the capture failed half-way): put
             # running statistics / counters back and drop the garbage gradients they accumulated
             torch.cuda.synchronize()
@@ -169,14 +165,36 @@ class GraphedTwoPass:
         ya, yb, feats = out[0], out[1], out[2:]
         for p in self._touched:  # what ops.grad_sink does on the eager path
             p.__dict__["_cy_touched"] = True
-        k = len(self.taps)
-        for pass_idx in range(2):  # fire the registered taps in the eager order: pass A blocks, then pass B
-            for j, n in enumerate(self.taps):
-                m = self.model.get_module(n)
-                o = feats[pass_idx * k + j]
-                for hook in list(m._forward_hooks.values()):
-                    hook(m, (None,), o)
+        _fire_taps(self.model, self.taps, feats)
         return ya, yb
+
+
+def _fire_taps(model: nn.Module, taps: List[str], feats) -> None:
+    """hand the tapped blocks' outputs to the registered forward hooks in the eager order: the blocks
+    of the labeled pass, then those of the unlabeled pass"""
+    k = len(taps)
+    for pass_idx in range(2):
+        for j, n in enumerate(taps):
+            m = model.get_module(n)
+            for hook in list(m._forward_hooks.values()):
+                hook(m, (None,), feats[pass_idx * k + j])
+
+
+class _silenced_taps:
+    """`with _silenced_taps(model, taps):` -- the registered forward hooks of the tapped blocks see nothing"""
+
+    def __init__(self, model: nn.Module, taps: List[str]):
+        self.blocks = [model.get_module(n) for n in taps]
+
+    def __enter__(self):
+        self.stash = [m._forward_hooks for m in self.blocks]
+        for m in self.blocks:
+            m._forward_hooks = OrderedDict()
+
+    def __exit__(self, *exc):
+        for m, hooks in zip(self.blocks, self.stash):
+            m._forward_hooks = hooks
+        return False
 
 
 def _key(model: nn.Module, xa: Tensor, xb: Tensor, disable_bn: bool, autocast_dtype) -> tuple:
@@ -237,9 +255,15 @@ def two_pass(model: nn.Module, bn_context, xa: Tensor, xb: Tensor, disable_bn: b
     # probe step: the eager two-stream passes, with gradient-flow detection on every output
     taps = _tapped_blocks(model)
     ops.note_home_stream(xa.device)
-    outs = _TwoPass(model, taps, bn_context)(xa, xb)
+    with _silenced_taps(model, taps):
+        outs = _TwoPass(model, taps, bn_context)(xa, xb)
+    # the hooks get aliases of the tapped outputs: a gradient arriving at an alias came from a hook,
+    # not from the network's own path through that block (which every tapped block of a pass that is
+    # differentiated at all would otherwise report)
+    outs = outs[:2] + tuple(o.view_as(o) for o in outs[2:])
     probe = _Probe(len(outs))
     probe.watch(outs)
+    _fire_taps(model, taps, outs[2:])
     if len(cache) > 4:
         cache.clear()
     cache[key] = probe

@@ -343,9 +343,9 @@ class ordered:
             rec = _order_events.get(self.key)
             if rec is not None:
                 cur = torch.cuda.current_stream()
-                # an event recorded outside a graph capture cannot be waited on inside one (and vice
-                # versa); captures are fenced by full stream synchronisation, so skipping is safe
-                if rec[1] != cur and rec[2] == torch.cuda.is_current_stream_capturing():
+                # an event recorded outside a graph capture cannot be waited on inside one, nor one of
+                # another capture; captures are fenced by full stream synchronisation, so skipping is safe
+                if rec[1] != cur and rec[2] == _capture_id(cur):
                     cur.wait_event(rec[0])
         return self
 
@@ -353,11 +353,18 @@ class ordered:
         if _multi_stream_live:
             rec = _order_events.get(self.key)
             cur = torch.cuda.current_stream()
-            cap = torch.cuda.is_current_stream_capturing()
+            cap = _capture_id(cur)
             ev = rec[0] if (rec is not None and rec[2] == cap) else torch.cuda.Event()
             ev.record(cur)
             _order_events[self.key] = (ev, cur, cap)
         return False
+
+
+def _capture_id(stream) -> int:
+    """0 outside HIP-graph capture, else the id of the capture `stream` belongs to"""
+    if not torch.cuda.is_current_stream_capturing():
+        return 0
+    return int(_lib.load().cy_stream_capture_id(stream.cuda_stream))
 
 
 def grad_sink(p: Tensor) -> Optional[Tensor]:

@@ -53,7 +53,7 @@ class _DiscreteMIEpochHook(EpocherHook):
 
     def _call_implementation(self, *, unlabeled_image, unlabeled_image_tf, affine_transformer, **kwargs):
         n_unl = len(unlabeled_image)
-        plain, transformed = torch.chunk(self._extractor.feature()[-2 * n_unl:], 2, dim=0)
+        plain, transformed = torch.chunk(self._extractor.tail(2 * n_unl), 2, dim=0)
         assert plain.shape == transformed.shape
         both_views = torch.cat([affine_transformer(plain), transformed], dim=0)
         terms = [self._criterion(*torch.chunk(prob, 2, dim=0)) for prob in self._projector(both_views)]

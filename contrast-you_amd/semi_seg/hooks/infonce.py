@@ -130,7 +130,7 @@ class _INFONCEEpochHook(EpocherHook):
     def _call_implementation(self, *, affine_transformer, seed, unlabeled_tf_logits, unlabeled_logits_tf,
                              partition_group, label_group, **kwargs):
         n_unl = len(unlabeled_logits_tf)
-        feature_ = self._extractor.feature()[-n_unl * 2:]
+        feature_ = self._extractor.tail(n_unl * 2)
         unlabeled_features, unlabeled_tf_features = torch.chunk(feature_, 2, dim=0)
         unlabeled_features_tf = affine_transformer(unlabeled_features)
         norm_features_tf, norm_tf_features = torch.chunk(
@@ -167,7 +167,7 @@ class _INFONCEDenseHook(_INFONCEEpochHook):
     def _call_implementation(self, *, affine_transformer, seed, unlabeled_tf_logits, unlabeled_logits_tf,
                              partition_group, label_group, **kwargs):
         n_unl = len(unlabeled_logits_tf)
-        feature_ = self._extractor.feature()[-n_unl * 2:]
+        feature_ = self._extractor.tail(n_unl * 2)
         unlabeled_features, unlabeled_tf_features = torch.chunk(feature_, 2, dim=0)
         unlabeled_features_tf = affine_transformer(unlabeled_features, seed=seed)
         sh, sw = self._projector._spatial_size

@@ -47,6 +47,10 @@ extern "C" {
 int cy_abi_version(void);
 /* name of the offload arch the library was built for ("gfx950"). */
 const char* cy_build_arch(void);
+/* id of the HIP-graph capture `stream` currently belongs to, 0 when it is not capturing.  Host-side
+ * only (hipStreamGetCaptureInfo): lets the binding tell apart events recorded in different captures
+ * (an event recorded inside one capture must not be waited on inside another). */
+unsigned long long cy_stream_capture_id(void* stream);
 
 /* ------------------------------------------------------------------------
  * 3x3 convolution, stride 1, pad 1, no bias  (nn.Conv2d at

@@ -282,3 +282,34 @@ def test_trainer_checkpoint_schema_and_resume(tmp_path):
     assert (tmp_path / "config.yaml").exists() and (tmp_path / "config_1.yaml").exists()
     with pytest.raises(NotImplementedError):
         trainer_zoo["mixup"]()
+
+
+def test_feature_tap_tail_equals_the_slice_of_the_concatenation():
+    """SingleFeatureExtractor.tail(rows) == feature()[-rows:], without touching earlier recordings
+    when the boundary falls between two recordings"""
+    import torch
+    from torch import nn
+    from contrastyou.arch.utils import SingleFeatureExtractor
+
+    class Net(nn.Module):
+        arch_elements = ("blk",)
+
+        def __init__(self):
+            super().__init__()
+            self.blk = nn.Linear(3, 2)
+
+        def get_module(self, name):
+            return getattr(self, name)
+
+        def forward(self, x):
+            return self.blk(x)
+
+    net = Net()
+    with SingleFeatureExtractor(net, "blk") as tap:
+        tap.set_enable(True)
+        a, b = net(torch.randn(2, 3)), net(torch.randn(4, 3))
+        full = tap.feature()
+        assert torch.equal(tap.tail(4), full[-4:]) and tap.tail(4) is b
+        assert torch.equal(tap.tail(3), full[-3:]) and torch.equal(tap.tail(6), full)
+        tap.tail(4).sum().backward()
+        assert a.grad_fn is not None and net.blk.weight.grad is not None
