@@ -16,6 +16,7 @@
 // sum-of-squares partials for the following BatchNorm (deterministic: one
 // partial per tile, fixed-order reduction in cy_bn_finalize) and stores
 // 16-byte NHWC chunks after a wave-private LDS transpose.
+#include "cy_conv_plane.h"
 #include "cy_conv_tile.h"
 
 #include <cstdlib>
@@ -500,7 +501,19 @@ TileChoice choose_tile(long NH, int W, int Cout) {
   return c;
 }
 
+// The plane kernel (cy_conv_plane.h) tiles the image in 16 x 14 outputs.  CY_CONV_PLANE=0 keeps
+// every layer on conv3x3_igemm_kernel (A/B measurements).
+bool use_plane_kernel(int W) {
+  static const bool enabled = [] {
+    const char* e = getenv("CY_CONV_PLANE");
+    return !(e && e[0] == '0');
+  }();
+  return enabled && W % 14 == 0;
+}
+constexpr int kPlaneTH = 16, kPlaneTW = 14;
+
 struct ConvPlan {
+  bool plane;
   TileChoice tile;
   int ksplit;         // >1: split-K over input-channel chunks + finish kernel
   int finish_blocks;  // blocks (= stat partials) of the finish kernel
@@ -512,8 +525,13 @@ struct ConvPlan {
 // the reduction over input-channel chunks across blockIdx.z.
 ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes) {
   ConvPlan p;
+  p.plane = use_plane_kernel(W);
   p.tile = choose_tile((long)N * H, W, Cout);
   const long npix = (long)N * H * W;
+  if (p.plane) {
+    p.tile.th = kPlaneTH, p.tile.tw = kPlaneTW;
+    p.tile.bn = Cout >= 128 ? 128 : (Cout > 32 ? 64 : 32);
+  }
   const int tiles = cy_cdiv((long)N * H, p.tile.th) * cy_cdiv(W, p.tile.tw);
   const int blocks = tiles * cy_cdiv(Cout, p.tile.bn);
   const int kc = (p.tile.bn <= 64 ? 64 : 128) / elem_bytes;  // must match dispatch_conv's PITCHB
@@ -551,8 +569,13 @@ int launch_finish(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
 }
 
 template <typename T>
-int dispatch_conv(const ConvArgs& a, hipStream_t st) {
-  const TileChoice c = choose_tile(a.NH, a.W, a.Cout);
+int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
+  if (p.plane) {
+    if (p.tile.bn == 128) return launch_conv_plane<T, kPlaneTH, 128, 2, 2, 128, false>(a, st);
+    if (p.tile.bn == 64) return launch_conv_plane<T, kPlaneTH, 64, 4, 1, 64, true>(a, st);
+    return launch_conv_plane<T, kPlaneTH, 32, 4, 1, 64, true>(a, st);
+  }
+  const TileChoice c = p.tile;
   // BN <= 64 (small-channel, HBM-leaning layers): 64-byte channel chunks, all nine weight taps
   // resident in LDS.  BN = 128: 128-byte chunks, weights through a 2-deep per-tap ring.
 #define CY_CONV_CASE(TH_, TW_, BN_, WGM_, WGN_, P_, ALLT_) \
@@ -775,7 +798,7 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
   a.ws = (float*)ws;
   if (p.ksplit > 1 && (!ws || ws_bytes < p.ws_bytes)) return CY_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  rc = d->in_dtype == CY_BF16 ? dispatch_conv<bf16>(a, st) : dispatch_conv<float>(a, st);
+  rc = d->in_dtype == CY_BF16 ? dispatch_conv<bf16>(a, p, st) : dispatch_conv<float>(a, p, st);
   if (rc != CY_OK || p.ksplit == 1) return rc;
   return d->in_dtype == CY_BF16 ? launch_finish<bf16>(a, p, st) : launch_finish<float>(a, p, st);
 }

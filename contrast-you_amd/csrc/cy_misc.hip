@@ -224,4 +224,16 @@ int cy_radam_step(float* param, const float* grad, float* exp_avg, float* exp_av
   return CY_OK;
 }
 
+// profiling aid: one thread writes the device's constant-rate wall clock (100 MHz) into buf[slot];
+// launched between the kernels of a stream (also inside a captured graph) it timestamps that point
+// of the stream on the GPU's own clock.  tools/step_timeline.py builds the step's timeline from it.
+static __global__ void stamp_kernel(unsigned long long* buf, int slot) { buf[slot] = wall_clock64(); }
+
+int cy_debug_stamp(unsigned long long* buf, int slot, void* stream) {
+  if (!buf || slot < 0) return CY_ERR_ARG;
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, buf, slot);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
 }  // extern "C"

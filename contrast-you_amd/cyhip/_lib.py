@@ -43,6 +43,7 @@ _SIGS = {
     "cy_abi_version": (c_int, []),
     "cy_build_arch": (c_char_p, []),
     "cy_stream_capture_id": (C.c_ulonglong, [_P]),
+    "cy_debug_stamp": (c_int, [_P, c_int, _P]),
     "cy_conv3x3_packed_dims": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "cy_conv3x3_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "cy_conv3x3_num_partials": (c_int, [_PCD]),

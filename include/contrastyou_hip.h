@@ -51,6 +51,9 @@ const char* cy_build_arch(void);
  * only (hipStreamGetCaptureInfo): lets the binding tell apart events recorded in different captures
  * (an event recorded inside one capture must not be waited on inside another). */
 unsigned long long cy_stream_capture_id(void* stream);
+/* profiling aid: a one-thread kernel on `stream` stores the device wall clock (100 MHz ticks) into
+ * buf[slot] (device memory); works inside a stream capture. */
+int cy_debug_stamp(unsigned long long* buf, int slot, void* stream);
 
 /* ------------------------------------------------------------------------
  * 3x3 convolution, stride 1, pad 1, no bias  (nn.Conv2d at

@@ -59,6 +59,14 @@ CONV_CASES = [
     (2, 14, 14, 32, 0, 32, 1, 0),     # generic masked 16x16 tile on 14x14, pool on load
     (1, 20, 20, 40, 24, 48, 0, 0),    # generic masked tile, odd channel counts, concat
     (2, 14, 14, 256, 0, 128, 0, 0),   # K = 4 chunks
+    # widths that are multiples of 14 run the plane kernel (cy_conv_plane.h, 16 x 14 tiles):
+    (2, 56, 56, 32, 0, 32, 0, 0),     # 32 couts, one chunk, weights of all taps resident
+    (1, 28, 28, 64, 64, 64, 0, 0),    # 64 couts, 4 chunks with register-prefetched halo, concat
+    (2, 28, 28, 16, 0, 8, 0, 0),      # tiny channels (padding paths)
+    (1, 28, 56, 128, 0, 64, 2, 0),    # upsample on load, non-square
+    (3, 14, 28, 64, 0, 48, 0, 1),     # tile spans images, rows not a multiple of 16, prologue
+    (1, 28, 28, 64, 0, 96, 1, 0),     # pool on load (staged synchronously), 96 couts
+    (5, 14, 14, 128, 128, 128, 0, 0), # 128 couts, concat, image borders inside every tile
 ]
 
 
