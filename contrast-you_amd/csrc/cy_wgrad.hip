@@ -20,6 +20,8 @@
 // pool / upsample / concat / BN+ReLU-prologue addressing is identical.
 #include "cy_conv_tile.h"
 
+#include <cstdlib>
+
 namespace {
 
 struct WgradArgs {
@@ -260,6 +262,274 @@ __global__ void __launch_bounds__(256, 2)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 weight gradient, twelve waves per workgroup (one workgroup per CU).
+//
+// wgrad_kernel above keeps all nine taps of a 32x32 (co,ci) block in one wave: 144 accumulator
+// registers, which leaves no room to keep a tile's worth of global loads in flight, so its staging
+// runs at ~1.8 TB/s and only overlaps with the MFMA phase through the CU's second workgroup.  Here a
+// wave owns ONE kernel row (dh) of a 32x32 block -- 48 accumulator registers -- and the workgroup is
+// (co blocks x ci blocks x pixel splits = 4) x 3 kernel rows = 12 waves, 3 per SIMD:
+//  * the next tile's dy rows and input halo are requested into registers before this tile's MFMAs
+//    (7-14 x 16 bytes per thread x 768 threads in flight) and written to the OTHER half of a
+//    double-buffered LDS image after them: one barrier per tile, global latency behind the MFMAs;
+//  * operand fragments are the same transposed LDS reads (ds_read_b64_tr_b16) as above.
+template <int WCO, int WCI, int WK>
+struct Wg12Cfg {
+  static constexpr int BCO = 32 * WCO, BCI = 32 * WCI;
+  static constexpr int PA = BCO * 2, PB = BCI * 2;  // dy / halo pixel pitch in bytes (bf16)
+  static constexpr int NT = 768;
+  static constexpr int MAXPIX = 256, HP = 36, MAXHALO = 360, MAXITEMS = 340;
+  static constexpr int A_BYTES = MAXPIX * PA, B_BYTES = MAXHALO * PB, BUF = A_BYTES + B_BYTES;
+  static constexpr int RED_BYTES = WK > 1 ? 12 * 1024 * 4 : 0;
+  static constexpr int MAIN = 2 * BUF > RED_BYTES ? 2 * BUF : RED_BYTES;
+  static constexpr int SMEM = MAIN + 256 * 4 + 16;
+  static constexpr int CPA = PA / 16, CPB = PB / 16;
+  static constexpr int NDY = (MAXPIX * CPA + NT - 1) / NT;     // dy items (16 B) per thread
+  static constexpr int NHL = (MAXITEMS * CPB + NT - 1) / NT;   // halo items per thread
+  static_assert(WCO * WCI * WK == 4, "4 x 3 waves");
+  static_assert(SMEM <= 160 * 1024, "LDS");
+};
+
+template <int WCO, int WCI, int WK>
+__global__ void __launch_bounds__(768, 1)
+    wgrad12_kernel(const WgradArgs g) {
+  using C = Wg12Cfg<WCO, WCI, WK>;
+  using T = bf16;
+  constexpr int PA = C::PA, PB = C::PB, CPA = C::CPA, CPB = C::CPB, NT = C::NT;
+  constexpr int EPC = 8;
+  constexpr int SWA = PA == 128 ? 2 : 0, SWB = PB == 128 ? 2 : 0;  // pair swizzle of 128-byte pixels
+  constexpr int HW2 = C::HP;
+  const ConvArgs& a = g.c;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* s_ktab = reinterpret_cast<int*>(smem + C::MAIN);  // tile pixel k -> halo pixel (ty+1)*HP + tx+1
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dh = wave % 3 - 1;
+  const int rest = wave / 3;
+  const int wk = rest % WK;
+  const int wci = (rest / WK) % WCI;
+  const int wco = rest / (WK * WCI);
+  const int r = lane & 31, h = lane >> 5;
+
+  const int TH = g.TH, TW = g.TW;
+  const int npix = TH * TW;
+  const int nsteps = (npix + 15) / 16;
+  const int npix_pad = nsteps * 16;
+  const int ci_tiles = g.ci_pad / C::BCI;
+  const int co_t = blockIdx.x / ci_tiles, ci_t = blockIdx.x % ci_tiles;
+  const int co0 = co_t * C::BCO, ci0 = ci_t * C::BCI;
+  const int split = blockIdx.y;
+  const int ntiles = g.tiles_h * g.tiles_w;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  if (tid < 256) {
+    const int kk = tid < npix ? tid : 0;
+    const int ty = kk / TW, tx = kk - ty * TW;
+    s_ktab[tid] = (ty + 1) * HW2 + tx + 1;
+  }
+
+  // ---- staging: request (global -> registers) / commit (registers -> LDS buffer) ----------------
+  // tiles never span images (TH | H): the image of a tile and its first row in it are uniform
+  const T* dyp = reinterpret_cast<const T*>(g.dy);
+  const T* s1 = reinterpret_cast<const T*>(a.src1);
+  const T* s2 = reinterpret_cast<const T*>(a.src2);
+  const int cha = tid % CPA, chb = tid % CPB;  // constant per thread (768 % CP* == 0)
+  const int HWt = TW + 2;
+  const int nhalo = (TH + 2) * HWt;
+  const int cabs = ci0 + chb * EPC;
+  const bool in2 = cabs >= a.C1;
+  const bool cvalid = cabs < a.C1 + a.C2;
+  const bool pooled = a.mode1 == CY_SRC_POOL2 && !in2;  // 2x2 max on load: staged in the commit phase
+  const bool pro = a.prologue && !in2 && cvalid;
+  float psc[EPC], psh[EPC];
+  if (pro) {
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      psc[j] = a.scale[cabs + j];
+      psh[j] = a.shift[cabs + j];
+    }
+  }
+  auto src_row = [&](int n, int hh) -> int {  // pixel index of (row hh of image n, column 0), or -1
+    if (hh < 0 || hh >= a.H) return -1;
+    if (in2 || a.mode1 == CY_SRC_DIRECT) return (n * a.H + hh) * a.W;
+    if (a.mode1 == CY_SRC_POOL2) return (n * 2 * a.H + 2 * hh) * (2 * a.W);
+    return (n * (a.H >> 1) + (hh >> 1)) * (a.W >> 1);
+  };
+  u32x4 dreg[C::NDY], hreg[C::NHL];
+  unsigned hok = 0;
+  auto request = [&](int tile) {
+    const int ct = tile % g.tiles_w, rt = tile / g.tiles_w;
+    const int R0 = rt * TH, w0 = ct * TW;
+    const int n = R0 / a.H, hh0 = R0 - n * a.H;
+    const int co = co0 + cha * EPC;
+#pragma unroll
+    for (int i = 0; i < C::NDY; ++i) {
+      const int k = (tid + i * NT) / CPA;
+      dreg[i] = u32x4{0u, 0u, 0u, 0u};
+      if (k < npix && co < a.Cout) {
+        const int ty = k / TW, tx = k - ty * TW;
+        const int w = w0 + tx;
+        if (w < a.W) dreg[i] = ld16(dyp + ((size_t)(R0 + ty) * a.W + w) * g.ldy + co);
+      }
+    }
+    hok = 0;
+    if (pooled) return;
+    const T* base = in2 ? s2 + (cabs - a.C1) : s1 + cabs;
+    const int ld = in2 ? a.ld2 : a.ld1;
+    const int wsh = (!in2 && a.mode1 == CY_SRC_UP2) ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < C::NHL; ++i) {
+      const int lin = (tid + i * NT) / CPB;
+      const int hr = lin / HWt, hc = lin - hr * HWt;
+      const int w = w0 - 1 + hc;
+      hreg[i] = u32x4{0u, 0u, 0u, 0u};
+      if (lin < nhalo && cvalid && w >= 0 && w < a.W) {
+        const int rp = src_row(n, hh0 - 1 + hr);
+        if (rp >= 0) {
+          hreg[i] = ld16(base + (size_t)(rp + (w >> wsh)) * ld);
+          hok |= 1u << i;
+        }
+      }
+    }
+  };
+  auto commit = [&](int tile, unsigned char* sDy, unsigned char* sIn) {
+#pragma unroll
+    for (int i = 0; i < C::NDY; ++i) {
+      const int k = (tid + i * NT) / CPA;
+      if (k < npix_pad) st16(sDy + k * PA + (halo_chunk<PA, SWA>(k, cha) << 4), dreg[i]);
+    }
+    if (pooled) {
+      const int ct = tile % g.tiles_w, rt = tile / g.tiles_w;
+      const int R0 = rt * TH, w0 = ct * TW;
+      const int n = R0 / a.H, hh0 = R0 - n * a.H;
+      for (int lin = tid / CPB; lin < nhalo; lin += NT / CPB) {
+        const int hr = lin / HWt, hc = lin - hr * HWt;
+        const int pix = hr * HW2 + hc;
+        const int w = w0 - 1 + hc;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        const int rp = src_row(n, hh0 - 1 + hr);
+        if (cvalid && w >= 0 && w < a.W && rp >= 0) {
+          const T* p = s1 + (size_t)(rp + 2 * w) * a.ld1 + cabs;
+          const size_t rowstep = (size_t)(2 * a.W) * a.ld1;
+          const u32x4 v00 = ld16(p), v01 = ld16(p + a.ld1), v10 = ld16(p + rowstep),
+                      v11 = ld16(p + rowstep + a.ld1);
+          float f0[EPC], f1[EPC], f2[EPC], f3[EPC];
+          Chunk<T>::unpack(v00, f0);
+          Chunk<T>::unpack(v01, f1);
+          Chunk<T>::unpack(v10, f2);
+          Chunk<T>::unpack(v11, f3);
+#pragma unroll
+          for (int j = 0; j < EPC; ++j) f0[j] = fmaxf(fmaxf(f0[j], f1[j]), fmaxf(f2[j], f3[j]));
+          v = Chunk<T>::pack(f0);
+        }
+        st16(sIn + pix * PB + (halo_chunk<PB, SWB>(pix, chb) << 4), v);
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < C::NHL; ++i) {
+      const int lin = (tid + i * NT) / CPB;
+      if (lin < nhalo) {
+        const int hr = lin / HWt, hc = lin - hr * HWt;
+        const int pix = hr * HW2 + hc;
+        u32x4 v = hreg[i];
+        if (pro && ((hok >> i) & 1u)) {
+          float f[EPC];
+          Chunk<T>::unpack(v, f);
+#pragma unroll
+          for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(psc[j], f[j], psh[j]), 0.f);
+          v = Chunk<T>::pack(f);
+        }
+        st16(sIn + pix * PB + (halo_chunk<PB, SWB>(pix, chb) << 4), v);
+      }
+    }
+  };
+
+  if (split < ntiles) {
+    request(split);
+    commit(split, smem, smem + C::A_BYTES);
+  }
+  __syncthreads();  // first tile staged, s_ktab published
+
+  // per-lane constants of the transposed fragment reads (see wgrad_kernel)
+  const int q = (lane & 15) >> 2, p4 = lane & 3, gsel = (lane >> 4) & 1;
+  const int acol0 = (wco * 32 + 16 * gsel + 4 * p4) * 2;
+  const int bcol0 = (wci * 32 + 16 * gsel + 4 * p4) * 2;
+  const int dhoff = dh * HW2 * PB;
+
+  int cur = 0;
+  for (int tile = split; tile < ntiles; tile += g.S, cur ^= 1) {
+    const int next = tile + g.S;
+    if (next < ntiles) request(next);
+    const unsigned char* sDy = smem + cur * C::BUF;
+    const unsigned char* sIn = sDy + C::A_BYTES;
+    for (int step = wk; step < nsteps; step += WK) {
+      const int k1 = step * 16 + 8 * h + q, k2 = k1 + 4;
+      // (k1 >> 1) & 1 == ((k1 + 4) >> 1) & 1: both rows share the swizzle term
+      const int acol = acol0 ^ (SWA == 2 ? (((k1 >> 1) & 1) << 6) : 0);
+      const unsigned char* a_lo = sDy + k1 * PA + acol;
+      const Mma<bf16>::Frag af = WFrag<bf16>::load(a_lo, a_lo + 4 * PA);
+      const int p1 = s_ktab[k1], p2 = s_ktab[k2];  // (pad pixels map to pixel 0; their dy rows are zero)
+      Mma<bf16>::Frag bfr[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        // the swizzle term of pixel p + dh*HW2 + dw depends on dw only (HW2 % 4 == 0)
+        const int c1 = bcol0 ^ (SWB == 2 ? ((((p1 + d - 1) >> 1) & 1) << 6) : 0);
+        const int c2 = bcol0 ^ (SWB == 2 ? ((((p2 + d - 1) >> 1) & 1) << 6) : 0);
+        bfr[d] = WFrag<bf16>::load(sIn + (p1 + d - 1) * PB + dhoff + c1, sIn + (p2 + d - 1) * PB + dhoff + c2);
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) Mma<bf16>::mma(af, bfr[d], acc[d]);
+    }
+    if (next < ntiles) commit(next, smem + (cur ^ 1) * C::BUF, smem + (cur ^ 1) * C::BUF + C::A_BYTES);
+    __syncthreads();  // this tile consumed by every wave, the next one staged
+  }
+
+  // ---- write the split's slab: taps (dh, dw = -1..1) of this wave ----
+  float* slab = g.ws + (size_t)split * 9 * g.co_pad * g.ci_pad;
+  if constexpr (WK == 1) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int tap = (dh + 1) * 3 + d;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        slab[((size_t)tap * g.co_pad + co0 + wco * 32 + row) * g.ci_pad + ci0 + wci * 32 + r] = acc[d][reg];
+      }
+    }
+  } else {
+    float* red = reinterpret_cast<float*>(smem);  // [kernel row][block][pixel split][32][32]
+    const int grp = (dh + 1) * (WCO * WCI) + wco * WCI + wci;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int tap = (dh + 1) * 3 + d;
+      __syncthreads();
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        red[((grp * WK + wk) * 32 + row) * 32 + r] = acc[d][reg];
+      }
+      __syncthreads();
+      for (int e = wk * 64 + lane; e < 1024; e += WK * 64) {  // the WK waves of a group share 1024 outputs
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < WK; ++w) sum += red[((grp * WK + w) * 32) * 32 + e];
+        const int row = e >> 5, col = e & 31;
+        slab[((size_t)tap * g.co_pad + co0 + wco * 32 + row) * g.ci_pad + ci0 + wci * 32 + col] = sum;
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
     wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int SG, int Cout,
                         int Cin, int co_pad, int ci_pad, int accumulate) {
@@ -309,12 +579,18 @@ __global__ void __launch_bounds__(256)
 }
 
 struct WgPlan {
+  bool twelve;  // bf16: the twelve-wave kernel (CY_WGRAD12=0 keeps wgrad_kernel, for A/B runs)
   int wco, wci, wk;
   int TH, TW, tiles_h, tiles_w, S, co_pad, ci_pad;
 };
 
 WgPlan plan_wgrad(const cy_conv_desc* d) {
   WgPlan p;
+  static const bool twelve_enabled = [] {
+    const char* e = getenv("CY_WGRAD12");
+    return !(e && e[0] == '0');
+  }();
+  p.twelve = twelve_enabled && d->in_dtype == CY_BF16;
   const int Cin = d->C1 + d->C2;
   if (d->in_dtype == CY_F32) {
     p.wco = 1, p.wci = 1, p.wk = 4;
@@ -340,8 +616,13 @@ WgPlan plan_wgrad(const cy_conv_desc* d) {
   p.tiles_w = cy_cdiv(d->W, p.TW);
   const int out_tiles = (p.co_pad / (32 * p.wco)) * (p.ci_pad / (32 * p.wci));
   const int ntiles = p.tiles_h * p.tiles_w;
-  // enough workgroups to fill 256 CUs twice, slabs bounded to ~48 MB
-  int S = 512 / out_tiles;
+  // enough workgroups to fill 256 CUs twice (wgrad_kernel: two per CU) or once (twelve waves: one
+  // per CU), slabs bounded to ~48 MB
+  int S = (p.twelve ? 256 : 512) / out_tiles;
+  if (const char* e = getenv("CY_WGRAD_SMUL")) {  // tuning: scale the number of pixel splits
+    const int f = atoi(e);
+    if (f > 1) S *= f;
+  }
   const long slab_bytes = 9L * p.co_pad * p.ci_pad * 4;
   const long cap = (48L << 20) / slab_bytes;
   if (S > cap) S = (int)cap;
@@ -364,6 +645,23 @@ int launch_wgrad(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
   }
   dim3 grid((p.co_pad / C::BCO) * (p.ci_pad / C::BCI), p.S);
   hipLaunchKernelGGL(kern, grid, dim3(256), C::SMEM, st, g);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+template <int WCO, int WCI, int WK>
+int launch_wgrad12(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
+  using C = Wg12Cfg<WCO, WCI, WK>;
+  auto kern = wgrad12_kernel<WCO, WCI, WK>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM) != hipSuccess)
+      return CY_ERR_LAUNCH;
+    attr_done = true;
+  }
+  dim3 grid((p.co_pad / C::BCO) * (p.ci_pad / C::BCI), p.S);
+  hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::SMEM, st, g);
   CY_CHECK_LAUNCH();
   return CY_OK;
 }
@@ -504,6 +802,11 @@ int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, 
   int rc;
   if (d->in_dtype == CY_F32) {
     rc = launch_wgrad<float, 1, 1, 4>(g, p, st);
+  } else if (p.twelve) {
+    if (p.wco == 2 && p.wci == 2) rc = launch_wgrad12<2, 2, 1>(g, p, st);
+    else if (p.wco == 2) rc = launch_wgrad12<2, 1, 2>(g, p, st);
+    else if (p.wci == 2) rc = launch_wgrad12<1, 2, 2>(g, p, st);
+    else rc = launch_wgrad12<1, 1, 4>(g, p, st);
   } else if (p.wco == 2 && p.wci == 2) {
     rc = launch_wgrad<bf16, 2, 2, 1>(g, p, st);
   } else if (p.wco == 2) {
