@@ -27,7 +27,7 @@ import torch
 from torch import Tensor, nn
 
 from cyhip import ops
-from cyhip.functions import ChainCfg, ConvChainFn, HeadFn, defer_batch_counters
+from cyhip.functions import ChainCfg, ConvChainFn, HeadFn, compute_dtype_for, defer_batch_counters, prepack
 
 from ._base import _check_params, _complete_arch_start2end
 from .utils import get_bn_track, get_requires_grad
@@ -151,8 +151,21 @@ class UNet(nn.Module):
             raise ValueError(f"expected [N,{self._input_dim},H,W], got {tuple(x.shape)}")
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise ValueError("spatial dims must be multiples of 16 (four 2x2 poolings)")
+        # every 3x3 weight changes with the optimizer step: repack them all with one launch (a no-op
+        # while the packed images are current, e.g. for the second pass of a step)
+        prepack(self._packed_conv_weights(), compute_dtype_for(x, self._compute_dtype))
         with defer_batch_counters():
             return self._forward(x, until)
+
+    def _packed_conv_weights(self):
+        """the weights that go through the MFMA kernels (all 3x3 convolutions but the 1-4 channel stem)"""
+        ws = []
+        for m in self.modules():
+            if isinstance(m, _ConvBlock):
+                ws += [m.conv[3].weight] if m._first else [m.conv[0].weight, m.conv[3].weight]
+            elif isinstance(m, _UpConv):
+                ws.append(m.up[1].weight)
+        return [w for w in ws if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()]
 
     def _forward(self, x: Tensor, until: Optional[str]):
         e1 = self._Conv1(x)

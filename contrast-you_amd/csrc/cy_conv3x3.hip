@@ -631,6 +631,43 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
   }
 }
 
+// every layer of the network in one launch: `items` (device) lists the layers, a work element i of
+// the flattened range belongs to the last item with first <= i
+template <typename T>
+__global__ void __launch_bounds__(256)
+    pack_weights_batched_kernel(const cy_pack_item* __restrict__ items, int n, long long total,
+                                T* __restrict__ wf_arena, T* __restrict__ wd_arena) {
+  __shared__ cy_pack_item sit[64];
+  for (int i = threadIdx.x; i < n; i += 256) sit[i] = items[i];
+  __syncthreads();
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256LL) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {  // last item with first <= i
+      const int mid = (lo + hi + 1) >> 1;
+      if (sit[mid].first <= i) lo = mid; else hi = mid - 1;
+    }
+    const cy_pack_item& it = sit[lo];
+    const long long j = i - it.first;
+    const long long nf = 9LL * it.co_pad * it.ci_pad;
+    if (j < nf) {
+      const int ci = (int)(j % it.ci_pad);
+      const int co = (int)((j / it.ci_pad) % it.co_pad);
+      const int tap = (int)(j / ((long long)it.ci_pad * it.co_pad));
+      float v = 0.f;
+      if (ci < it.Cin && co < it.Cout) v = it.w[((size_t)co * it.Cin + ci) * 9 + tap];
+      wf_arena[it.off_f + j] = from_f32<T>(v);
+    } else {
+      const long long k = j - nf;
+      const int co = (int)(k % it.co_pad2);
+      const int ci = (int)((k / it.co_pad2) % it.ci_pad2);
+      const int tap = (int)(k / ((long long)it.co_pad2 * it.ci_pad2));
+      float v = 0.f;
+      if (ci < it.Cin && co < it.Cout) v = it.w[((size_t)co * it.Cin + ci) * 9 + (8 - tap)];
+      wd_arena[it.off_d + k] = from_f32<T>(v);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // First layer: Cin in 1..4, image is f32 NCHW.  HBM-bound on the output write;
 // plain VALU.  Thread = (pixel, group of 8 output channels).
@@ -738,6 +775,24 @@ int cy_conv3x3_pack_weights(const float* w, void* wf, void* wd, int Cout, int Ci
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, w, (float*)wf,
                        (float*)wd, Cout, Cin, co_pad, ci_pad, ci_pad2, co_pad2);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_conv3x3_pack_weights_batched(const cy_pack_item* items, int n_items, long long total,
+                                    void* wf_arena, void* wd_arena, int dtype, void* stream) {
+  if (!items || n_items <= 0 || n_items > 64 || total <= 0 || !wf_arena || !wd_arena) return CY_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long long want = (total + 255) / 256;
+  const int blocks = (int)(want > 8192 ? 8192 : want);
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(pack_weights_batched_kernel<bf16>, dim3(blocks), dim3(256), 0, st, items, n_items,
+                       total, (bf16*)wf_arena, (bf16*)wd_arena);
+  else if (dtype == CY_F32)
+    hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(blocks), dim3(256), 0, st, items, n_items,
+                       total, (float*)wf_arena, (float*)wd_arena);
   else
     return CY_ERR_DTYPE;
   CY_CHECK_LAUNCH();

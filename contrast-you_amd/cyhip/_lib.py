@@ -35,6 +35,13 @@ class ConvDesc(C.Structure):
         "ld1", "ld2", "ldo", "split_c", "ldo2")]
 
 
+class PackItem(C.Structure):
+    """mirror of cy_pack_item"""
+    _fields_ = [("w", c_void_p), ("off_f", C.c_longlong), ("off_d", C.c_longlong), ("first", C.c_longlong),
+                ("Cout", c_int32), ("Cin", c_int32), ("co_pad", c_int32), ("ci_pad", c_int32),
+                ("ci_pad2", c_int32), ("co_pad2", c_int32)]
+
+
 _P = c_void_p
 _PCD = POINTER(ConvDesc)
 
@@ -46,6 +53,7 @@ _SIGS = {
     "cy_debug_stamp": (c_int, [_P, c_int, _P]),
     "cy_conv3x3_packed_dims": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "cy_conv3x3_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "cy_conv3x3_pack_weights_batched": (c_int, [_P, c_int, C.c_longlong, _P, _P, c_int, _P]),
     "cy_conv3x3_num_partials": (c_int, [_PCD]),
     "cy_conv3x3_fwd_ws_bytes": (c_size_t, [_PCD]),
     "cy_conv3x3_fwd": (c_int, [_PCD, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),

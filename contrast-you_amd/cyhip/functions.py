@@ -70,6 +70,26 @@ def packed_weights(w: Tensor, dtype: torch.dtype):
     return wf, wd
 
 
+def prepack(weights, dtype: torch.dtype) -> None:
+    """pack ALL the given 3x3 weights with one launch if the first one's packed image is stale (they
+    change together, with the optimizer step), and file the results where `packed_weights` looks"""
+    if not weights:
+        return
+    w0 = weights[0]
+    cap = torch.cuda.is_current_stream_capturing()
+    hit = w0.__dict__.get("_cy_pack", {}).get(dtype)
+    if hit is not None and hit[0] == (w0._version, _weights_epoch, w0.data_ptr(), cap):
+        return
+    cur = torch.cuda.current_stream(w0.device)
+    packs = ops.pack_weights_batched([w.detach() for w in weights], dtype)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    capid = ops._capture_id(cur)
+    for w, (wf, wd) in zip(weights, packs):
+        w.__dict__.setdefault("_cy_pack", {})[dtype] = ((w._version, _weights_epoch, w.data_ptr(), cap),
+                                                        wf, wd, ev, cur, capid)
+
+
 def compute_dtype_for(x: Tensor, requested: Optional[torch.dtype]) -> torch.dtype:
     """bf16 under autocast (AMPScaler.autocast, contrastyou/amp/amp.py:44), else the requested
     dtype, else f32 (verification mode)."""

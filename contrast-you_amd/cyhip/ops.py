@@ -136,6 +136,59 @@ def pack_weights(w: Tensor, dtype: torch.dtype, want_dgrad: bool = True):
     return wf, wd
 
 
+class _PackSet:
+    """device table + arena layout for packing a fixed list of 3x3 weights in one launch"""
+
+    def __init__(self, weights, dtype):
+        items = (_lib.PackItem * len(weights))()
+        self.views = []  # per weight: (offset, shape) of the forward and of the dgrad image
+        off_f = off_d = first = 0
+        for it, w in zip(items, weights):
+            Cout, Cin = w.shape[0], w.shape[1]
+            cop, cip = packed_dims(Cout, Cin)
+            cip2, cop2 = packed_dims(Cin, Cout)
+            it.w, it.off_f, it.off_d, it.first = w.data_ptr(), off_f, off_d, first
+            it.Cout, it.Cin, it.co_pad, it.ci_pad, it.ci_pad2, it.co_pad2 = Cout, Cin, cop, cip, cip2, cop2
+            self.views.append(((off_f, (9, cop, cip)), (off_d, (9, cip2, cop2))))
+            off_f += 9 * cop * cip
+            off_d += 9 * cip2 * cop2
+            first += 9 * cop * cip + 9 * cip2 * cop2
+        self.n, self.size_f, self.size_d, self.total = len(weights), off_f, off_d, first
+        raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+        self.table = raw.to(weights[0].device)
+
+
+_pack_sets = {}
+
+
+def pack_weights_batched(weights, dtype: torch.dtype):
+    """[(wf, wd)] for a list of [Cout,Cin,3,3] f32 weights, packed by ONE kernel launch into two fresh
+    arenas (the per-layer views alias them).  The layer table lives on the device and is built once per
+    (weight storages, dtype)."""
+    require_gpu(*weights)
+    for w in weights:
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            raise ValueError("pack_weights_batched wants contiguous f32 weights")
+    if len(weights) > 64:
+        raise ValueError("at most 64 layers per batched pack")
+    key = (dtype, tuple(w.data_ptr() for w in weights), tuple(tuple(w.shape) for w in weights))
+    ps = _pack_sets.get(key)
+    if ps is None:
+        if len(_pack_sets) > 8:
+            _pack_sets.clear()
+        ps = _pack_sets[key] = _PackSet(weights, dtype)
+    dev = weights[0].device
+    af = torch.empty(ps.size_f, dtype=dtype, device=dev)
+    ad = torch.empty(ps.size_d, dtype=dtype, device=dev)
+    _lib.call("cy_conv3x3_pack_weights_batched", ps.table.data_ptr(), ps.n, ps.total, af.data_ptr(),
+              ad.data_ptr(), dtype_code(dtype), _stream())
+    out = []
+    for (of, shf), (od, shd) in ps.views:
+        nf, nd = shf[0] * shf[1] * shf[2], shd[0] * shd[1] * shd[2]
+        out.append((af[of:of + nf].view(shf), ad[od:od + nd].view(shd)))
+    return out
+
+
 _desc_cache = {}
 
 

@@ -88,6 +88,23 @@ int cy_conv3x3_packed_dims(int Cout, int Cin, int* co_pad, int* ci_pad);
 int cy_conv3x3_pack_weights(const float* w, void* wf, void* wd, int Cout, int Cin, int dtype,
                             void* stream);
 
+/* All 3x3 weights of a network in ONE launch (the per-layer call above costs a launch per layer and
+ * step: the weights change with every optimizer step).  `items` is a DEVICE array describing the
+ * layers: source pointer, geometry, the element offsets of the layer's forward / data-gradient image
+ * inside the two output arenas, and `first` = index of the layer's first work element in the
+ * flattened range [0, total) (total = sum over layers of 9*co_pad*ci_pad + 9*ci_pad2*co_pad2).
+ * Offsets instead of pointers keep the table valid when the arenas are re-allocated per step. */
+typedef struct cy_pack_item {
+  const float* w;          /* [Cout][Cin][3][3] f32 */
+  long long off_f, off_d;  /* element offsets into wf_arena / wd_arena */
+  long long first;
+  int Cout, Cin;
+  int co_pad, ci_pad;      /* forward image  [9][co_pad][ci_pad]   (cy_conv3x3_packed_dims(Cout, Cin)) */
+  int ci_pad2, co_pad2;    /* dgrad image    [9][ci_pad2][co_pad2] (cy_conv3x3_packed_dims(Cin, Cout)) */
+} cy_pack_item;
+int cy_conv3x3_pack_weights_batched(const cy_pack_item* items, int n_items, long long total,
+                                    void* wf_arena, void* wd_arena, int dtype, void* stream);
+
 /* Number of per-tile statistic partials the forward kernel writes for `d`
  * (stats buffer is float[num_partials][2][Cout]: sum, sum of squares). */
 int cy_conv3x3_num_partials(const cy_conv_desc* d);

@@ -424,3 +424,19 @@ def test_ema_and_radam():
         opt.step()
         ops.radam_step(pg, grad.to(DEV), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-5, step)
         assert_close(pg, p.detach(), 1e-6, f"radam step {step}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_weight_pack_equals_per_layer_pack(dtype):
+    """cy_conv3x3_pack_weights_batched (one launch for all layers) writes the same packed images as
+    cy_conv3x3_pack_weights layer by layer"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(32, 32), (64, 32), (8, 16), (128, 64), (48, 40), (256, 128)]
+    ws = [rnd(co, ci, 3, 3, gen=g).to(DEV) for co, ci in shapes]
+    packs = ops.pack_weights_batched(ws, dtype)
+    again = ops.pack_weights_batched(ws, dtype)  # second call: cached layer table, fresh arenas
+    for w, (wf, wd), (wf2, wd2) in zip(ws, packs, again):
+        rf, rd = ops.pack_weights(w, dtype)
+        assert torch.equal(wf, rf) and torch.equal(wd, rd), tuple(w.shape)
+        assert torch.equal(wf2, rf) and torch.equal(wd2, rd), tuple(w.shape)
