@@ -631,40 +631,55 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
   }
 }
 
-// every layer of the network in one launch: `items` (device) lists the layers, a work element i of
-// the flattened range belongs to the last item with first <= i
+// every layer of the network in one launch: `items` (device) lists the layers; the unit of work is a
+// 32 (co) x 32 (ci) tile of one layer (`first` = index of the layer's first tile), transposed
+// through LDS so that the f32 source is read in contiguous runs of 288 floats and both images are
+// written in contiguous runs of 32 elements
+__host__ __device__ inline int pack_tiles_co(int co_pad, int co_pad2) {
+  return ((co_pad > co_pad2 ? co_pad : co_pad2) + 31) / 32;
+}
+__host__ __device__ inline int pack_tiles_ci(int ci_pad, int ci_pad2) {
+  return ((ci_pad > ci_pad2 ? ci_pad : ci_pad2) + 31) / 32;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
-    pack_weights_batched_kernel(const cy_pack_item* __restrict__ items, int n, long long total,
-                                T* __restrict__ wf_arena, T* __restrict__ wd_arena) {
-  __shared__ cy_pack_item sit[64];
-  for (int i = threadIdx.x; i < n; i += 256) sit[i] = items[i];
-  __syncthreads();
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256LL) {
+    pack_weights_batched_kernel(const cy_pack_item* __restrict__ items, int n, T* __restrict__ wf_arena,
+                                T* __restrict__ wd_arena) {
+  __shared__ T tile[9][32][33];
+  __shared__ cy_pack_item sit;
+  __shared__ int s_local;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
     int lo = 0, hi = n - 1;
-    while (lo < hi) {  // last item with first <= i
+    while (lo < hi) {  // last item with first <= blockIdx.x
       const int mid = (lo + hi + 1) >> 1;
-      if (sit[mid].first <= i) lo = mid; else hi = mid - 1;
+      if (items[mid].first <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
     }
-    const cy_pack_item& it = sit[lo];
-    const long long j = i - it.first;
-    const long long nf = 9LL * it.co_pad * it.ci_pad;
-    if (j < nf) {
-      const int ci = (int)(j % it.ci_pad);
-      const int co = (int)((j / it.ci_pad) % it.co_pad);
-      const int tap = (int)(j / ((long long)it.ci_pad * it.co_pad));
-      float v = 0.f;
-      if (ci < it.Cin && co < it.Cout) v = it.w[((size_t)co * it.Cin + ci) * 9 + tap];
-      wf_arena[it.off_f + j] = from_f32<T>(v);
-    } else {
-      const long long k = j - nf;
-      const int co = (int)(k % it.co_pad2);
-      const int ci = (int)((k / it.co_pad2) % it.ci_pad2);
-      const int tap = (int)(k / ((long long)it.co_pad2 * it.ci_pad2));
-      float v = 0.f;
-      if (ci < it.Cin && co < it.Cout) v = it.w[((size_t)co * it.Cin + ci) * 9 + (8 - tap)];
-      wd_arena[it.off_d + k] = from_f32<T>(v);
-    }
+    sit = items[lo];
+    s_local = (int)(blockIdx.x - items[lo].first);
+  }
+  __syncthreads();
+  const cy_pack_item& it = sit;
+  const int tci_n = pack_tiles_ci(it.ci_pad, it.ci_pad2);
+  const int co0 = (s_local / tci_n) * 32, ci0 = (s_local % tci_n) * 32;
+  const int ncol = (it.Cin - ci0 < 32 ? it.Cin - ci0 : 32) * 9;  // valid floats per source row (may be <= 0)
+  for (int idx = tid; idx < 32 * 288; idx += 256) {
+    const int row = idx / 288, col = idx - row * 288;
+    float v = 0.f;
+    if (co0 + row < it.Cout && col < ncol) v = it.w[((size_t)(co0 + row) * it.Cin + ci0) * 9 + col];
+    tile[col % 9][row][col / 9] = from_f32<T>(v);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 9 * 1024; idx += 256) {
+    const int tap = idx >> 10, hi5 = (idx >> 5) & 31, lo5 = idx & 31;
+    // forward image [tap][co][ci]: ci fastest
+    if (co0 + hi5 < it.co_pad && ci0 + lo5 < it.ci_pad)
+      wf_arena[it.off_f + ((size_t)tap * it.co_pad + co0 + hi5) * it.ci_pad + ci0 + lo5] = tile[tap][hi5][lo5];
+    // data-gradient image [8-tap][ci][co]: co fastest
+    if (ci0 + hi5 < it.ci_pad2 && co0 + lo5 < it.co_pad2)
+      wd_arena[it.off_d + ((size_t)(8 - tap) * it.ci_pad2 + ci0 + hi5) * it.co_pad2 + co0 + lo5] =
+          tile[tap][lo5][hi5];
   }
 }
 
@@ -676,8 +691,11 @@ __global__ void __launch_bounds__(256)
     conv3x3_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
                          TO* __restrict__ out, float* __restrict__ stats, int N, int Cin, int H,
                          int W, int Cout) {
+  // a block walks a contiguous pixel range, 256 / (Cout/8) pixels per iteration; the BN statistics
+  // are accumulated in registers over the whole range and reduced ONCE per block (one partial per
+  // block: fixed order => deterministic)
   __shared__ float sw[9 * 4 * 64];  // [tap][ci][co], Cout <= 64
-  __shared__ float sred[2 * 256 * 8];
+  __shared__ float sred[4 * 2 * 64];  // [wave][sum | sumsq][cout]
   const int tid = threadIdx.x;
   for (int i = tid; i < 9 * Cin * Cout; i += 256) {
     const int co = i % Cout;
@@ -686,19 +704,26 @@ __global__ void __launch_bounds__(256)
     sw[i] = w[((size_t)co * Cin + ci) * 9 + tap];
   }
   __syncthreads();
-  const int CG = Cout / 8;
-  const int ppb = 256 / CG;  // pixels per block
+  const int CG = Cout / 8;   // power of two (checked by the host)
+  const int ppb = 256 / CG;  // pixels per iteration
   const int cg = tid % CG;
-  const long p = (long)blockIdx.x * ppb + tid / CG;
   const long npix = (long)N * H * W;
-  float acc[8];
+  const long per = ((npix + gridDim.x - 1) / gridDim.x + ppb - 1) / ppb * ppb;
+  const long p0 = (long)blockIdx.x * per;
+  const long p1 = p0 + per < npix ? p0 + per : npix;
+  float s1[8], s2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  const bool valid = p < npix;
-  if (valid) {
-    const int wq = (int)(p % W);
-    const int hq = (int)((p / W) % H);
-    const int n = (int)(p / ((long)W * H));
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  for (long p = p0 + tid / CG; p < p1; p += ppb) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    // (32-bit index arithmetic: 64-bit divisions cost more than the 72 FMAs of a pixel)
+    const unsigned pu = (unsigned)p;
+    const unsigned row = pu / (unsigned)W;
+    const int wq = (int)(pu - row * (unsigned)W);
+    const int n = (int)(row / (unsigned)H);
+    const int hq = (int)(row - (unsigned)n * (unsigned)H);
     for (int ci = 0; ci < Cin; ++ci) {
       const float* xp = x + ((size_t)n * Cin + ci) * H * W;
 #pragma unroll
@@ -718,24 +743,44 @@ __global__ void __launch_bounds__(256)
       st16(op, Chunk<float>::pack(acc));
       st16(reinterpret_cast<float*>(op) + 4, Chunk<float>::pack(acc + 4));
     }
-  }
-  if (stats) {
-    // block reduction per channel: sred[which][pixel slot][8]
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float q = valid ? round_through<TO>(acc[j]) : 0.f;
-      sred[(0 * 256 + tid) * 8 + j] = q;
-      sred[(1 * 256 + tid) * 8 + j] = q * q;
+      const float q = round_through<TO>(acc[j]);
+      s1[j] += q;
+      s2[j] += q * q;
+    }
+  }
+  if (stats) {
+    // lanes of a wave that share a cout group (xor-shuffles over the pixel bits), then the four waves
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a1 = s1[j], a2 = s2[j];
+      for (int o = CG; o < 64; o <<= 1) {
+        a1 += __shfl_xor(a1, o, 64);
+        a2 += __shfl_xor(a2, o, 64);
+      }
+      if (lane < CG) {
+        sred[(wave * 2 + 0) * 64 + lane * 8 + j] = a1;
+        sred[(wave * 2 + 1) * 64 + lane * 8 + j] = a2;
+      }
     }
     __syncthreads();
     if (tid < 2 * Cout) {
       const int which = tid / Cout, co = tid % Cout;
-      const int g = co / 8, j = co % 8;
-      float s = 0.f;
-      for (int q = 0; q < ppb; ++q) s += sred[(which * 256 + q * CG + g) * 8 + j];
-      stats[((size_t)blockIdx.x * 2 + which) * Cout + co] = s;
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t += sred[(q * 2 + which) * 64 + co];
+      stats[((size_t)blockIdx.x * 2 + which) * Cout + co] = t;
     }
   }
+}
+
+int first_conv_blocks(long npix, int Cout) {
+  const int ppb = 256 / (Cout / 8);
+  long b = (npix + ppb - 1) / ppb;
+  if (b > 2048) b = 2048;  // 8 blocks per CU: a few hundred pixels each at the U-Net's sizes
+  return (int)b;
 }
 
 }  // namespace
@@ -783,16 +828,15 @@ int cy_conv3x3_pack_weights(const float* w, void* wf, void* wd, int Cout, int Ci
 
 int cy_conv3x3_pack_weights_batched(const cy_pack_item* items, int n_items, long long total,
                                     void* wf_arena, void* wd_arena, int dtype, void* stream) {
-  if (!items || n_items <= 0 || n_items > 64 || total <= 0 || !wf_arena || !wd_arena) return CY_ERR_ARG;
+  if (!items || n_items <= 0 || n_items > 64 || total <= 0 || total > 0x7fffffffLL || !wf_arena || !wd_arena)
+    return CY_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const long long want = (total + 255) / 256;
-  const int blocks = (int)(want > 8192 ? 8192 : want);
   if (dtype == CY_BF16)
-    hipLaunchKernelGGL(pack_weights_batched_kernel<bf16>, dim3(blocks), dim3(256), 0, st, items, n_items,
-                       total, (bf16*)wf_arena, (bf16*)wd_arena);
+    hipLaunchKernelGGL(pack_weights_batched_kernel<bf16>, dim3((unsigned)total), dim3(256), 0, st, items,
+                       n_items, (bf16*)wf_arena, (bf16*)wd_arena);
   else if (dtype == CY_F32)
-    hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(blocks), dim3(256), 0, st, items, n_items,
-                       total, (float*)wf_arena, (float*)wd_arena);
+    hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3((unsigned)total), dim3(256), 0, st, items,
+                       n_items, (float*)wf_arena, (float*)wd_arena);
   else
     return CY_ERR_DTYPE;
   CY_CHECK_LAUNCH();
@@ -860,14 +904,14 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
 
 int cy_conv3x3_first_num_partials(int N, int H, int W, int Cout) {
   if (Cout % 8 || Cout > 64 || 256 % (Cout / 8)) return CY_ERR_SHAPE;
-  const int ppb = 256 / (Cout / 8);
-  return cy_cdiv((long)N * H * W, ppb);
+  return first_conv_blocks((long)N * H * W, Cout);
 }
 
 int cy_conv3x3_first_fwd(const float* x, const float* w, void* out, float* stats, int N, int Cin,
                          int H, int W, int Cout, int out_dtype, void* stream) {
   if (!x || !w || !out) return CY_ERR_ARG;
   if (Cin < 1 || Cin > 4) return CY_ERR_SHAPE;
+  if ((long)N * H * W >= (1L << 31)) return CY_ERR_SHAPE;  // the kernel indexes pixels in 32 bits
   const int np = cy_conv3x3_first_num_partials(N, H, W, Cout);
   if (np < 0) return np;
   hipStream_t st = (hipStream_t)stream;

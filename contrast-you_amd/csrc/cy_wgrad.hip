@@ -689,9 +689,11 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
     for (long p = p0 + prow; p < p1; p += rows) {
-      const int wq = (int)(p % W);
-      const int hq = (int)((p / W) % H);
-      const int n = (int)(p / ((long)W * H));
+      const unsigned pu = (unsigned)p;  // 32-bit index arithmetic (npix < 2^31 checked by the host)
+      const unsigned row = pu / (unsigned)W;
+      const int wq = (int)(pu - row * (unsigned)W);
+      const int n = (int)(row / (unsigned)H);
+      const int hq = (int)(row - (unsigned)n * (unsigned)H);
       float d[8];
       if constexpr (sizeof(T) == 2) {
         Chunk<bf16>::unpack(ld16(dy + p * Cout + cg * 8), d);
@@ -838,6 +840,7 @@ int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int accumu
                            void* stream) {
   if (!x || !dy || !dw || !ws) return CY_ERR_ARG;
   if (Cin < 1 || Cin > 4 || Cout % 8 || Cout > 64 || 256 % (Cout / 8)) return CY_ERR_SHAPE;
+  if ((long)N * H * W >= (1L << 31)) return CY_ERR_SHAPE;
   if (ws_bytes < cy_conv3x3_first_wgrad_ws_bytes(N, Cin, H, W, Cout)) return CY_ERR_WORKSPACE;
   const int nblk = first_wgrad_blocks((long)N * H * W);
   hipStream_t st = (hipStream_t)stream;

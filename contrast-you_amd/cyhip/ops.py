@@ -152,7 +152,7 @@ class _PackSet:
             self.views.append(((off_f, (9, cop, cip)), (off_d, (9, cip2, cop2))))
             off_f += 9 * cop * cip
             off_d += 9 * cip2 * cop2
-            first += 9 * cop * cip + 9 * cip2 * cop2
+            first += -(-max(cop, cop2) // 32) * -(-max(cip, cip2) // 32)  # 32 x 32 (co, ci) tiles
         self.n, self.size_f, self.size_d, self.total = len(weights), off_f, off_d, first
         raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
         self.table = raw.to(weights[0].device)

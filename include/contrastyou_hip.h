@@ -91,8 +91,9 @@ int cy_conv3x3_pack_weights(const float* w, void* wf, void* wd, int Cout, int Ci
 /* All 3x3 weights of a network in ONE launch (the per-layer call above costs a launch per layer and
  * step: the weights change with every optimizer step).  `items` is a DEVICE array describing the
  * layers: source pointer, geometry, the element offsets of the layer's forward / data-gradient image
- * inside the two output arenas, and `first` = index of the layer's first work element in the
- * flattened range [0, total) (total = sum over layers of 9*co_pad*ci_pad + 9*ci_pad2*co_pad2).
+ * inside the two output arenas, and `first` = index of the layer's first work unit in the flattened
+ * range [0, total).  A work unit is a 32 (co) x 32 (ci) tile; a layer has
+ * ceil(max(co_pad, co_pad2) / 32) * ceil(max(ci_pad, ci_pad2) / 32) of them, co-major.
  * Offsets instead of pointers keep the table valid when the arenas are re-allocated per step. */
 typedef struct cy_pack_item {
   const float* w;          /* [Cout][Cin][3][3] f32 */

@@ -11,7 +11,9 @@ import json
 import sys
 from collections import defaultdict
 
-FAMILIES = {"conv3x3_igemm": "conv3x3_igemm_kernel", "conv3x3_wgrad": "wgrad_kernel"}
+# bench.py's name of a kernel family -> substrings of the kernel names that belong to it
+FAMILIES = {"conv3x3_igemm": ("conv3x3_igemm_kernel", "conv3x3_plane_kernel"),
+            "conv3x3_wgrad": ("wgrad_kernel", "wgrad12_kernel")}
 
 
 def load(d, counter):
@@ -20,8 +22,9 @@ def load(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        for fam, key in FAMILIES.items():
-            if key in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"] and "first" not in r["Kernel_Name"]:
+        for fam, keys in FAMILIES.items():
+            if any(k in r["Kernel_Name"] for k in keys) and "reduce" not in r["Kernel_Name"] \
+                    and "first" not in r["Kernel_Name"]:
                 acc[fam][0] += float(r["Counter_Value"])
                 acc[fam][1] += 1
     return acc
