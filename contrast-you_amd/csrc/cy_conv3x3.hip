@@ -514,6 +514,7 @@ constexpr int kPlaneTH = 16, kPlaneTW = 14;
 
 struct ConvPlan {
   bool plane;
+  bool one_per_cu;  // plane, 128 couts: at most one workgroup per CU, halo prefetch in registers
   TileChoice tile;
   int ksplit;         // >1: split-K over input-channel chunks + finish kernel
   int finish_blocks;  // blocks (= stat partials) of the finish kernel
@@ -531,6 +532,13 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes) {
   if (p.plane) {
     p.tile.th = kPlaneTH, p.tile.tw = kPlaneTW;
     p.tile.bn = Cout >= 128 ? 128 : (Cout > 32 ? 64 : 32);
+    // 128-cout layers with fewer tiles than CUs (56x56 at N=16: 224 tiles): two 64-cout workgroups
+    // per tile instead of one (10-13 % faster there, 10-50 % slower at 448 tiles)
+    static const int bn64_below = [] {
+      const char* e = getenv("CY_PLANE_BN64_BELOW");
+      return e ? atoi(e) : 300;
+    }();
+    if (Cout == 128 && cy_cdiv((long)N * H, kPlaneTH) * (W / kPlaneTW) < bn64_below) p.tile.bn = 64;
   }
   const int tiles = cy_cdiv((long)N * H, p.tile.th) * cy_cdiv(W, p.tile.tw);
   const int blocks = tiles * cy_cdiv(Cout, p.tile.bn);
@@ -541,6 +549,22 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes) {
     Z = cy_cdiv(384, blocks);
     if (Z > ncc) Z = ncc;
     if (Z > 8) Z = 8;
+  }
+  p.one_per_cu = false;
+  if (p.plane && p.tile.bn == 128) {
+    static const int mode = [] {
+      const char* e = getenv("CY_PLANE_ONE_PER_CU");
+      return e ? atoi(e) : 1;
+    }();
+    if (mode && ncc >= 2) {  // aim at 192..288 workgroups, each with >= 2 chunks to pipeline
+      int z1 = blocks >= 256 ? 1 : 256 / blocks;
+      if (z1 > ncc / 2) z1 = ncc / 2;
+      if (z1 < 1) z1 = 1;
+      if (blocks * z1 >= 192 && blocks * z1 <= 288 && Cout % 8 == 0) {
+        p.one_per_cu = true;
+        Z = z1;
+      }
+    }
   }
   if (const char* ov = getenv("CY_KSPLIT")) {  // tuning override (tools/bench_layers.py)
     const int z = atoi(ov);
@@ -571,7 +595,9 @@ int launch_finish(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
 template <typename T>
 int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
   if (p.plane) {
-    if (p.tile.bn == 128) return launch_conv_plane<T, kPlaneTH, 128, 2, 2, 128, false>(a, st);
+    if (p.tile.bn == 128)
+      return p.one_per_cu ? launch_conv_plane<T, kPlaneTH, 128, 2, 2, 128, false, true>(a, st)
+                          : launch_conv_plane<T, kPlaneTH, 128, 2, 2, 128, false, false>(a, st);
     if (p.tile.bn == 64) return launch_conv_plane<T, kPlaneTH, 64, 4, 1, 64, true>(a, st);
     return launch_conv_plane<T, kPlaneTH, 32, 4, 1, 64, true>(a, st);
   }

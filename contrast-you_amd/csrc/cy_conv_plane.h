@@ -73,8 +73,10 @@ struct PlaneCfg {
   static_assert(APL >= ZB + 18 && APL % 16 == SKEW % 16, "plane pitch");
 };
 
-template <typename T, int TH, int BN, int WGM, int WGN, int PITCHB, bool ALLT>
-__global__ void __launch_bounds__(256, 2)
+// PREFA (ring variant only): one workgroup per CU with the 512-register budget that buys -- the next
+// chunk's halo tile is requested into registers before the nine taps, as in the ALLT variants
+template <typename T, int TH, int BN, int WGM, int WGN, int PITCHB, bool ALLT, bool PREFA = false>
+__global__ void __launch_bounds__(256, PREFA ? 1 : 2)
     conv3x3_plane_kernel(const ConvArgs a) {
   using C = PlaneCfg<T, TH, BN, WGM, WGN, PITCHB, ALLT>;
   using M = Mma<T>;
@@ -154,7 +156,7 @@ __global__ void __launch_bounds__(256, 2)
   const int ch = tid & (CPP - 1);
   const T* s1 = reinterpret_cast<const T*>(a.src1);
   const T* s2 = reinterpret_cast<const T*>(a.src2);
-  constexpr int NAW = ALLT ? NA : (NA < 4 ? NA : 4);  // items in flight per thread (register window)
+  constexpr int NAW = (ALLT || PREFA) ? NA : (NA < 4 ? NA : 4);  // items in flight per thread (register window)
   u32x4 areg[NAW];
   unsigned aok = 0;  // bit i: areg[i] holds loaded data (else zero fill)
   auto a_pooled = [&](int c0) { return a.mode1 == CY_SRC_POOL2 && c0 + ch * EPC < a.C1; };
@@ -331,9 +333,9 @@ __global__ void __launch_bounds__(256, 2)
     const int it0 = cc0 * 9, nit = cc1 * 9;
     for (int cc = cc0; cc < cc1; ++cc) {
       const bool more = cc + 1 < cc1;
-      // (no register prefetch of the next halo tile here: 128 accumulator + 48 fragment registers
-      // leave no room for it, and a chunk is 288 MFMAs per wave -- long enough for the second
-      // workgroup of the CU to cover the staging)
+      // (two workgroups per CU: no register prefetch of the next halo tile -- 128 accumulator + 48
+      // fragment registers leave no room for it; the second workgroup of the CU covers the staging)
+      if (PREFA && more) a_request((cc + 1) * KC, 0);
       auto ring_tap = [&](auto TAP) {
         constexpr int tap = decltype(TAP)::value;
         const int it = cc * 9 + tap;
@@ -343,7 +345,7 @@ __global__ void __launch_bounds__(256, 2)
         if (has_next) b_commit(sB + ((it + 1 - it0) & 1) * C::B_BYTES);
         if (tap == 8 && more) {
           __syncthreads();  // every wave is done reading the halo tile
-          a_stage((cc + 1) * KC);
+          if constexpr (PREFA) a_commit((cc + 1) * KC, 0); else a_stage((cc + 1) * KC);
         }
         __syncthreads();
       };
@@ -469,10 +471,10 @@ __global__ void __launch_bounds__(256, 2)
   }
 }
 
-template <typename T, int TH, int BN, int WGM, int WGN, int PITCHB, bool ALLT>
+template <typename T, int TH, int BN, int WGM, int WGN, int PITCHB, bool ALLT, bool PREFA = false>
 int launch_conv_plane(ConvArgs a, hipStream_t st) {
   using C = PlaneCfg<T, TH, BN, WGM, WGN, PITCHB, ALLT>;
-  auto kern = conv3x3_plane_kernel<T, TH, BN, WGM, WGN, PITCHB, ALLT>;
+  auto kern = conv3x3_plane_kernel<T, TH, BN, WGM, WGN, PITCHB, ALLT, PREFA>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
