@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256, PREFA ? 1 : 2)
 #pragma unroll
       for (int m = 0; m < M_REP; ++m)
 #pragma unroll
-        for (int n = 0; n < N_REP; ++n) M::mma(af[cur][m], bf[cur][n], acc[m][n]);
+        for (int n = 0; n < N_REP; ++n) M::mma(bf[cur][n], af[cur][m], acc[m][n]);  // rows = couts
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -352,107 +352,120 @@ __global__ void __launch_bounds__(256, PREFA ? 1 : 2)
       CY_NINE_TAPS(ring_tap(TapC<TAP_>{}));
     }
   }
-  if constexpr (ALLT) __syncthreads();  // the epilogue scratch aliases the operand buffers
+  if constexpr (ALLT) __syncthreads();  // the statistics scratch aliases the operand buffers
 
-  // ---------------- epilogue: accumulator (position q, cout) -> NHWC ----------------
-  // q = ty*16 + hx; columns hx = 0 and 15 are the halo columns (garbage accumulators)
+  // ---------------- epilogue: accumulators -> NHWC, straight from registers ----------------
+  // The MFMAs run with the WEIGHTS as the row operand, so a lane holds ONE position (q = frag base
+  // + r; q = ty*16 + hx, columns hx = 0 and 15 are the halo columns = garbage) and 16 couts in four
+  // runs of four consecutive channels ((reg&3) + 8*(reg>>2) + 4*h): four 8-byte (bf16) stores per
+  // fragment, no LDS transpose and no per-element index arithmetic.
+  auto position = [&](int m, int& R, int& w) -> bool {
+    const int q = (wm * M_REP + m) * 32 + r;
+    const int hx = q & 15;
+    R = R0 + (q >> 4);
+    w = w0 + hx - 1;
+    return hx >= 1 && hx <= TW && R < a.NH && w < a.W;
+  };
   if (a.ksplit > 1) {
     float* wsz = a.ws + (size_t)blockIdx.z * ((size_t)a.NH * a.W) * a.Cout;
-    float* scr = reinterpret_cast<float*>(smem) + wave * (32 * 36);
 #pragma unroll
-    for (int n = 0; n < N_REP; ++n) {
-      const int cobase = n0 + (wn * N_REP + n) * 32;
+    for (int m = 0; m < M_REP; ++m) {
+      int R, w;
+      if (!position(m, R, w)) continue;
+      float* dst = wsz + ((size_t)R * a.W + w) * a.Cout;
 #pragma unroll
-      for (int m = 0; m < M_REP; ++m) {
-        const int qbase = (wm * M_REP + m) * 32;
+      for (int n = 0; n < N_REP; ++n)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-          scr[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 36 + r] = acc[m][n][reg];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int itx = 0; itx < 4; ++itx) {
-          const int idx = lane + itx * 64;
-          const int pix = idx >> 3, cch = idx & 7;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(scr + pix * 36 + cch * 4);
-          const int q = qbase + pix;
-          const int hx = q & 15;
-          const int R = R0 + (q >> 4), w = w0 + hx - 1;
-          const int co = cobase + cch * 4;
-          if (hx >= 1 && hx <= TW && R < a.NH && w < a.W && co < a.Cout)
-            *reinterpret_cast<f32x4*>(wsz + ((size_t)R * a.W + w) * a.Cout + co) = v;
+        for (int g = 0; g < 4; ++g) {
+          const int co = n0 + (wn * N_REP + n) * 32 + 8 * g + 4 * h;
+          if (co < a.Cout)
+            *reinterpret_cast<f32x4*>(dst + co) = f32x4{acc[m][n][4 * g], acc[m][n][4 * g + 1],
+                                                        acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
         }
-        __builtin_amdgcn_wave_barrier();
-      }
     }
     return;
   }
-  constexpr int EPO = 16 / (int)sizeof(T);  // output elements per 16-byte chunk
-  constexpr int CPO = 32 / EPO;             // chunks per 32-cout row
-  float* scratch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
-  float* sstat = reinterpret_cast<float*>(smem) + 4 * (32 * 36);
+  float* sstat = reinterpret_cast<float*>(smem);
   const bool do_stats = a.stats != nullptr;
   T* o1 = reinterpret_cast<T*>(a.out);
   T* o2 = reinterpret_cast<T*>(a.out2);
-
 #pragma unroll
   for (int n = 0; n < N_REP; ++n) {
-    float s1v = 0.f, s2v = 0.f;
-    const int cobase = n0 + (wn * N_REP + n) * 32;
+    float s1[16], s2[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
 #pragma unroll
     for (int m = 0; m < M_REP; ++m) {
-      const int qbase = (wm * M_REP + m) * 32;
+      int R, w;
+      const bool ok = position(m, R, w);
+      const size_t gp = (size_t)R * a.W + w;
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        const float v = acc[m][n][reg];
-        scratch[row * 36 + r] = v;
-        if (do_stats) {
-          const int q = qbase + row;
-          const int hx = q & 15;
-          if (hx >= 1 && hx <= TW && R0 + (q >> 4) < a.NH && w0 + hx - 1 < a.W) {
-            const float qv = round_through<T>(v);
-            s1v += qv;
-            s2v += qv * qv;
+      for (int g = 0; g < 4; ++g) {
+        const int co = n0 + (wn * N_REP + n) * 32 + 8 * g + 4 * h;
+        T pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[m][n][4 * g + j];
+          pk[j] = from_f32<T>(v);
+          if (do_stats && ok) {
+            const float qv = to_f32<T>(pk[j]);
+            s1[4 * g + j] += qv;
+            s2[4 * g + j] += qv * qv;
+          }
+        }
+        if (ok && co < a.Cout) {
+          T* dst = (a.split_c > 0 && co >= a.split_c) ? o2 + gp * a.ldo2 + (co - a.split_c)
+                                                      : o1 + gp * a.ldo + co;
+          if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, *reinterpret_cast<const s16x4*>(pk));
+          } else {
+            *reinterpret_cast<f32x4*>(dst) = f32x4{pk[0], pk[1], pk[2], pk[3]};
           }
         }
       }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int itx = 0; itx < (32 * CPO) / 64; ++itx) {
-        const int idx = lane + itx * 64;
-        const int pix = idx / CPO, cch = idx % CPO;
-        float f[EPO];
-        const f32x4* sp = reinterpret_cast<const f32x4*>(scratch + pix * 36 + cch * EPO);
-#pragma unroll
-        for (int qq = 0; qq < EPO / 4; ++qq) {
-          const f32x4 t = sp[qq];
-          f[4 * qq] = t[0];
-          f[4 * qq + 1] = t[1];
-          f[4 * qq + 2] = t[2];
-          f[4 * qq + 3] = t[3];
-        }
-        const int q = qbase + pix;
-        const int hx = q & 15;
-        const int R = R0 + (q >> 4), w = w0 + hx - 1;
-        const int co = cobase + cch * EPO;
-        if (hx >= 1 && hx <= TW && R < a.NH && w < a.W && co < a.Cout) {
-          const size_t gp = (size_t)R * a.W + w;
-          const u32x4 pk = Chunk<T>::pack(f);
-          if (a.split_c > 0 && co >= a.split_c)
-            st16(o2 + gp * a.ldo2 + (co - a.split_c), pk);
-          else
-            st16(o1 + gp * a.ldo + co, pk);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
     }
     if (do_stats) {
-      s1v += __shfl_xor(s1v, 32, 64);
-      s2v += __shfl_xor(s2v, 32, 64);
-      if (h == 0) {
-        const int col = (wn * N_REP + n) * 32 + r;
-        sstat[(wm * 2 + 0) * BN + col] = s1v;
-        sstat[(wm * 2 + 1) * BN + col] = s2v;
+      // reduce-scatter over the 32 lanes of each half (same h): xor 16 / 8 / 4 / 2 halve the value
+      // count while they pair the lanes, xor 1 joins the last pair; a lane ends up with the total
+      // of register index ((lane>>4)&1)*8 + ((lane>>3)&1)*4 + ((lane>>2)&1)*2 + ((lane>>1)&1)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool up = (lane & 16) != 0;
+        const float snd1 = up ? s1[i] : s1[i + 8], snd2 = up ? s2[i] : s2[i + 8];
+        const float kp1 = up ? s1[i + 8] : s1[i], kp2 = up ? s2[i + 8] : s2[i];
+        s1[i] = kp1 + __shfl_xor(snd1, 16, 64);
+        s2[i] = kp2 + __shfl_xor(snd2, 16, 64);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool up = (lane & 8) != 0;
+        const float snd1 = up ? s1[i] : s1[i + 4], snd2 = up ? s2[i] : s2[i + 4];
+        const float kp1 = up ? s1[i + 4] : s1[i], kp2 = up ? s2[i + 4] : s2[i];
+        s1[i] = kp1 + __shfl_xor(snd1, 8, 64);
+        s2[i] = kp2 + __shfl_xor(snd2, 8, 64);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool up = (lane & 4) != 0;
+        const float snd1 = up ? s1[i] : s1[i + 2], snd2 = up ? s2[i] : s2[i + 2];
+        const float kp1 = up ? s1[i + 2] : s1[i], kp2 = up ? s2[i + 2] : s2[i];
+        s1[i] = kp1 + __shfl_xor(snd1, 4, 64);
+        s2[i] = kp2 + __shfl_xor(snd2, 4, 64);
+      }
+      {
+        const bool up = (lane & 2) != 0;
+        const float snd1 = up ? s1[0] : s1[1], snd2 = up ? s2[0] : s2[1];
+        const float kp1 = up ? s1[1] : s1[0], kp2 = up ? s2[1] : s2[0];
+        s1[0] = kp1 + __shfl_xor(snd1, 2, 64);
+        s2[0] = kp2 + __shfl_xor(snd2, 2, 64);
+      }
+      s1[0] += __shfl_xor(s1[0], 1, 64);
+      s2[0] += __shfl_xor(s2[0], 1, 64);
+      if ((lane & 1) == 0) {
+        const int reg = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        const int col = (wn * N_REP + n) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        sstat[(wm * 2 + 0) * BN + col] = s1[0];
+        sstat[(wm * 2 + 1) * BN + col] = s2[0];
       }
     }
   }
