@@ -533,48 +533,55 @@ __global__ void __launch_bounds__(768, 1)
 __global__ void __launch_bounds__(256)
     wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int SG, int Cout,
                         int Cin, int co_pad, int ci_pad, int accumulate) {
-  // block = (256/SG) consecutive (co,ci) outputs x SG slab groups.  Group g sums slabs
-  // g, g+SG, ... in increasing order, then the SG group sums are added in group order: the
-  // summation tree is a function of (S, SG) only => bitwise reproducible.
-  __shared__ float sred[256 * 9];
+  // thread = four consecutive ci of one co (16-byte slab reads, 36 contiguous output floats) x one
+  // of SG slab groups.  Group g sums slabs g, g+SG, ... in increasing order, then the SG group sums
+  // are added in group order: the summation tree is a function of (S, SG) only => bitwise reproducible.
+  __shared__ float sred[256 * 36];
   const int opb = 256 / SG;
   const int ol = threadIdx.x % opb, sg = threadIdx.x / opb;
-  const long total = (long)Cout * Cin;
+  const int Q = Cin / 4;
+  const long total = (long)Cout * Q;
   const long i = (long)blockIdx.x * opb + ol;
   const size_t slab = (size_t)9 * co_pad * ci_pad;
   const size_t tapstride = (size_t)co_pad * ci_pad;
-  float s[9];
+  f32x4 s[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) s[t] = 0.f;
+  for (int t = 0; t < 9; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int co = i < total ? (int)(i / Q) : 0;
+  const int ci = i < total ? (int)(i % Q) * 4 : 0;
   if (i < total) {
-    const int ci = (int)(i % Cin);
-    const int co = (int)(i / Cin);
     const size_t off = (size_t)co * ci_pad + ci;
     for (int q = sg; q < S; q += SG) {
       const float* p = ws + q * slab + off;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) s[t] += p[t * tapstride];
+      for (int t = 0; t < 9; ++t) s[t] += *reinterpret_cast<const f32x4*>(p + t * tapstride);
     }
   }
   if (SG > 1) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) sred[(sg * opb + ol) * 9 + t] = s[t];
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sred[(sg * opb + ol) * 36 + t * 4 + j] = s[t][j];
     __syncthreads();
     if (sg == 0) {
       for (int g = 1; g < SG; ++g)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) s[t] += sred[(g * opb + ol) * 9 + t];
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s[t][j] += sred[(g * opb + ol) * 36 + t * 4 + j];
     }
   }
   if (sg == 0 && i < total) {
-    float* o = dw + (size_t)i * 9;
-    if (accumulate) {
+    float* o = dw + ((size_t)co * Cin + ci) * 9;  // [co][ci][tap]: 4 ci x 9 taps contiguous
 #pragma unroll
-      for (int t = 0; t < 9; ++t) o[t] += s[t];
-    } else {
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int t = 0; t < 9; ++t) o[t] = s[t];
-    }
+      for (int t = 0; t < 9; ++t) {
+        if (accumulate)
+          o[j * 9 + t] += s[t][j];
+        else
+          o[j * 9 + t] = s[t][j];
+      }
   }
 }
 
@@ -820,7 +827,8 @@ int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, 
   }
   if (rc != CY_OK) return rc;
   const int Cin = d->C1 + d->C2;
-  const long total = (long)d->Cout * Cin;
+  if (Cin % 4) return CY_ERR_SHAPE;
+  const long total = (long)d->Cout * (Cin / 4);  // one thread per four consecutive ci
   int SG = 1;  // slab groups per output: more when there are few outputs and many slabs
   while (SG < 32 && SG * 2 <= p.S && (total * SG) / 256 < 1024) SG *= 2;
   const int opb = 256 / SG;
