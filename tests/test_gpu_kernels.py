@@ -440,3 +440,57 @@ def test_batched_weight_pack_equals_per_layer_pack(dtype):
         rf, rd = ops.pack_weights(w, dtype)
         assert torch.equal(wf, rf) and torch.equal(wd, rd), tuple(w.shape)
         assert torch.equal(wf2, rf) and torch.equal(wd2, rd), tuple(w.shape)
+
+
+def _random_conv_cases(n, seed):
+    """seeded random geometries for the conv kernels: widths that select the plane kernel (multiples
+    of 14) and widths that do not, row counts that leave partial tiles, channel counts that are not
+    multiples of the cout / chunk tiles, every load mode, concat and prologue"""
+    import random as _r
+    rng = _r.Random(seed)
+    cases = []
+    while len(cases) < n:
+        W = rng.choice([14, 28, 42, 56, 16, 24, 32])
+        H = rng.choice([14, 28, 16, 10, 6])
+        N = rng.choice([1, 2, 3, 5])
+        mode = rng.choice([0, 0, 0, 1, 2])
+        if mode == 2 and (H % 2 or W % 2):
+            continue
+        C1 = 8 * rng.randint(1, 20)
+        C2 = 0 if mode or rng.random() < 0.6 else 8 * rng.randint(1, 10)
+        Cout = 8 * rng.randint(1, 24)
+        pro = int(C2 == 0 and mode == 0 and rng.random() < 0.4)
+        cases.append((N, H, W, C1, C2, Cout, mode, pro))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_conv_cases(24, seed=11))
+def test_conv3x3_random_geometries_bf16(case):
+    """forward + statistics, data gradient and weight gradient of one random layer against torch (bf16)"""
+    ops = _ops()
+    dtype = torch.bfloat16
+    N, H, W, C1, C2, Cout, mode, pro = case
+    x1, x2, w, scale, shift = make_conv_case(case, dtype, 17)
+    g = torch.Generator().manual_seed(23)
+    dy = rnd(N, Cout, H, W, gen=g).to(dtype).float()
+    wv = w.clone().requires_grad_(True)
+    if pro:
+        a_in = F.relu(x1 * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(dtype).float()
+        ref = F.conv2d(a_in, wv, None, 1, 1)
+    else:
+        ref, a_in = conv_ref(x1, x2, wv, mode, scale, shift)
+    (ref * dy).sum().backward()
+    kw = dict(mode=mode, scale=None if scale is None else scale.to(DEV), shift=None if shift is None else shift.to(DEV))
+    wf, wd = ops.pack_weights(w.to(DEV), dtype)
+    g1, g2 = nhwc(x1, dtype), None if x2 is None else nhwc(x2, dtype)
+    out, stats = ops.conv3x3_fwd(g1, g2, wf, Cout, **kw)
+    assert_close(out, ref.detach(), TOL[dtype], f"fwd {case}")
+    o = cpu(out).double()
+    s = cpu(stats).double().sum(0)
+    assert_close(s[0] / o.numel(), o.sum(dim=(0, 2, 3)) / o.numel(), 1e-4, f"stat sum {case}")
+    assert_close(s[1] / o.numel(), (o * o).sum(dim=(0, 2, 3)) / o.numel(), 1e-4, f"stat sumsq {case}")
+    # data gradient w.r.t. the conv's (concatenated, pooled / upsampled) input
+    din, _ = ops.conv3x3_fwd(nhwc(dy, dtype), None, wd, C1 + C2, want_stats=False)
+    assert_close(din, F.conv_transpose2d(dy, w, None, 1, 1), TOL[dtype], f"dgrad {case}")
+    dw = ops.conv3x3_wgrad(g1, g2, nhwc(dy, dtype), **kw)
+    assert_close(dw, wv.grad, 2e-3, f"wgrad {case}")
