@@ -295,10 +295,12 @@ __global__ void __launch_bounds__(256, PREFA ? 1 : 2)
           af[nxt][m] = frag(sAt + abase[m][d] + (ks + 1) * 2 * NCH * APLB, APLB);
       }
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int m = 0; m < M_REP; ++m)
 #pragma unroll
         for (int n = 0; n < N_REP; ++n) M::mma(bf[cur][n], af[cur][m], acc[m][n]);  // rows = couts
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
   };

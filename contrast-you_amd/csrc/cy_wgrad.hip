@@ -487,8 +487,10 @@ __global__ void __launch_bounds__(768, 1)
         const int c2 = bcol0 ^ (SWB == 2 ? ((((p2 + d - 1) >> 1) & 1) << 6) : 0);
         bfr[d] = WFrag<bf16>::load(sIn + (p1 + d - 1) * PB + dhoff + c1, sIn + (p2 + d - 1) * PB + dhoff + c2);
       }
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int d = 0; d < 3; ++d) Mma<bf16>::mma(af, bfr[d], acc[d]);
+      __builtin_amdgcn_s_setprio(0);
     }
     if (next < ntiles) commit(next, smem + (cur ^ 1) * C::BUF, smem + (cur ^ 1) * C::BUF + C::A_BYTES);
     __syncthreads();  // this tile consumed by every wave, the next one staged
