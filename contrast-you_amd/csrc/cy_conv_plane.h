@@ -401,6 +401,7 @@ __global__ void __launch_bounds__(256, PREFA ? 1 : 2)
       int R, w;
       const bool ok = position(m, R, w);
       const size_t gp = (size_t)R * a.W + w;
+      u32x2 packed[4];  // bf16: the four 4-channel runs of this lane, packed
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int co = n0 + (wn * N_REP + n) * 32 + 8 * g + 4 * h;
@@ -415,13 +416,32 @@ __global__ void __launch_bounds__(256, PREFA ? 1 : 2)
             s2[4 * g + j] += qv * qv;
           }
         }
-        if (ok && co < a.Cout) {
+        if constexpr (sizeof(T) == 2) {
+          packed[g] = __builtin_bit_cast(u32x2, *reinterpret_cast<const s16x4*>(pk));
+        } else if (ok && co < a.Cout) {
           T* dst = (a.split_c > 0 && co >= a.split_c) ? o2 + gp * a.ldo2 + (co - a.split_c)
                                                       : o1 + gp * a.ldo + co;
-          if constexpr (sizeof(T) == 2) {
-            *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, *reinterpret_cast<const s16x4*>(pk));
-          } else {
-            *reinterpret_cast<f32x4*>(dst) = f32x4{pk[0], pk[1], pk[2], pk[3]};
+          *reinterpret_cast<f32x4*>(dst) = f32x4{pk[0], pk[1], pk[2], pk[3]};
+        }
+      }
+      if constexpr (sizeof(T) == 2) {
+        // lane i holds channels 8g+0..3, lane i+32 channels 8g+4..7 of the same position: one half-wave
+        // swap per dword of a run pair (g, g+1) leaves the lower half with channels 8g..8g+7 and the
+        // upper half with 8g+8..8g+15 -- two 16-byte stores per fragment instead of four 8-byte ones
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          u32x2 lo = packed[g], hi = packed[g + 1];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(lo[j], hi[j], false, false);
+            lo[j] = sw[0];
+            hi[j] = sw[1];
+          }
+          const int co = n0 + (wn * N_REP + n) * 32 + 8 * g + 8 * h;
+          if (ok && co < a.Cout) {
+            T* dst = (a.split_c > 0 && co >= a.split_c) ? o2 + gp * a.ldo2 + (co - a.split_c)
+                                                        : o1 + gp * a.ldo + co;
+            *reinterpret_cast<u32x4*>(dst) = u32x4{lo[0], lo[1], hi[0], hi[1]};
           }
         }
       }
