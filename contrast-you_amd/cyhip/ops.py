@@ -6,6 +6,7 @@ Activations are logical [N,C,H,W] tensors in channels_last memory (= NHWC).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Optional, Tuple
 
@@ -447,8 +448,11 @@ def conv3x3_wgrad(src1: Tensor, src2: Optional[Tensor], dy: Tensor, *, mode: int
     ws = _ws(nbytes, src1.device)
     dw = out if out is not None else torch.empty((Cout, C1 + C2, 3, 3), dtype=torch.float32, device=src1.device)
     ev = _prof_begin()
-    _lib.call("cy_conv3x3_wgrad", d.ref, src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
-              dy.data_ptr(), dw.data_ptr(), 0 if out is None else 1, ws.data_ptr(), nbytes, _stream())
+    # accumulation into a live .grad is a read-modify-write: the two passes of a step may reach the
+    # same weight from different streams
+    with (ordered(("conv_grad", out.data_ptr())) if out is not None else contextlib.nullcontext()):
+        _lib.call("cy_conv3x3_wgrad", d.ref, src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
+                  dy.data_ptr(), dw.data_ptr(), 0 if out is None else 1, ws.data_ptr(), nbytes, _stream())
     if ev is not None:
         esz = src1.element_size()
         nb = esz * (src1.numel() + (0 if src2 is None else src2.numel()) + dy.numel()) + 4 * 9 * (C1 + C2) * Cout
@@ -481,8 +485,9 @@ def conv_first_wgrad(x: Tensor, dy: Tensor, out: Optional[Tensor] = None) -> Ten
     nbytes = _lib.load().cy_conv3x3_first_wgrad_ws_bytes(N, Cin, H, W, Cout)
     ws = _ws(nbytes, x.device)
     dw = out if out is not None else torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
-    _lib.call("cy_conv3x3_first_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 0 if out is None else 1, N,
-              Cin, H, W, Cout, dtype_code(dy.dtype), ws.data_ptr(), nbytes, _stream())
+    with (ordered(("conv_grad", out.data_ptr())) if out is not None else contextlib.nullcontext()):
+        _lib.call("cy_conv3x3_first_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 0 if out is None else 1,
+                  N, Cin, H, W, Cout, dtype_code(dy.dtype), ws.data_ptr(), nbytes, _stream())
     return dw
 
 
