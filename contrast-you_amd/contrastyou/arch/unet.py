@@ -27,7 +27,8 @@ import torch
 from torch import Tensor, nn
 
 from cyhip import ops
-from cyhip.functions import ChainCfg, ConvChainFn, HeadFn, compute_dtype_for, defer_batch_counters, prepack
+from cyhip.functions import (ChainCfg, ConvChainFn, HeadFn, begin_pass, compute_dtype_for, defer_batch_counters,
+                             prepack)
 
 from ._base import _check_params, _complete_arch_start2end
 from .utils import get_bn_track, get_requires_grad
@@ -153,6 +154,7 @@ class UNet(nn.Module):
             raise ValueError("spatial dims must be multiples of 16 (four 2x2 poolings)")
         # every 3x3 weight changes with the optimizer step: repack them all with one launch (a no-op
         # while the packed images are current, e.g. for the second pass of a step)
+        begin_pass()
         prepack(self._packed_conv_weights(), compute_dtype_for(x, self._compute_dtype))
         with defer_batch_counters():
             return self._forward(x, until)

@@ -33,6 +33,14 @@ struct WgradArgs {
   int tiles_h, tiles_w;
   int S;
   int co_pad, ci_pad;
+  // second pixel segment (twelve-wave kernel): the same layer evaluated on another batch -- tile rows
+  // >= tiles_h_a belong to it.  Same geometry per image, its own tensors and BN coefficients.
+  int tiles_h_a;
+  const void* src1_b;
+  const void* src2_b;
+  const void* dy_b;
+  const float* scale_b;
+  const float* shift_b;
 };
 
 template <typename T> struct WFrag;
@@ -339,9 +347,6 @@ __global__ void __launch_bounds__(768, 1)
 
   // ---- staging: request (global -> registers) / commit (registers -> LDS buffer) ----------------
   // tiles never span images (TH | H): the image of a tile and its first row in it are uniform
-  const T* dyp = reinterpret_cast<const T*>(g.dy);
-  const T* s1 = reinterpret_cast<const T*>(a.src1);
-  const T* s2 = reinterpret_cast<const T*>(a.src2);
   const int cha = tid % CPA, chb = tid % CPB;  // constant per thread (768 % CP* == 0)
   const int HWt = TW + 2;
   const int nhalo = (TH + 2) * HWt;
@@ -351,13 +356,25 @@ __global__ void __launch_bounds__(768, 1)
   const bool pooled = a.mode1 == CY_SRC_POOL2 && !in2;  // 2x2 max on load: staged in the commit phase
   const bool pro = a.prologue && !in2 && cvalid;
   float psc[EPC], psh[EPC];
-  if (pro) {
-#pragma unroll
-    for (int j = 0; j < EPC; ++j) {
-      psc[j] = a.scale[cabs + j];
-      psh[j] = a.shift[cabs + j];
-    }
-  }
+  int coef_seg = -1;  // segment whose BN coefficients psc / psh hold
+  // the tensors of the segment a tile row belongs to (wave-uniform)
+  struct Seg {
+    const T* dy;
+    const T* s1;
+    const T* s2;
+    int rt;   // tile row inside the segment
+    int id;
+  };
+  auto segment = [&](int rt) {
+    Seg sg;
+    const bool second = rt >= g.tiles_h_a;
+    sg.id = second ? 1 : 0;
+    sg.rt = second ? rt - g.tiles_h_a : rt;
+    sg.dy = reinterpret_cast<const T*>(second ? g.dy_b : g.dy);
+    sg.s1 = reinterpret_cast<const T*>(second ? g.src1_b : a.src1);
+    sg.s2 = reinterpret_cast<const T*>(second ? g.src2_b : a.src2);
+    return sg;
+  };
   auto src_row = [&](int n, int hh) -> int {  // pixel index of (row hh of image n, column 0), or -1
     if (hh < 0 || hh >= a.H) return -1;
     if (in2 || a.mode1 == CY_SRC_DIRECT) return (n * a.H + hh) * a.W;
@@ -367,8 +384,22 @@ __global__ void __launch_bounds__(768, 1)
   u32x4 dreg[C::NDY], hreg[C::NHL];
   unsigned hok = 0;
   auto request = [&](int tile) {
-    const int ct = tile % g.tiles_w, rt = tile / g.tiles_w;
-    const int R0 = rt * TH, w0 = ct * TW;
+    const int ct = tile % g.tiles_w;
+    const Seg sg = segment(tile / g.tiles_w);
+    const T* dyp = sg.dy;
+    const T* s1 = sg.s1;
+    const T* s2 = sg.s2;
+    if (pro && sg.id != coef_seg) {  // (the tiles of a workgroup switch segment at most once)
+      const float* sc = sg.id ? g.scale_b : a.scale;
+      const float* sh = sg.id ? g.shift_b : a.shift;
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) {
+        psc[j] = sc[cabs + j];
+        psh[j] = sh[cabs + j];
+      }
+      coef_seg = sg.id;
+    }
+    const int R0 = sg.rt * TH, w0 = ct * TW;
     const int n = R0 / a.H, hh0 = R0 - n * a.H;
     const int co = co0 + cha * EPC;
 #pragma unroll
@@ -408,8 +439,10 @@ __global__ void __launch_bounds__(768, 1)
       if (k < npix_pad) st16(sDy + k * PA + (halo_chunk<PA, SWA>(k, cha) << 4), dreg[i]);
     }
     if (pooled) {
-      const int ct = tile % g.tiles_w, rt = tile / g.tiles_w;
-      const int R0 = rt * TH, w0 = ct * TW;
+      const int ct = tile % g.tiles_w;
+      const Seg sg = segment(tile / g.tiles_w);
+      const T* s1 = sg.s1;
+      const int R0 = sg.rt * TH, w0 = ct * TW;
       const int n = R0 / a.H, hh0 = R0 - n * a.H;
       for (int lin = tid / CPB; lin < nhalo; lin += NT / CPB) {
         const int hr = lin / HWt, hc = lin - hr * HWt;
@@ -781,9 +814,12 @@ size_t cy_conv3x3_wgrad_ws_bytes(const cy_conv_desc* d) {
   return (size_t)p.S * 9 * p.co_pad * p.ci_pad * sizeof(float);
 }
 
-int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
-                     const float* shift, const void* dy, float* dw, int accumulate, void* ws,
-                     size_t ws_bytes, void* stream) {
+// one launch over the pixels of `d` (segment a) and, when n_b > 0, of the same layer on a second batch
+// of n_b images (segment b: its own tensors and BN coefficients); plan from the total batch
+static int wgrad_impl(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
+                      const float* shift, const void* dy, int n_b, const void* src1_b, const void* src2_b,
+                      const float* scale_b, const float* shift_b, const void* dy_b, float* dw,
+                      int accumulate, void* ws, size_t ws_bytes, void* stream) {
   if (!d || !src1 || !dy || !dw || !ws) return CY_ERR_ARG;
   if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C1 <= 0 || d->C2 < 0 || d->Cout <= 0)
     return CY_ERR_SHAPE;
@@ -795,13 +831,19 @@ int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, 
   if (d->C2 && (!src2 || d->ld2 % epc)) return CY_ERR_ARG;
   if (d->prologue && (d->C2 || !scale || !shift)) return CY_ERR_ARG;
   if (d->mode1 == CY_SRC_UP2 && ((d->H & 1) || (d->W & 1))) return CY_ERR_SHAPE;
-  const WgPlan p = plan_wgrad(d);
+  cy_conv_desc dt = *d;  // the plan sees the total batch
+  dt.N = d->N + (n_b > 0 ? n_b : 0);
+  const WgPlan p = plan_wgrad(&dt);
+  if (n_b > 0) {
+    if (!p.twelve) return CY_ERR_DTYPE;  // two segments: twelve-wave (bf16) kernel only
+    if (!src1_b || !dy_b || (d->C2 && !src2_b) || (d->prologue && (!scale_b || !shift_b))) return CY_ERR_ARG;
+  }
   if (ws_bytes < (size_t)p.S * 9 * p.co_pad * p.ci_pad * sizeof(float)) return CY_ERR_WORKSPACE;
   WgradArgs g = {};
   ConvArgs& a = g.c;
   a.src1 = src1, a.src2 = src2, a.scale = scale, a.shift = shift, a.w = nullptr;
   a.out = nullptr, a.out2 = nullptr, a.stats = nullptr;
-  a.N = d->N, a.H = d->H, a.W = d->W, a.NH = d->N * d->H;
+  a.N = dt.N, a.H = d->H, a.W = d->W, a.NH = dt.N * d->H;
   a.C1 = d->C1, a.C2 = d->C2, a.Cout = d->Cout;
   a.mode1 = d->mode1, a.prologue = d->prologue;
   a.ld1 = d->ld1, a.ld2 = d->ld2, a.ldo = 0, a.ldo2 = 0, a.split_c = 0;
@@ -809,6 +851,8 @@ int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, 
   g.dy = dy, g.ws = (float*)ws, g.ldy = d->ldo;
   g.TH = p.TH, g.TW = p.TW, g.tiles_h = p.tiles_h, g.tiles_w = p.tiles_w, g.S = p.S;
   g.co_pad = p.co_pad, g.ci_pad = p.ci_pad;
+  g.tiles_h_a = (d->N * d->H) / p.TH;  // (TH | H: segments begin on tile rows)
+  g.src1_b = src1_b, g.src2_b = src2_b, g.dy_b = dy_b, g.scale_b = scale_b, g.shift_b = shift_b;
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (d->in_dtype == CY_F32) {
@@ -839,6 +883,30 @@ int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, 
                      p.S, SG, d->Cout, Cin, p.co_pad, p.ci_pad, accumulate);
   CY_CHECK_LAUNCH();
   return CY_OK;
+}
+
+int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
+                     const float* shift, const void* dy, float* dw, int accumulate, void* ws,
+                     size_t ws_bytes, void* stream) {
+  return wgrad_impl(d, src1, src2, scale, shift, dy, 0, nullptr, nullptr, nullptr, nullptr, nullptr, dw,
+                    accumulate, ws, ws_bytes, stream);
+}
+
+size_t cy_conv3x3_wgrad_pair_ws_bytes(const cy_conv_desc* d, int n_b) {
+  if (!d || n_b <= 0) return 0;
+  cy_conv_desc dt = *d;
+  dt.N += n_b;
+  return cy_conv3x3_wgrad_ws_bytes(&dt);
+}
+
+int cy_conv3x3_wgrad_pair(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
+                          const float* shift, const void* dy, int n_b, const void* src1_b,
+                          const void* src2_b, const float* scale_b, const float* shift_b,
+                          const void* dy_b, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                          void* stream) {
+  if (n_b <= 0) return CY_ERR_ARG;
+  return wgrad_impl(d, src1, src2, scale, shift, dy, n_b, src1_b, src2_b, scale_b, shift_b, dy_b, dw,
+                    accumulate, ws, ws_bytes, stream);
 }
 
 size_t cy_conv3x3_first_wgrad_ws_bytes(int N, int Cin, int H, int W, int Cout) {

@@ -59,6 +59,9 @@ _SIGS = {
     "cy_conv3x3_fwd": (c_int, [_PCD, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "cy_conv3x3_wgrad_ws_bytes": (c_size_t, [_PCD]),
     "cy_conv3x3_wgrad": (c_int, [_PCD, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "cy_conv3x3_wgrad_pair_ws_bytes": (c_size_t, [_PCD, c_int]),
+    "cy_conv3x3_wgrad_pair": (c_int, [_PCD, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, _P,
+                                      c_size_t, _P]),
     "cy_conv3x3_first_num_partials": (c_int, [c_int, c_int, c_int, c_int]),
     "cy_conv3x3_first_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cy_conv3x3_first_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

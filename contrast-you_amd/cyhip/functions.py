@@ -9,6 +9,7 @@ nearest-upsample and channel concat are addressing modes of the consuming conv).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -90,6 +91,97 @@ def prepack(weights, dtype: torch.dtype) -> None:
                                                         wf, wd, ev, cur, capid)
 
 
+# ---- weight gradients of a layer that two passes of one step go through ------------------------------
+# SemiSupervisedEpocher's two-stage step evaluates the network twice (labeled batch; unlabeled batch +
+# its transformed view) and both backward passes add into the same .grad.  Instead of two launches
+# (each with its own slab traffic and slab reduction) the pass that reaches a weight FIRST in the
+# backward order parks its operands, the second one issues ONE launch over both batches
+# (cy_conv3x3_wgrad_pair).  A forward-use counter per weight says whether a partner can still come;
+# whatever is still parked when the backward pass ends (the partner's branch got no gradient: e.g. the
+# decoder of the unlabeled pass) is issued then as an ordinary single launch.
+# Backward passes run in reverse forward order (autograd serves the node with the highest sequence
+# number first), so the pass that was evaluated FIRST in a step is differentiated last: it never parks
+# -- nobody can come after it -- and takes along what the later passes parked.
+PAIR_WGRAD = os.environ.get("CY_PAIR_WGRAD", "1") != "0"
+_parked = {}  # id(weight) -> _Parked
+_keepalive = []  # operands of joint launches issued from another stream, until the backward pass ends
+_pass_serial = 0          # network evaluations so far (begin_pass)
+_step_first_pass = None   # serial of the first evaluation since the last backward pass ended
+
+
+def begin_pass() -> int:
+    """called by the network's forward: a new evaluation (pass) begins"""
+    global _pass_serial, _step_first_pass
+    _pass_serial += 1
+    if _step_first_pass is None and torch.is_grad_enabled():  # (evaluation passes are not differentiated)
+        _step_first_pass = _pass_serial
+    return _pass_serial
+
+
+class _Parked:
+    __slots__ = ("w", "sink", "src1", "src2", "dy", "mode", "scale", "shift", "stream", "event", "capid")
+
+
+def note_forward_use(w: Tensor, needs_grad: bool) -> None:
+    """called by a Function's forward (where grad mode is always off: `needs_grad` comes from
+    ctx.needs_input_grad, which is False under an outer no_grad)"""
+    if PAIR_WGRAD and needs_grad:
+        w.__dict__["_cy_uses"] = w.__dict__.get("_cy_uses", 0) + 1
+
+
+def _flush_parked() -> None:
+    global _step_first_pass
+    _step_first_pass = None
+    _keepalive.clear()
+    for key in list(_parked):
+        p = _parked.pop(key)
+        p.w.__dict__["_cy_uses"] = 0
+        with torch.cuda.stream(p.stream):
+            ops.conv3x3_wgrad(p.src1, p.src2, p.dy, mode=p.mode, scale=p.scale, shift=p.shift, out=p.sink)
+        ops.note_side_work(p.stream)  # (a no-op for the home stream's join; covers a parked side stream)
+
+
+def wgrad_into_sink(w: Tensor, sink: Tensor, src1: Tensor, src2: Optional[Tensor], dy: Tensor, mode: int,
+                    scale: Optional[Tensor], shift: Optional[Tensor], pass_id: int) -> None:
+    """sink += dw of one 3x3 conv, pairing the two passes of a step into one launch where it can"""
+    uses = w.__dict__.get("_cy_uses", 0)
+    if uses > 0:
+        uses -= 1
+        w.__dict__["_cy_uses"] = uses
+    cur = torch.cuda.current_stream(dy.device)
+    p = _parked.pop(id(w), None)
+    if p is not None and p.sink is sink and p.mode == mode and p.src1.shape[1:] == src1.shape[1:]:
+        if p.stream != cur and p.capid == ops._capture_id(cur):
+            cur.wait_event(p.event)
+        ops.conv3x3_wgrad_pair(p.src1, p.src2, p.dy, p.scale, p.shift, src1, src2, dy, scale, shift,
+                               mode=mode, out=sink)
+        if p.stream != cur:
+            if ops.CAPTURING:
+                # inside a capture record_stream is not available: keep the other stream's operands
+                # alive until the backward pass (= the capture) ends, so that its allocator cannot hand
+                # their memory out again while this launch reads it
+                _keepalive.append(p)
+            else:
+                for t in (p.src1, p.src2, p.dy, p.scale, p.shift):
+                    if t is not None:
+                        t.record_stream(cur)
+        return
+    if p is not None:  # not the same layer geometry after all: issue it on its own
+        _parked[id(w)] = p
+        _flush_parked()
+    if PAIR_WGRAD and uses > 0 and pass_id != _step_first_pass and src1.dtype == torch.bfloat16:
+        q = _Parked()
+        q.w, q.sink, q.src1, q.src2, q.dy, q.mode, q.scale, q.shift = w, sink, src1, src2, dy, mode, scale, shift
+        q.stream, q.event, q.capid = cur, torch.cuda.Event(), ops._capture_id(cur)
+        q.event.record(cur)
+        _parked[id(w)] = q
+        ops.at_backward_end(_flush_parked)
+        return
+    if _step_first_pass is not None:
+        ops.at_backward_end(_flush_parked)  # (also re-arms the pass bookkeeping for the next step)
+    ops.conv3x3_wgrad(src1, src2, dy, mode=mode, scale=scale, shift=shift, out=sink)
+
+
 def compute_dtype_for(x: Tensor, requested: Optional[torch.dtype]) -> torch.dtype:
     """bf16 under autocast (AMPScaler.autocast, contrastyou/amp/amp.py:44), else the requested
     dtype, else f32 (verification mode)."""
@@ -147,6 +239,7 @@ class ConvChainFn(torch.autograd.Function):
             if i == 0 and cfg.first:
                 y, part = ops.conv_first_fwd(cur, w, dt, want_stats=use_batch)
             else:
+                note_forward_use(w, ctx.needs_input_grad[3 + 3 * i])
                 wf, _ = packed_weights(w, dt)
                 y, part = ops.conv3x3_fwd(cur, cur2 if i == 0 else None, wf, Cout,
                                           mode=mode if i == 0 else 0, scale=scale, shift=shift,
@@ -166,6 +259,7 @@ class ConvChainFn(torch.autograd.Function):
             cur, cur2 = y, None
         out = ops.bn_relu_apply(ys[-1], scale, shift)
         ctx.cfg, ctx.nconv, ctx.dt = cfg, nconv, dt
+        ctx.pass_id = _pass_serial
         ctx.batch_flags = batch_flags
         ctx.x_shape = tuple(x1.shape)
         ctx.x_dtype = x1.dtype
@@ -213,10 +307,11 @@ class ConvChainFn(torch.autograd.Function):
                 if need_w:
                     if wsink is not None and ops.ASYNC_WGRAD:
                         with ops.on_side_stream(ys[i - 1], dy, ps, ph):
-                            ops.conv3x3_wgrad(ys[i - 1], None, dy, scale=ps, shift=ph, out=wsink)
+                            wgrad_into_sink(w, wsink, ys[i - 1], None, dy, 0, ps, ph, ctx.pass_id)
+                    elif wsink is not None:
+                        wgrad_into_sink(w, wsink, ys[i - 1], None, dy, 0, ps, ph, ctx.pass_id)
                     else:
-                        dw = ops.conv3x3_wgrad(ys[i - 1], None, dy, scale=ps, shift=ph, out=wsink)
-                        grads_p[3 * i] = None if wsink is not None else dw
+                        grads_p[3 * i] = ops.conv3x3_wgrad(ys[i - 1], None, dy, scale=ps, shift=ph)
                 _, wd = packed_weights(w, dt)
                 da, _ = ops.conv3x3_fwd(dy, None, wd, w.shape[1], want_stats=False)
             else:
@@ -226,12 +321,15 @@ class ConvChainFn(torch.autograd.Function):
                             if cfg.first:
                                 ops.conv_first_wgrad(x1, dy, out=wsink)
                             else:
-                                ops.conv3x3_wgrad(x1, x2, dy, mode=cfg.mode, out=wsink)
+                                wgrad_into_sink(w, wsink, x1, x2, dy, cfg.mode, None, None, ctx.pass_id)
                     else:
                         if cfg.first:
                             dw = ops.conv_first_wgrad(x1, dy, out=wsink)
+                        elif wsink is not None:
+                            wgrad_into_sink(w, wsink, x1, x2, dy, cfg.mode, None, None, ctx.pass_id)
+                            dw = None
                         else:
-                            dw = ops.conv3x3_wgrad(x1, x2, dy, mode=cfg.mode, out=wsink)
+                            dw = ops.conv3x3_wgrad(x1, x2, dy, mode=cfg.mode)
                         grads_p[0] = None if wsink is not None else dw
                 need_x1 = need[1]
                 need_x2 = ctx.has_x2 and need[2]

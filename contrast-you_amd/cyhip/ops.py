@@ -196,11 +196,12 @@ _desc_cache = {}
 class _Plan:
     """a conv descriptor with the plan numbers the library derives from it (queried once per shape:
     the host issue path is the step's critical resource)"""
-    __slots__ = ("d", "ref", "npart", "fwd_ws", "wgrad_ws")
+    __slots__ = ("d", "ref", "npart", "fwd_ws", "wgrad_ws", "pair_ws")
 
     def __init__(self, d: ConvDesc):
         self.d, self.ref = d, C.byref(d)
         self.npart = self.fwd_ws = self.wgrad_ws = None
+        self.pair_ws = {}  # images of the second segment -> workspace bytes of the paired weight gradient
 
 
 def _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, ld1, ld2, ldo, split_c=0, ldo2=0) -> _Plan:
@@ -337,9 +338,10 @@ _join_queued = False
 
 def ensure_backward_join() -> None:
     """called by backward nodes: if auxiliary streams carry work of this step (second-pass stream,
-    weight-gradient stream), make sure they are joined when the backward pass ends"""
+    weight-gradient stream) or work has been deferred to the end of the backward pass, make sure the
+    deferred work is issued and the streams are joined when the backward pass ends"""
     global _join_queued
-    if _side_pending and not _join_queued:
+    if (_side_pending or _at_backward_end) and not _join_queued:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_join_after_backward)
             _join_queued = True
@@ -347,9 +349,27 @@ def ensure_backward_join() -> None:
             pass
 
 
+_at_backward_end = []  # callables to run once when the current backward pass ends (before the joins)
+
+
+def at_backward_end(fn) -> None:
+    """run `fn()` when the backward pass that is executing ends (immediately if none is)"""
+    global _join_queued
+    if fn not in _at_backward_end:
+        _at_backward_end.append(fn)
+    if not _join_queued:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_after_backward)
+            _join_queued = True
+        except RuntimeError:  # not inside a backward pass
+            _join_after_backward()
+
+
 def _join_after_backward() -> None:
     global _join_queued
     _join_queued = False
+    while _at_backward_end:
+        _at_backward_end.pop(0)()
     join_side_streams()
 
 
@@ -458,6 +478,31 @@ def conv3x3_wgrad(src1: Tensor, src2: Optional[Tensor], dy: Tensor, *, mode: int
         nb = esz * (src1.numel() + (0 if src2 is None else src2.numel()) + dy.numel()) + 4 * 9 * (C1 + C2) * Cout
         _prof_end(ev, "conv3x3_wgrad", 2.0 * N * H * W * 9 * (C1 + C2) * Cout, float(nb))
     return dw
+
+
+def conv3x3_wgrad_pair(src1: Tensor, src2: Optional[Tensor], dy: Tensor, scale: Optional[Tensor],
+                       shift: Optional[Tensor], src1_b: Tensor, src2_b: Optional[Tensor], dy_b: Tensor,
+                       scale_b: Optional[Tensor], shift_b: Optional[Tensor], *, mode: int, out: Tensor) -> Tensor:
+    """out += dw(segment a) + dw(segment b): the same layer on two batches (e.g. the two passes of a
+    two-stage step) in ONE launch.  bf16 tensors of equal geometry per image."""
+    require_gpu(src1, dy, src1_b, dy_b)
+    N, C1 = src1.shape[0], src1.shape[1]
+    C2 = 0 if src2 is None else src2.shape[1]
+    Cout, H, W = dy.shape[1], dy.shape[2], dy.shape[3]
+    if tuple(src1_b.shape[1:]) != tuple(src1.shape[1:]) or tuple(dy_b.shape[1:]) != tuple(dy.shape[1:]) \
+            or src1_b.dtype != src1.dtype or (src2 is None) != (src2_b is None) or (scale is None) != (scale_b is None):
+        raise ValueError("conv3x3_wgrad_pair: the two segments must be the same layer")
+    d = _desc(N, H, W, C1, C2, Cout, mode, 1 if scale is not None else 0, dtype_code(src1.dtype), C1, C2, Cout)
+    nb = src1_b.shape[0]
+    nbytes = d.pair_ws.get(nb)
+    if nbytes is None:
+        nbytes = d.pair_ws[nb] = _lib.load().cy_conv3x3_wgrad_pair_ws_bytes(d.ref, nb)
+    ws = _ws(nbytes, src1.device)
+    with ordered(("conv_grad", out.data_ptr())):
+        _lib.call("cy_conv3x3_wgrad_pair", d.ref, src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
+                  dy.data_ptr(), nb, src1_b.data_ptr(), _ptr(src2_b), _ptr(scale_b), _ptr(shift_b),
+                  dy_b.data_ptr(), out.data_ptr(), 1, ws.data_ptr(), nbytes, _stream())
+    return out
 
 
 def conv_first_fwd(x: Tensor, w: Tensor, out_dtype: torch.dtype, want_stats: bool = True):

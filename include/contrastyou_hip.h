@@ -128,6 +128,19 @@ int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, 
                      const float* shift, const void* dy, float* dw, int accumulate, void* ws,
                      size_t ws_bytes, void* stream);
 
+/* The same layer's weight gradient over TWO batches in one launch: segment a is described by `d`
+ * (d->N images), segment b has n_b images of the same geometry with its own tensors and -- if
+ * d->prologue -- its own BN coefficients.  dw (+)= dw_a + dw_b (fixed summation order).  This is what
+ * the two network passes of SemiSupervisedEpocher's two-stage step (epocher.py:348-360) contribute to
+ * one weight; one launch instead of two halves the slab traffic and the launch count of the encoder.
+ * bf16 only (CY_ERR_DTYPE otherwise). */
+size_t cy_conv3x3_wgrad_pair_ws_bytes(const cy_conv_desc* d, int n_b);
+int cy_conv3x3_wgrad_pair(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
+                          const float* shift, const void* dy, int n_b, const void* src1_b,
+                          const void* src2_b, const float* scale_b, const float* shift_b,
+                          const void* dy_b, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                          void* stream);
+
 /* First layer (input_dim 1..4, arch/unet.py:72): x is the f32 NCHW image
  * [N,Cin,H,W]; w is the reference-layout f32 weight [Cout][Cin][3][3]. */
 int cy_conv3x3_first_num_partials(int N, int H, int W, int Cout);

@@ -494,3 +494,29 @@ def test_conv3x3_random_geometries_bf16(case):
     assert_close(din, F.conv_transpose2d(dy, w, None, 1, 1), TOL[dtype], f"dgrad {case}")
     dw = ops.conv3x3_wgrad(g1, g2, nhwc(dy, dtype), **kw)
     assert_close(dw, wv.grad, 2e-3, f"wgrad {case}")
+
+
+@pytest.mark.parametrize("case", [(2, 28, 28, 64, 0, 64, 0, 1), (1, 56, 56, 32, 0, 64, 1, 0),
+                                  (3, 14, 14, 128, 0, 256, 0, 0), (2, 28, 28, 32, 32, 32, 0, 0)])
+def test_conv3x3_wgrad_pair_equals_the_sum_of_two_launches(case):
+    """cy_conv3x3_wgrad_pair: the same layer on two batches (own tensors, own BN coefficients) in one
+    launch accumulates dw_a + dw_b"""
+    ops = _ops()
+    dtype = torch.bfloat16
+    N, H, W, C1, C2, Cout, mode, pro = case
+    segs = []
+    for n, seed in ((N, 31), (N + 1, 32)):
+        c = (n,) + case[1:]
+        x1, x2, w, scale, shift = make_conv_case(c, dtype, seed)
+        g = torch.Generator().manual_seed(seed + 100)
+        dy = rnd(n, Cout, H, W, gen=g).to(dtype).float()
+        segs.append((nhwc(x1, dtype), None if x2 is None else nhwc(x2, dtype), nhwc(dy, dtype),
+                     None if scale is None else scale.to(DEV), None if shift is None else shift.to(DEV)))
+    base = torch.randn(Cout, C1 + C2, 3, 3, device=DEV)
+    ref = base.clone()
+    for s1, s2, dy, sc, sh in segs:
+        ops.conv3x3_wgrad(s1, s2, dy, mode=mode, scale=sc, shift=sh, out=ref)
+    out = base.clone()
+    (a1, a2, ady, asc, ash), (b1, b2, bdy, bsc, bsh) = segs
+    ops.conv3x3_wgrad_pair(a1, a2, ady, asc, ash, b1, b2, bdy, bsc, bsh, mode=mode, out=out)
+    assert_close(out - base, cpu(ref - base), 1e-5, f"pair wgrad {case}")
