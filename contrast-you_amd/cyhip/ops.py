@@ -498,10 +498,16 @@ def conv3x3_wgrad_pair(src1: Tensor, src2: Optional[Tensor], dy: Tensor, scale: 
     if nbytes is None:
         nbytes = d.pair_ws[nb] = _lib.load().cy_conv3x3_wgrad_pair_ws_bytes(d.ref, nb)
     ws = _ws(nbytes, src1.device)
+    ev = _prof_begin()
     with ordered(("conv_grad", out.data_ptr())):
         _lib.call("cy_conv3x3_wgrad_pair", d.ref, src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
                   dy.data_ptr(), nb, src1_b.data_ptr(), _ptr(src2_b), _ptr(scale_b), _ptr(shift_b),
                   dy_b.data_ptr(), out.data_ptr(), 1, ws.data_ptr(), nbytes, _stream())
+    if ev is not None:
+        esz = src1.element_size()
+        nbts = esz * sum(t.numel() for t in (src1, src2, dy, src1_b, src2_b, dy_b) if t is not None) \
+            + 4 * 9 * (C1 + C2) * Cout
+        _prof_end(ev, "conv3x3_wgrad", 2.0 * (N + nb) * H * W * 9 * (C1 + C2) * Cout, float(nbts))
     return out
 
 
