@@ -146,7 +146,9 @@ def wgrad_into_sink(w: Tensor, sink: Tensor, src1: Tensor, src2: Optional[Tensor
     """sink += dw of one 3x3 conv, pairing the two passes of a step into one launch where it can"""
     uses = w.__dict__.get("_cy_uses", 0)
     if uses > 0:
-        uses -= 1
+        # (the step's first pass is differentiated last: whatever the counter still says then -- an
+        # evaluation that never reached a loss -- must not leak into the next step)
+        uses = 0 if pass_id == _step_first_pass else uses - 1
         w.__dict__["_cy_uses"] = uses
     cur = torch.cuda.current_stream(dy.device)
     p = _parked.pop(id(w), None)
