@@ -116,7 +116,27 @@ class FusedRAdam(torch.optim.Optimizer):
         pending, self._pending = getattr(self, "_pending", None), None
         if pending is not None:
             self._apply_state(pending)
+        self.broadcast_state()
         bump_weights_epoch()
+
+    def broadcast_state(self, src: int = 0):
+        """data-parallel replicas must start from identical parameters and moments (the gradient all-reduce
+        keeps them identical from then on): what DistributedDataParallel's constructor does for the
+        reference's plain modules.  One broadcast per flat buffer; called whenever the flat buffers are
+        (re)built and after a checkpoint has been applied."""
+        if not self._dp:
+            return
+        src_global = dist.get_global_rank(self._pg, src) if self._pg is not None else src
+        for i, f in enumerate(self._flat):
+            if f is None:
+                continue
+            st = self._flat_state[i]
+            for buf in (f.data, st["exp_avg"], st["exp_avg_sq"]):
+                dist.broadcast(buf, src=src_global, group=self._pg)
+            meta = torch.tensor([st["step"], *st["steps"]], dtype=torch.int64, device=f.data.device)
+            dist.broadcast(meta, src=src_global, group=self._pg)
+            vals = meta.tolist()
+            st["step"], st["steps"] = int(vals[0]), [int(v) for v in vals[1:]]
 
     def _needs_flat(self) -> bool:
         return any(f is None or f.stale() for f in self._flat)
@@ -157,6 +177,7 @@ class FusedRAdam(torch.optim.Optimizer):
         if not self._needs_flat():
             self._pending = None
             self._apply_state(state)
+            self.broadcast_state()
 
     def _apply_state(self, state):
         for i, st in state["flat"].items():

@@ -814,7 +814,7 @@ int first_conv_blocks(long npix, int Cout) {
 // ---------------------------------------------------------------------------
 extern "C" {
 
-int cy_abi_version(void) { return 5; }
+int cy_abi_version(void) { return 6; }
 const char* cy_build_arch(void) { return "gfx950"; }
 
 unsigned long long cy_stream_capture_id(void* stream) {
@@ -893,6 +893,19 @@ static ConvPlan plan_of(const cy_conv_desc* d) {
 int cy_conv3x3_num_partials(const cy_conv_desc* d) {
   if (conv_check(d) != CY_OK) return CY_ERR_ARG;
   return plan_of(d).partials;
+}
+
+int cy_conv3x3_plan(const cy_conv_desc* d, cy_conv_plan* plan) {
+  const int rc = conv_check(d);
+  if (rc != CY_OK) return rc;
+  if (!plan) return CY_ERR_ARG;
+  const ConvPlan p = plan_of(d);
+  plan->kernel = p.plane ? 1 : 0;
+  plan->th = p.tile.th, plan->tw = p.tile.tw, plan->bn = p.tile.bn;
+  plan->ksplit = p.ksplit, plan->one_per_cu = p.one_per_cu ? 1 : 0, plan->partials = p.partials;
+  plan->workgroups = cy_cdiv((long)d->N * d->H, p.tile.th) * cy_cdiv(d->W, p.tile.tw) *
+                     cy_cdiv(d->Cout, p.tile.bn) * p.ksplit;
+  return CY_OK;
 }
 
 size_t cy_conv3x3_fwd_ws_bytes(const cy_conv_desc* d) {

@@ -7,19 +7,24 @@
 
 namespace {
 
-// output pixel (oy,ox) -> input pixel (iy,ix) under theta (affine_grid/grid_sample
-// conventions, align_corners=False, nearest = round-half-to-even); returns false when
-// the source is outside the image (zero padding).
+// output pixel (oy,ox) -> input pixel (iy,ix) under theta (affine_grid / grid_sample conventions,
+// align_corners=False, nearest = round-half-to-even); returns false when the source is outside the
+// image (zero padding).  Nearest-neighbour sampling is discontinuous in the source coordinate, so the
+// coordinate arithmetic is part of the definition: it is done in f64, one correctly rounded operation
+// at a time in the order written here (no FMA contraction), which any IEEE-754 host reproduces bit for
+// bit (oracle.losses.affine_source_index).
 __device__ __forceinline__ bool affine_src(const float* th, int oy, int ox, int H, int W, int* iy,
                                            int* ix) {
-  const float xo = (2.f * ox + 1.f) / (float)W - 1.f;
-  const float yo = (2.f * oy + 1.f) / (float)H - 1.f;
-  const float xi = th[0] * xo + th[1] * yo + th[2];
-  const float yi = th[3] * xo + th[4] * yo + th[5];
-  const float px = ((xi + 1.f) * (float)W - 1.f) * 0.5f;
-  const float py = ((yi + 1.f) * (float)H - 1.f) * 0.5f;
-  const float rx = nearbyintf(px), ry = nearbyintf(py);
-  if (!(rx >= 0.f && rx <= (float)(W - 1) && ry >= 0.f && ry <= (float)(H - 1))) return false;
+#pragma clang fp contract(off)
+  const double t0 = th[0], t1 = th[1], t2 = th[2], t3 = th[3], t4 = th[4], t5 = th[5];
+  const double xo = __dsub_rn(__ddiv_rn((double)(2 * ox + 1), (double)W), 1.0);
+  const double yo = __dsub_rn(__ddiv_rn((double)(2 * oy + 1), (double)H), 1.0);
+  const double xi = __dadd_rn(__dadd_rn(__dmul_rn(t0, xo), __dmul_rn(t1, yo)), t2);
+  const double yi = __dadd_rn(__dadd_rn(__dmul_rn(t3, xo), __dmul_rn(t4, yo)), t5);
+  const double px = __dmul_rn(__dsub_rn(__dmul_rn(__dadd_rn(xi, 1.0), (double)W), 1.0), 0.5);
+  const double py = __dmul_rn(__dsub_rn(__dmul_rn(__dadd_rn(yi, 1.0), (double)H), 1.0), 0.5);
+  const double rx = rint(px), ry = rint(py);
+  if (!(rx >= 0.0 && rx <= (double)(W - 1) && ry >= 0.0 && ry <= (double)(H - 1))) return false;
   *ix = (int)rx;
   *iy = (int)ry;
   return true;

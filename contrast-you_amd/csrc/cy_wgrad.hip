@@ -808,6 +808,17 @@ int first_wgrad_blocks(long npix) {
 
 extern "C" {
 
+int cy_conv3x3_wgrad_plan(const cy_conv_desc* d, int n_b, cy_wgrad_plan* plan) {
+  if (!d || !plan || d->Cout <= 0 || d->C1 <= 0 || d->H <= 0 || d->W <= 0 || d->N <= 0 || n_b < 0) return CY_ERR_ARG;
+  cy_conv_desc dt = *d;
+  dt.N += n_b;
+  const WgPlan p = plan_wgrad(&dt);
+  plan->twelve = p.twelve ? 1 : 0;
+  plan->wco = p.wco, plan->wci = p.wci, plan->wk = p.wk, plan->th = p.TH, plan->tw = p.TW, plan->splits = p.S;
+  plan->workgroups = (p.co_pad / (32 * p.wco)) * (p.ci_pad / (32 * p.wci)) * p.S;
+  return CY_OK;
+}
+
 size_t cy_conv3x3_wgrad_ws_bytes(const cy_conv_desc* d) {
   if (!d || d->Cout <= 0 || d->C1 <= 0 || d->H <= 0 || d->W <= 0 || d->N <= 0) return 0;
   const WgPlan p = plan_wgrad(d);

@@ -11,7 +11,7 @@ from pathlib import Path
 
 CY_F32, CY_BF16 = 0, 1
 CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2 = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _ERRORS = {-1: "CY_ERR_ARG (bad/NULL argument)", -2: "CY_ERR_SHAPE (unsupported shape)",
            -3: "CY_ERR_DTYPE (unsupported dtype)", -4: "CY_ERR_LAUNCH (HIP launch failed)",
@@ -42,6 +42,16 @@ class PackItem(C.Structure):
                 ("ci_pad2", c_int32), ("co_pad2", c_int32)]
 
 
+class ConvPlan(C.Structure):
+    """mirror of cy_conv_plan"""
+    _fields_ = [(n, c_int32) for n in ("kernel", "th", "tw", "bn", "ksplit", "one_per_cu", "partials", "workgroups")]
+
+
+class WgradPlan(C.Structure):
+    """mirror of cy_wgrad_plan"""
+    _fields_ = [(n, c_int32) for n in ("twelve", "wco", "wci", "wk", "th", "tw", "splits", "workgroups")]
+
+
 _P = c_void_p
 _PCD = POINTER(ConvDesc)
 
@@ -55,6 +65,8 @@ _SIGS = {
     "cy_conv3x3_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "cy_conv3x3_pack_weights_batched": (c_int, [_P, c_int, C.c_longlong, _P, _P, c_int, _P]),
     "cy_conv3x3_num_partials": (c_int, [_PCD]),
+    "cy_conv3x3_plan": (c_int, [_PCD, POINTER(ConvPlan)]),
+    "cy_conv3x3_wgrad_plan": (c_int, [_PCD, c_int, POINTER(WgradPlan)]),
     "cy_conv3x3_fwd_ws_bytes": (c_size_t, [_PCD]),
     "cy_conv3x3_fwd": (c_int, [_PCD, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "cy_conv3x3_wgrad_ws_bytes": (c_size_t, [_PCD]),

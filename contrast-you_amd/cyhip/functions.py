@@ -43,6 +43,13 @@ class defer_batch_counters:
         return False
 
 
+# Introspection tap for parity tests (the counterpart of a forward hook for what a block does NOT
+# materialise): when set to a callable it receives, for every conv of every block evaluation,
+# (bn module, raw conv output y, BN scale, BN shift, materialised block output or None) -- exactly the
+# tensors the kernels route ReLU / max-pool decisions by.  None (the default) costs nothing.
+RAW_TAP = None
+
+
 def bump_weights_epoch() -> None:
     global _weights_epoch
     _weights_epoch += 1
@@ -260,6 +267,9 @@ class ConvChainFn(torch.autograd.Function):
             batch_flags.append(use_batch)
             cur, cur2 = y, None
         out = ops.bn_relu_apply(ys[-1], scale, shift)
+        if RAW_TAP is not None:
+            for i in range(nconv):
+                RAW_TAP(cfg.bns[i], ys[i], coefs[i][0], coefs[i][1], out if i == nconv - 1 else None)
         ctx.cfg, ctx.nconv, ctx.dt = cfg, nconv, dt
         ctx.pass_id = _pass_serial
         ctx.batch_flags = batch_flags

@@ -128,6 +128,12 @@ class GraphedTwoPass:
         self._wrapper.train(model.training)
         params = [p for p in model.parameters() if p.requires_grad]
         state = {k: v.clone() for k, v in model.state_dict().items()}
+        # warm-up and capture run the passes for real and accumulate garbage into the live .grad buffers.
+        # Inside a gradient-accumulation window (AMPScaler.optimizer_zero only zeroes every
+        # accumulate_iter steps, contrastyou/amp/amp.py:33-39) those buffers hold the previous
+        # micro-batches' gradients: snapshot them (and the "received a gradient" flags) and put them back.
+        grads_before = [p.grad.detach().clone() for p in params]
+        touched_before = [bool(p.__dict__.get("_cy_touched", False)) for p in params]
         silence = _silenced_taps(model, self.taps)  # the real taps must not see warm-up / capture tensors
         silence.__enter__()
         for p in params:
@@ -150,13 +156,13 @@ class GraphedTwoPass:
             F.bump_weights_epoch()
             silence.__exit__()
             # warm-up and capture ran the passes for real (also when the capture failed half-way): put
-            # running statistics / counters back and drop the garbage gradients they accumulated
+            # running statistics / counters and the gradient buffers back
             torch.cuda.synchronize()
             with torch.no_grad():
                 model.load_state_dict(state, strict=True)
-                torch._foreach_zero_([p.grad for p in params])
-            for p in params:
-                p.__dict__["_cy_touched"] = False
+                torch._foreach_copy_([p.grad for p in params], grads_before)
+            for p, t in zip(params, touched_before):
+                p.__dict__["_cy_touched"] = t
 
     def __call__(self, xa: Tensor, xb: Tensor) -> Tuple[Tensor, Tensor]:
         ops.note_home_stream(xa.device)

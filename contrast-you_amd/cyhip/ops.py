@@ -216,6 +216,28 @@ def _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, ld1, ld2, ldo, split_c=0, l
     return p
 
 
+KERNEL_NAMES = {0: "conv3x3_igemm_kernel", 1: "conv3x3_plane_kernel", 2: "conv3x3_pc_kernel"}
+
+
+def conv3x3_plan(N, H, W, C1, C2, Cout, dtype: torch.dtype, mode: int = 0, prologue: bool = False) -> dict:
+    """the launch plan of cy_conv3x3_fwd for this layer geometry (host-side query, no GPU needed)"""
+    d = _desc(N, H, W, C1, C2, Cout, mode, 1 if prologue else 0, dtype_code(dtype), C1, C2, Cout)
+    p = _lib.ConvPlan()
+    _lib.call("cy_conv3x3_plan", d.ref, C.byref(p))
+    out = {f: getattr(p, f) for f, _ in p._fields_}
+    out["kernel"] = KERNEL_NAMES[out["kernel"]]
+    return out
+
+
+def conv3x3_wgrad_plan(N, H, W, C1, C2, Cout, dtype: torch.dtype, mode: int = 0, prologue: bool = False,
+                       n_b: int = 0) -> dict:
+    """the launch plan of cy_conv3x3_wgrad (n_b > 0: of cy_conv3x3_wgrad_pair) for this layer geometry"""
+    d = _desc(N, H, W, C1, C2, Cout, mode, 1 if prologue else 0, dtype_code(dtype), C1, C2, Cout)
+    p = _lib.WgradPlan()
+    _lib.call("cy_conv3x3_wgrad_plan", d.ref, n_b, C.byref(p))
+    return {f: getattr(p, f) for f, _ in p._fields_}
+
+
 def _out_hw(src1: Tensor, mode: int) -> Tuple[int, int]:
     H, W = src1.shape[2], src1.shape[3]
     if mode == CY_SRC_POOL2:

@@ -1,7 +1,9 @@
 """Mean-teacher regulariser (semi_seg/hooks/mt.py:49-207): an EMA teacher copy of the model
-predicts the unlabeled batch (no grad, train-mode BN unless update_bn), its logits go through the
-same affine map, and weight * MSE(softmax(teacher_tf), softmax(student_tf)) is added; after the
-step the teacher is updated by `EMAUpdater` = cy_ema_update over every parameter."""
+predicts the unlabeled batch (no grad; train-mode BN, or -- with update_bn, where the EMA also tracks
+the running statistics -- every teacher BatchNorm in eval mode, mt.py:162-166), its logits go through
+the same affine map, and weight * MSE(softmax(teacher_tf) [hard_clip: its arg-max one-hot, mt.py:190-192],
+softmax(student_tf)) is added; after the step the teacher is updated by `EMAUpdater` = cy_ema_update
+over every parameter."""
 from __future__ import annotations
 
 from copy import deepcopy
@@ -55,7 +57,8 @@ class MeanTeacherTrainerHook(TrainerHook):
 
     def __call__(self):
         return _MeanTeacherEpocherHook(name=self._hook_name, weight=self._weight, model=self.trainer._model,
-                                       teacher_model=self._teacher_model, updater=self._updater)
+                                       teacher_model=self._teacher_model, updater=self._updater,
+                                       hard_clip=self._hard_clip)
 
     @property
     def teacher_model(self):
@@ -67,10 +70,16 @@ class MeanTeacherTrainerHook(TrainerHook):
 
 
 class _MeanTeacherEpocherHook(EpocherHook):
-    def __init__(self, *, name: str, weight: float, model, teacher_model, updater: EMAUpdater) -> None:
+    def __init__(self, *, name: str, weight: float, model, teacher_model, updater: EMAUpdater,
+                 hard_clip: bool = False) -> None:
         super().__init__(name=name)
         self._weight, self._model, self._teacher_model, self._updater = weight, model, teacher_model, updater
+        self._hard_clip = hard_clip
         self._teacher_model.train()
+        if updater._update_bn:  # the EMA'd running statistics are the ones to use: freeze every BN to eval()
+            for m in self._teacher_model.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
 
     def configure_meters_given_epocher(self, meters: MeterInterface):
         meters = super().configure_meters_given_epocher(meters)
@@ -81,6 +90,12 @@ class _MeanTeacherEpocherHook(EpocherHook):
         with torch.no_grad():
             teacher_logits = self._teacher_model(unlabeled_image)
             teacher_logits_tf = affine_transformer(teacher_logits)
+            if self._hard_clip:
+                # one-hot of the teacher's arg-max class, expressed as logits whose softmax IS that one-hot
+                # (exp(-1e4) == 0 in f32), so that the fused softmax-pair MSE kernel applies unchanged
+                C = teacher_logits_tf.shape[1]
+                hard = torch.nn.functional.one_hot(teacher_logits_tf.argmax(1), C).movedim(-1, 1)
+                teacher_logits_tf = hard.to(torch.float32) * 1e4
         loss = SoftmaxMSEFn.apply(teacher_logits_tf.detach(), unlabeled_tf_logits)
         self.meters["loss"].add(loss.detach())
         return self._weight * loss

@@ -110,6 +110,19 @@ int cy_conv3x3_pack_weights_batched(const cy_pack_item* items, int n_items, long
  * (stats buffer is float[num_partials][2][Cout]: sum, sum of squares). */
 int cy_conv3x3_num_partials(const cy_conv_desc* d);
 
+/* The launch plan the library derives for `d`: which kernel instantiation cy_conv3x3_fwd will run.
+ * Parity tests assert on it, so that every instantiation that appears in profiles/ is known to be
+ * covered by a test that provably took it (the plan depends on N, H, W, channel counts and dtype). */
+typedef struct cy_conv_plan {
+  int32_t kernel;     /* 0: conv3x3_igemm_kernel, 1: conv3x3_plane_kernel, 2: conv3x3_pc_kernel */
+  int32_t th, tw, bn; /* output tile (rows x columns) and output channels per workgroup */
+  int32_t ksplit;     /* >1: split-K over input-channel chunks + conv_splitk_finish_kernel */
+  int32_t one_per_cu; /* plane kernel, 128 couts: the one-workgroup-per-CU build with halo prefetch */
+  int32_t partials;   /* = cy_conv3x3_num_partials(d) */
+  int32_t workgroups; /* grid size of the conv launch */
+} cy_conv_plan;
+int cy_conv3x3_plan(const cy_conv_desc* d, cy_conv_plan* plan);
+
 /* out = conv3x3(concat(src1', src2), w).  stats may be NULL.  Layers with too few
  * output tiles to fill the chip run split-K over input-channel chunks and need a
  * workspace of cy_conv3x3_fwd_ws_bytes(d) bytes (0 for the others; ws may then be NULL). */
@@ -127,6 +140,16 @@ size_t cy_conv3x3_wgrad_ws_bytes(const cy_conv_desc* d);
 int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
                      const float* shift, const void* dy, float* dw, int accumulate, void* ws,
                      size_t ws_bytes, void* stream);
+
+/* Launch plan of the weight gradient for `d` (+ n_b images of a second segment, 0 for none). */
+typedef struct cy_wgrad_plan {
+  int32_t twelve;        /* 1: wgrad12_kernel (bf16), 0: wgrad_kernel */
+  int32_t wco, wci, wk;  /* wave layout: 32x32 (co,ci) blocks per workgroup and pixel splits inside it */
+  int32_t th, tw;        /* spatial tile */
+  int32_t splits;        /* pixel splits = f32 slabs summed by wgrad_reduce_kernel */
+  int32_t workgroups;
+} cy_wgrad_plan;
+int cy_conv3x3_wgrad_plan(const cy_conv_desc* d, int n_b, cy_wgrad_plan* plan);
 
 /* The same layer's weight gradient over TWO batches in one launch: segment a is described by `d`
  * (d->N images), segment b has n_b images of the same geometry with its own tensors and -- if

@@ -148,14 +148,39 @@ def dice_summary(preds: List[Tensor], targets: List[Tensor], groups: List[List[s
 
 
 # ---------------------------------------------------------------- affine augmentation
+def affine_source_index(theta: Tensor, H: int, W: int):
+    """(flat source index [N, H*W], valid mask) of the nearest-neighbour affine resampling: output pixel ->
+    normalised coordinate -> theta -> source pixel, affine_grid / grid_sample conventions
+    (align_corners=False, round-half-to-even, zeros outside).  The coordinate arithmetic is part of the
+    definition (a nearest-neighbour pick is discontinuous): f64, one IEEE operation at a time in this order --
+    the device kernel (csrc/cy_misc.hip affine_src) performs the same sequence bit for bit."""
+    t = theta.detach().to(torch.float64)  # the f32 values of theta, exactly
+    N = t.shape[0]
+    xo = ((2 * torch.arange(W, dtype=torch.float64) + 1) / float(W) - 1.0).view(1, 1, W)
+    yo = ((2 * torch.arange(H, dtype=torch.float64) + 1) / float(H) - 1.0).view(1, H, 1)
+    c = lambda i, j: t[:, i, j].view(N, 1, 1)  # noqa: E731
+    xi = (c(0, 0) * xo + c(0, 1) * yo) + c(0, 2)
+    yi = (c(1, 0) * xo + c(1, 1) * yo) + c(1, 2)
+    px = ((xi + 1.0) * float(W) - 1.0) * 0.5
+    py = ((yi + 1.0) * float(H) - 1.0) * 0.5
+    rx, ry = torch.round(px), torch.round(py)
+    valid = (rx >= 0) & (rx <= W - 1) & (ry >= 0) & (ry <= H - 1)
+    src = (ry.clamp(0, H - 1) * W + rx.clamp(0, W - 1)).long()
+    return src.view(N, H * W), valid.view(N, H * W)
+
+
 def affine_nearest(x: Tensor, theta: Tensor, gamma: Optional[Tensor] = None) -> Tensor:
     """The build's own definition of the in-step augmentation (the reference delegates to the
-    un-vendored `rising`, semi_seg/augment.py:297-311 -- parity unpinned): optional gamma x**g,
-    then nearest grid_sample of affine_grid(theta), zeros padding, align_corners=False."""
+    un-vendored `rising`, semi_seg/augment.py:297-311 -- parity unpinned): optional gamma x**g, then
+    nearest-neighbour resampling under theta with zeros padding -- F.grid_sample(F.affine_grid(theta),
+    mode="nearest", align_corners=False) with the source coordinates computed in f64
+    (`affine_source_index`), so that the pick is reproducible bit for bit on any device."""
     if gamma is not None:
-        x = x ** gamma.view(-1, 1, 1, 1)
-    grid = F.affine_grid(theta, list(x.shape), align_corners=False)
-    return F.grid_sample(x, grid, mode="nearest", padding_mode="zeros", align_corners=False)
+        x = x ** gamma.view(-1, 1, 1, 1).to(x.dtype)
+    N, C, H, W = x.shape
+    src, valid = affine_source_index(theta, H, W)
+    out = torch.gather(x.reshape(N, C, H * W), 2, src.view(N, 1, H * W).expand(N, C, H * W))
+    return (out * valid.view(N, 1, H * W).to(x.dtype)).view(N, C, H, W)
 
 
 def make_theta(scale: float, rot_deg: float, tx: float, ty: float, flip_h: bool, flip_w: bool) -> Tensor:

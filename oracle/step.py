@@ -28,21 +28,23 @@ from . import unet as ou
 def semi_step(sd: Dict[str, Tensor], psd: Dict[str, Tensor], *, labeled_image: Tensor, labeled_target: Tensor,
               unlabeled_image: Tensor, unlabeled_image_tf: Tensor, theta: Tensor, labels: List[int],
               momentum: float = 0.01, weight: float = 1.0, two_stage: bool = True,
-              feature_name: str = "Conv5", round_dtype: Optional[torch.dtype] = None):
+              feature_name: str = "Conv5", round_dtype: Optional[torch.dtype] = None,
+              force: Optional[dict] = None):
     """forward + losses of one step; `sd`/`psd` tensors that require grad receive .grad after
-    `total.backward()`.  Returns dict(total, sup, reg, label_logits, unlabeled_logits_tf)."""
+    `total.backward()`.  Returns dict(total, sup, reg, label_logits, unlabeled_logits_tf).
+    `force`: the device's own per-layer records of its passes in call order (oracle.unet.unet_forward)."""
     n_l, n_unl = labeled_image.shape[0], unlabeled_image.shape[0]
     feats_a, feats_b = {}, {}
     if two_stage:
         label_logits = ou.unet_forward(sd, labeled_image, training=True, momentum=momentum, feats=feats_a,
-                                       round_dtype=round_dtype)
+                                       round_dtype=round_dtype, force=force)
         both = ou.unet_forward(sd, torch.cat([unlabeled_image, unlabeled_image_tf], 0), training=True,
-                               momentum=momentum, feats=feats_b, round_dtype=round_dtype)
+                               momentum=momentum, feats=feats_b, round_dtype=round_dtype, force=force)
         unl_logits, unl_tf_logits = torch.split(both, [n_unl, n_unl], 0)
         collected = torch.cat([feats_a[feature_name], feats_b[feature_name]], 0)
     else:
         allv = ou.unet_forward(sd, torch.cat([labeled_image, unlabeled_image, unlabeled_image_tf], 0),
-                               training=True, momentum=momentum, feats=feats_a, round_dtype=round_dtype)
+                               training=True, momentum=momentum, feats=feats_a, round_dtype=round_dtype, force=force)
         label_logits, unl_logits, unl_tf_logits = torch.split(allv, [n_l, n_unl, n_unl], 0)
         collected = feats_a[feature_name]
     unl_logits_tf = ol.affine_nearest(unl_logits, theta)

@@ -71,16 +71,44 @@ def init_state_dict(input_dim: int, num_classes: int, max_channel: int, seed: in
     return sd
 
 
+def _take_forced(force: Optional[dict], prefix: str):
+    """next recorded evaluation of the BN layer `prefix` (see `unet_forward(force=)`), or None"""
+    if force is None:
+        return None
+    pos = force.setdefault("_pos", {})
+    i = pos.get(prefix, 0)
+    pos[prefix] = i + 1
+    return force[prefix][i]
+
+
+def _force_raw(y: Tensor, e: Optional[dict]) -> Tensor:
+    """value of the device's raw conv output, gradient path of the exact one"""
+    if e is None:
+        return y
+    return y + (e["y"].to(y.dtype) - y).detach()
+
+
 def _bn_relu(sd, prefix: str, y: Tensor, training: bool, momentum: float, track: bool,
-             round_dtype: Optional[torch.dtype]) -> Tensor:
+             round_dtype: Optional[torch.dtype], forced: Optional[dict] = None) -> Tensor:
     """nn.BatchNorm2d(momentum) + ReLU (unet.py:22-23): biased batch variance for the
-    normalisation, unbiased for the running estimate, eps 1e-5."""
+    normalisation, unbiased for the running estimate, eps 1e-5.
+    `forced` (a record of the device's own evaluation: raw output y, BN scale / shift, block output a)
+    pins the ReLU routing to the device's decisions and the activation VALUES to the device's, so that
+    the derivative computed here is the exact derivative of the function the device evaluated."""
     rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
     use_batch = training
     out = F.batch_norm(y, rm if (not training or track) else None, rv if (not training or track) else None,
                        sd[prefix + ".weight"], sd[prefix + ".bias"], use_batch, momentum, 1e-5)
     if training and track:
         sd[prefix + ".num_batches_tracked"] += 1
+    if forced is not None:
+        # the device routes by fmaf(scale, y, shift) > 0 in f32; the f64 product of two f32 values is
+        # exact and the f64 sum cannot change the sign, so this is the same predicate
+        pre = (forced["scale"].double().view(1, -1, 1, 1) * forced["y"].double()
+               + forced["shift"].double().view(1, -1, 1, 1))
+        out = out * (pre > 0).to(out.dtype)
+        a_dev = forced["a"] if forced.get("a") is not None else pre.clamp_min(0)
+        return out + (a_dev.to(out.dtype) - out).detach()
     out = F.relu(out)
     if round_dtype is not None:
         out = out.to(round_dtype).to(y.dtype)
@@ -91,34 +119,52 @@ def _round(t: Tensor, round_dtype: Optional[torch.dtype]) -> Tensor:
     return t if round_dtype is None else t.to(round_dtype).to(t.dtype)
 
 
-def _conv_block(sd, name: str, x: Tensor, training, momentum, track, rd, feats) -> Tensor:
+def _conv_block(sd, name: str, x: Tensor, training, momentum, track, rd, feats, force=None) -> Tensor:
     w0 = _round(sd[f"_{name}.conv.0.weight"], rd)
-    y = _round(F.conv2d(x, w0, None, 1, 1), rd)
-    a = _bn_relu(sd, f"_{name}.conv.1", y, training, momentum, track, rd)
+    e = _take_forced(force, f"_{name}.conv.1")
+    y = _force_raw(_round(F.conv2d(x, w0, None, 1, 1), rd), e)
+    a = _bn_relu(sd, f"_{name}.conv.1", y, training, momentum, track, rd, e)
     w1 = _round(sd[f"_{name}.conv.3.weight"], rd)
-    y = _round(F.conv2d(a, w1, None, 1, 1), rd)
-    a = _bn_relu(sd, f"_{name}.conv.4", y, training, momentum, track, rd)
+    e = _take_forced(force, f"_{name}.conv.4")
+    y = _force_raw(_round(F.conv2d(a, w1, None, 1, 1), rd), e)
+    a = _bn_relu(sd, f"_{name}.conv.4", y, training, momentum, track, rd, e)
     feats[name] = a
     return a
 
 
-def _up_conv(sd, name: str, x: Tensor, training, momentum, track, rd, feats) -> Tensor:
+def _up_conv(sd, name: str, x: Tensor, training, momentum, track, rd, feats, force=None) -> Tensor:
     x = F.interpolate(x, scale_factor=2, mode="nearest")  # nn.Upsample(scale_factor=2) default
     w = _round(sd[f"_{name}.up.1.weight"], rd)
-    y = _round(F.conv2d(x, w, None, 1, 1), rd)
-    a = _bn_relu(sd, f"_{name}.up.2", y, training, momentum, track, rd)
+    e = _take_forced(force, f"_{name}.up.2")
+    y = _force_raw(_round(F.conv2d(x, w, None, 1, 1), rd), e)
+    a = _bn_relu(sd, f"_{name}.up.2", y, training, momentum, track, rd, e)
     feats[name] = a
     return a
 
 
 def unet_forward(sd: Dict[str, Tensor], x: Tensor, *, training: bool = True, momentum: float = 0.1,
                  track_running_stats: bool = True, until: Optional[str] = None,
-                 round_dtype: Optional[torch.dtype] = None, feats: Optional[dict] = None) -> Tensor:
+                 round_dtype: Optional[torch.dtype] = None, feats: Optional[dict] = None,
+                 force: Optional[dict] = None) -> Tensor:
     """UNet.forward(x, until) of the reference.  `sd` BN buffers are updated in place in training
     mode.  round_dtype=torch.bfloat16 emulates the production storage precision (weights, raw
-    conv outputs and activations rounded to bf16, arithmetic in f32)."""
+    conv outputs and activations rounded to bf16, arithmetic in f32).
+    `force` = {BN prefix ("_Conv1.conv.1", "_Up5.up.2", ...): [record per evaluation, in call order]}
+    with records {"y": raw conv output, "scale", "shift": the BN coefficients, "a": block output or None}
+    taken from the device's own forward pass (cyhip.functions.RAW_TAP): values and ReLU / max-pool
+    routing are then the device's, the derivative is exact -- the deterministic gradient-parity mode
+    (a pre-activation that rounds to the other side of zero can no longer re-route a gradient)."""
     feats = {} if feats is None else feats
     t, m, k, rd = training, momentum, track_running_stats, round_dtype
+    if force is not None:
+        import functools
+        cb = functools.partial(_conv_block, force=force)
+        uc = functools.partial(_up_conv, force=force)
+        return _unet_body(sd, x, until, cb, uc, t, m, k, rd, feats)
+    return _unet_body(sd, x, until, _conv_block, _up_conv, t, m, k, rd, feats)
+
+
+def _unet_body(sd, x, until, _conv_block, _up_conv, t, m, k, rd, feats):
     e1 = _conv_block(sd, "Conv1", x, t, m, k, rd, feats)
     if until == "Conv1":
         return e1

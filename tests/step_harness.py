@@ -41,8 +41,35 @@ def rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
 
+class RawTaps:
+    """`with RawTaps(model) as rec:` -- records, per BN layer (reference-named prefix) and evaluation, the raw
+    conv output, the BN coefficients and the block output the device routes ReLU / max-pool by
+    (cyhip.functions.RAW_TAP); `rec.force` is the `force=` argument of oracle.unet.unet_forward"""
+
+    def __init__(self, model):
+        self.names = {m: n for n, m in model.named_modules() if isinstance(m, torch.nn.BatchNorm2d)}
+        self.force = {}
+
+    def __enter__(self):
+        from cyhip import functions as Fn
+
+        def tap(bn, y, scale, shift, a):
+            c = lambda t: None if t is None else t.detach().float().cpu()  # noqa: E731
+            self.force.setdefault(self.names[bn], []).append({"y": c(y), "scale": c(scale), "shift": c(shift), "a": c(a)})
+
+        self._fn, self._old = Fn, Fn.RAW_TAP
+        Fn.RAW_TAP = tap
+        return self
+
+    def __exit__(self, *exc):
+        self._fn.RAW_TAP = self._old
+        return False
+
+
 def compare_step_with_oracle(device="cuda:0", n_l=2, n_unl=3, hw=32, max_channel=128, dtype=torch.float32,
-                             two_stage=True, lr=1e-3, py_seed=0):
+                             two_stage=True, lr=1e-3, py_seed=0, pin_routing=False):
+    """pin_routing: the oracle differentiates the function the device evaluated (the device's ReLU / max-pool
+    decisions and activation values, oracle.unet.unet_forward(force=)): deterministic gradient parity"""
     from contrastyou.amp import BF16Scaler
     from contrastyou.arch import UNet
     from contrastyou.hooks.base import TrainerHook
@@ -98,7 +125,8 @@ def compare_step_with_oracle(device="cuda:0", n_l=2, n_unl=3, hw=32, max_channel
             return torch.zeros((), device=dev)
 
     random.seed(py_seed)
-    with ep.register_hook(hook(), SpyHook(name="spy")):
+    taps = RawTaps(model)
+    with ep.register_hook(hook(), SpyHook(name="spy")), taps:
         ep.run()
     torch.cuda.synchronize()
     stats = ep.get_metric()
@@ -110,14 +138,19 @@ def compare_step_with_oracle(device="cuda:0", n_l=2, n_unl=3, hw=32, max_channel
     theta_np, gam_np = AffineAugment().sample(n_unl, seed)
     theta = torch.from_numpy(theta_np)
     gam = torch.from_numpy(gam_np)
-    sd = ou.clone_state_dict(sd0, requires_grad=True)
-    psd = {k: v.clone().requires_grad_(True) for k, v in psd0.items()}
+    # (pinned routing: f64 oracle, so that what is left is the device's own f32 arithmetic error)
+    od = torch.float64 if pin_routing else torch.float32
+    sd = ou.clone_state_dict(sd0, requires_grad=True, dtype=od)
+    psd = {k: v.clone().to(od).requires_grad_(True) for k, v in psd0.items()}
     labels = ol.get_label("partition", "acdc", b["partition"], b["scan"])
-    out = ostep.semi_step(sd, psd, labeled_image=b["labeled_image"], labeled_target=b["labeled_target"],
-                          unlabeled_image=b["unlabeled_image"],
-                          unlabeled_image_tf=ol.affine_nearest(b["unlabeled_image_cf"], theta, gam), theta=theta,
+    theta = theta.to(od)
+    out = ostep.semi_step(sd, psd, labeled_image=b["labeled_image"].to(od), labeled_target=b["labeled_target"],
+                          unlabeled_image=b["unlabeled_image"].to(od),
+                          unlabeled_image_tf=ol.affine_nearest(b["unlabeled_image_cf"], theta.float(), gam).to(od),
+                          theta=theta,
                           labels=labels, momentum=0.01, two_stage=two_stage,
-                          round_dtype=torch.bfloat16 if dtype == torch.bfloat16 else None)
+                          round_dtype=torch.bfloat16 if dtype == torch.bfloat16 else None,
+                          force=taps.force if pin_routing else None)
     out["total"].backward()
     names = [k for k, v in sd.items() if v.requires_grad]
     grads = {k: sd[k].grad.clone() for k in names}

@@ -46,6 +46,18 @@ def _worker(rank: int, world: int, port: int, q):
         (zg * torch.arange(zg.numel()).view_as(zg).float()).sum().backward()
         expect = torch.arange(zg.numel()).view_as(zg).float()[3 * rank: 3 * rank + 3]
         assert torch.equal(z.grad, expect)
+        # replicas that were initialised differently (per-rank seeds, a checkpoint resumed on one rank only)
+        # are made identical when the flat buffers are built: rank 0's parameters and moments win
+        torch.manual_seed(1234 + rank)
+        net2 = torch.nn.Linear(6, 4)
+        mine = torch.cat([p.detach().reshape(-1).clone() for p in net2.parameters()])
+        opt2 = FusedRAdam(net2.parameters(), lr=1e-3)
+        opt2.zero_grad()
+        flat = opt2._flat[0].data
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1]), "parameters differ across ranks after the broadcast"
+        assert torch.equal(flat, mine) == (rank == 0)
         labels = parallel.gather_labels([f"r{rank}_{i}" for i in range(2)])
         assert labels == ["r0_0", "r0_1", "r1_0", "r1_1"]
         q.put((rank, "ok"))

@@ -160,3 +160,65 @@ def test_dice_of_trained_weights_matches_oracle():
     assert ref > 0.6, "the task must be learned for the comparison to mean anything"
     assert abs(d32 - ref) < 0.002, (d32, ref)
     assert abs(d16 - ref) < 0.002, (d16, ref)
+
+
+def test_mean_teacher_hard_clip_and_update_bn_follow_the_reference():
+    """reference semi_seg/hooks/mt.py:162-166 (update_bn: every teacher BatchNorm runs in eval mode on the
+    EMA'd running statistics and leaves them alone) and :190-192 (hard_clip: the teacher's arg-max one-hot
+    instead of its softmax)"""
+    from contrastyou.arch import UNet
+    from contrastyou.hooks.base import TrainerHook
+    from contrastyou.losses.kl import KL_div
+    from contrastyou.optim import RAdam
+    from oracle import losses as ol
+    from oracle import unet as ou
+    from semi_seg.augment import AffineAugment
+    from semi_seg.epochers import SemiSupervisedEpocher
+    from semi_seg.hooks import create_mt_hook
+
+    sd0 = ou.init_state_dict(1, 3, 128, seed=6)
+    for k in sd0:  # non-trivial running statistics, so that eval-mode BN differs from train-mode BN
+        if k.endswith("running_mean"):
+            sd0[k] = torch.linspace(-0.2, 0.2, sd0[k].numel())
+        if k.endswith("running_var"):
+            sd0[k] = torch.linspace(0.5, 1.5, sd0[k].numel())
+    g = torch.Generator().manual_seed(2)
+    n, hw = 3, 32
+    lab, unl = blob_batch(n, hw, 3, g), blob_batch(n, hw, 3, g)
+    model = UNet(input_dim=1, num_classes=3, max_channel=128, momentum=0.01)
+    model.load_state_dict(sd0)
+    model.to(DEV)
+    type(TrainerHook).names.clear()
+    mt = create_mt_hook(model=model, weight=1.0, alpha=0.99, weight_decay=1e-6, update_bn=True, hard_clip=True).to(DEV)
+    mt.register_trainer(SimpleNamespace(_model=model))
+    opt = RAdam([{"params": list(model.parameters())}], lr=1e-3, weight_decay=1e-5)
+    ep = SemiSupervisedEpocher(model=model, optimizer=opt, labeled_loader=Loader([lab]), unlabeled_loader=Loader([unl]),
+                               sup_criterion=KL_div(), num_batches=1, device=DEV, two_stage=True,
+                               scaler=torch.amp.GradScaler("cuda", enabled=False), accumulate_iter=1)
+    ep.init()
+    tbuf_before = {k: v.clone() for k, v in mt.teacher_model.named_buffers() if "running" in k}
+    random.seed(4)
+    with ep.register_hook(mt()) as _:
+        assert not any(m.training for m in mt.teacher_model.modules() if isinstance(m, torch.nn.BatchNorm2d))
+        ep.run()
+    stats = ep.get_metric()
+
+    random.seed(4)
+    seed = random.randint(0, int(1e7))
+    th, gam = AffineAugment().sample(n, seed)
+    theta, gam = torch.from_numpy(th), torch.from_numpy(gam)
+    sd = ou.clone_state_dict(sd0)
+    unl_tf = ol.affine_nearest(unl["img"][1], theta, gam)
+    ou.unet_forward(sd, lab["img"][0], training=True, momentum=0.01)
+    both = ou.unet_forward(sd, torch.cat([unl["img"][0], unl_tf]), training=True, momentum=0.01)
+    t_logits = ou.unet_forward(ou.clone_state_dict(sd0), unl["img"][0], training=False)  # eval-mode BN
+    t_tf = ol.affine_nearest(t_logits, theta)
+    hard = F.one_hot(t_tf.softmax(1).argmax(1), 3).movedim(-1, 1).float()
+    l_mt = F.mse_loss(hard, both[n:].softmax(1))
+    assert abs(stats["mt"]["loss"] - l_mt.item()) < 1e-4 * abs(l_mt.item()) + 1e-7, (stats["mt"]["loss"], l_mt.item())
+    # the teacher's forward left its running statistics alone; only the EMA (alpha = 0 at step 0) moved them
+    for k, v in mt.teacher_model.named_buffers():
+        if "running" in k:
+            student = dict(model.named_buffers())[k]
+            assert torch.allclose(v, student * (1 - 1e-6), rtol=1e-5, atol=1e-7), k
+            assert not torch.equal(v, tbuf_before[k])

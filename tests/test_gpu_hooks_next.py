@@ -248,9 +248,12 @@ def test_semi_trainer_two_epochs_schedule_checkpoint_resume(tmp_path):
     assert len((tmp_path / "storage.csv").read_text().strip().splitlines()) == 4
 
 
-def test_hip_graph_replay_of_the_two_passes_equals_eager_steps():
+@pytest.mark.parametrize("accumulate_iter", [1, 2])
+def test_hip_graph_replay_of_the_two_passes_equals_eager_steps(accumulate_iter):
     """cyhip.graphed: step 1 probes gradient flow eagerly, step 2 captures, steps 3-4 replay; weights,
-    BN statistics and meters after four steps must equal four eager steps from the same state"""
+    BN statistics and meters after four steps must equal four eager steps from the same state.
+    accumulate_iter=2: the capture happens INSIDE a gradient-accumulation window (the first micro-batch's
+    gradients are live in .grad while warm-up and capture run) and must not disturb it."""
     from contrastyou.amp import BF16Scaler
     from contrastyou.arch import UNet
     from contrastyou.hooks.base import TrainerHook
@@ -283,7 +286,7 @@ def test_hip_graph_replay_of_the_two_passes_equals_eager_steps():
                     weight_decay=1e-4)
         ep = SemiSupervisedEpocher(model=model, optimizer=opt, labeled_loader=Loader(lab), unlabeled_loader=Loader(unl),
                                    sup_criterion=KL_div(), num_batches=steps, cur_epoch=0, device=DEV, two_stage=True,
-                                   disable_bn=False, scaler=BF16Scaler(), accumulate_iter=1)
+                                   disable_bn=False, scaler=BF16Scaler(), accumulate_iter=accumulate_iter)
         ep.init()
         random.seed(9)
         with ep.register_hook(hook()):

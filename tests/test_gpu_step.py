@@ -13,9 +13,20 @@ def test_f32_step_matches_oracle(two_stage):
     assert r["rel_sup"] < 1e-4 and r["rel_reg"] < 1e-4 and r["rel_total"] < 1e-4, r
     assert r["rel_logits"] < 1e-4 and r["rel_logits_tf"] < 1e-4, r
     assert r["rel_running_mean"] < 1e-4, r
-    assert r["rel_grad_worst"] < 2e-2, r          # f32 CPU autograd vs f32 GPU, cancellation-heavy grads
     assert r["rel_param_after_step"] < 2e-3, r    # one RAdam step of size lr on O(0.1) weights
     assert r["rel_proj_after_step"] < 2e-3, r
+
+
+@pytest.mark.parametrize("two_stage", [True, False])
+def test_f32_step_gradients_with_pinned_routing(two_stage):
+    """every parameter gradient of the composed step (two passes accumulating into one .grad, the paired
+    weight-gradient launches, the hook's projector, the affine adjoint) against the f64 oracle's derivative
+    of the function the device evaluated: deterministic, tight"""
+    from tests.step_harness import compare_step_with_oracle
+    r = compare_step_with_oracle(n_l=2, n_unl=3, hw=32, max_channel=128, dtype=torch.float32, two_stage=two_stage,
+                                 pin_routing=True)
+    assert r["rel_grad_worst"] < 2e-4, r
+    assert r["rel_param_after_step"] < 1e-4 and r["rel_proj_after_step"] < 1e-4, r
 
 
 def test_f32_step_larger_shape():

@@ -1,0 +1,39 @@
+"""Every conv / weight-gradient kernel instantiation that the benchmark profile (profiles/) shows is reached
+by a parity case of tests/test_gpu_c2_geometry.py: the launch plan is a pure host-side function of the layer
+geometry (cy_conv3x3_plan / cy_conv3x3_wgrad_plan), so the coverage claim is checked here, on the CPU, and
+the GPU test asserts per case that the plan it ran is the one listed here."""
+import torch
+
+from tests import c2_layers as cl
+
+
+def _tested_kernel_names():
+    from cyhip import ops
+    names = set()
+    for N in (16, 32):
+        for name, H, C1, C2, Cout, mode, pro in cl.unet_layers(224, 512):
+            names.add(cl.conv_kernel_name(ops.conv3x3_plan(N, H, H, C1, C2, Cout, torch.bfloat16, mode, pro)))
+            names.add(cl.conv_kernel_name(ops.conv3x3_plan(N, H, H, Cout, 0, C1 + C2, torch.bfloat16, 0, 0)))
+            names.add(cl.wgrad_kernel_name(ops.conv3x3_wgrad_plan(N, H, H, C1, C2, Cout, torch.bfloat16, mode, pro)))
+    for name, H, C1, C2, Cout, mode, pro in cl.unet_layers(224, 512):
+        if name in cl.ENCODER:  # the two passes of the two-stage step in one launch
+            names.add(cl.wgrad_kernel_name(ops.conv3x3_wgrad_plan(16, H, H, C1, C2, Cout, torch.bfloat16, mode, pro,
+                                                                  n_b=32)))
+    return names
+
+
+def test_every_profiled_conv_instantiation_has_a_parity_case():
+    prof = cl.profiled_conv_kernels(cl.latest_profile())
+    assert prof, "no conv kernels found in the profile summary"
+    tested = _tested_kernel_names()
+    missing = sorted(prof - tested)
+    assert not missing, f"{cl.latest_profile().name} names kernel instantiations no C2-geometry parity case reaches: {missing}"
+
+
+def test_plan_query_matches_partials_and_split():
+    from cyhip import ops
+    p = ops.conv3x3_plan(16, 28, 28, 256, 0, 256, torch.bfloat16, 0, 1)  # Conv4b at N=16
+    assert p["kernel"] in ("conv3x3_plane_kernel", "conv3x3_pc_kernel") and p["bn"] == 128
+    assert p["workgroups"] >= 192
+    w = ops.conv3x3_wgrad_plan(16, 14, 14, 512, 0, 512, torch.bfloat16, 0, 1)
+    assert w["splits"] >= 1 and w["workgroups"] >= 64
