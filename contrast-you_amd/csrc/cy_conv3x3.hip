@@ -21,6 +21,8 @@
 
 #include <cstdlib>
 
+#include "cy_conv_pc.h"
+
 namespace {
 
 template <typename T, typename TO, int TH, int TW, int BN, int WGM, int WGN, int PITCHB, bool ALLT>
@@ -939,6 +941,91 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
   rc = d->in_dtype == CY_BF16 ? dispatch_conv<bf16>(a, p, st) : dispatch_conv<float>(a, p, st);
   if (rc != CY_OK || p.ksplit == 1) return rc;
   return d->in_dtype == CY_BF16 ? launch_finish<bf16>(a, p, st) : launch_finish<float>(a, p, st);
+}
+
+// ---- persistent producer / consumer kernel (cy_conv_pc.h) ------------------------------------------
+static int pc_check(const cy_conv_desc* d) {
+  const int rc = conv_check(d);
+  if (rc != CY_OK) return rc;
+  if (d->in_dtype != CY_BF16) return CY_ERR_DTYPE;
+  if (d->W % 14) return CY_ERR_SHAPE;
+  if (d->mode1 == CY_SRC_POOL2 && d->C2) return CY_ERR_ARG;
+  return CY_OK;
+}
+static PcPlan pc_plan_of(const cy_conv_desc* d) { return plan_pc(d->N, d->H, d->W, d->C1 + d->C2, d->Cout); }
+
+long long cy_conv3x3_pc_packed_elems(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0) return CY_ERR_ARG;
+  return pc_packed_elems(Cout, Cin);
+}
+
+int cy_conv3x3_pc_pack(const float* w, void* wpc_f, void* wpc_d, int Cout, int Cin, int dtype, void* stream) {
+  if (!w || !wpc_f || Cout <= 0 || Cin <= 0) return CY_ERR_ARG;
+  if (dtype != CY_BF16) return CY_ERR_DTYPE;
+  hipStream_t st = (hipStream_t)stream;
+  {
+    const long items = pc_packed_elems(Cout, Cin) / 8;
+    const int blocks = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
+    hipLaunchKernelGGL(pack_weights_pc_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, (bf16*)wpc_f, Cout, Cin,
+                       pc_bn_for(Cout), 0);
+    CY_CHECK_LAUNCH();
+  }
+  if (wpc_d) {
+    const long items = pc_packed_elems(Cin, Cout) / 8;
+    const int blocks = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
+    hipLaunchKernelGGL(pack_weights_pc_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, (bf16*)wpc_d, Cout, Cin,
+                       pc_bn_for(Cin), 1);
+    CY_CHECK_LAUNCH();
+  }
+  return CY_OK;
+}
+
+int cy_debug_pc_stamps(unsigned long long* dev_buf) {
+  g_pc_stamp_buf = dev_buf;
+  return CY_OK;
+}
+
+int cy_conv3x3_pc_num_partials(const cy_conv_desc* d) {
+  if (pc_check(d) != CY_OK) return CY_ERR_ARG;
+  return pc_plan_of(d).partials;
+}
+
+size_t cy_conv3x3_pc_ws_bytes(const cy_conv_desc* d) {
+  if (pc_check(d) != CY_OK) return 0;
+  return pc_plan_of(d).ws_bytes;
+}
+
+int cy_conv3x3_pc_fwd(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
+                      const float* shift, const void* w_pc, void* out, void* out2, float* stats, void* ws,
+                      size_t ws_bytes, void* stream) {
+  int rc = pc_check(d);
+  if (rc != CY_OK) return rc;
+  if (!src1 || !w_pc || !out) return CY_ERR_ARG;
+  if (d->C2 && !src2) return CY_ERR_ARG;
+  if (d->prologue && (!scale || !shift)) return CY_ERR_ARG;
+  if (d->split_c > 0 && !out2) return CY_ERR_ARG;
+  const PcPlan p = pc_plan_of(d);
+  if (p.ksplit > 1 && (!ws || ws_bytes < p.ws_bytes)) return CY_ERR_WORKSPACE;
+  PcArgs pa = {};
+  ConvArgs& a = pa.c;
+  a.src1 = src1, a.src2 = src2, a.scale = scale, a.shift = shift, a.w = nullptr;
+  a.out = out, a.out2 = out2, a.stats = stats;
+  a.N = d->N, a.H = d->H, a.W = d->W, a.NH = d->N * d->H;
+  a.C1 = d->C1, a.C2 = d->C2, a.Cout = d->Cout;
+  a.mode1 = d->mode1, a.prologue = d->prologue;
+  a.ld1 = d->ld1, a.ld2 = d->ld2, a.ldo = d->ldo, a.ldo2 = d->ldo2, a.split_c = d->split_c;
+  a.ksplit = p.ksplit, a.ws = (float*)ws;
+  pa.wpc = w_pc, pa.tiles = p.tiles, pa.nblk = p.nblk, pa.nst = p.nst, pa.units = p.units;
+  pa.inv_h = 1.0f / (float)d->H;
+  pa.inv_ks = 1.0f / (float)p.ksplit, pa.inv_tiles = 1.0f / (float)p.tiles, pa.inv_tiles_w = 1.0f / (float)(d->W / 14);
+  hipStream_t st = (hipStream_t)stream;
+  if (p.bn == 128) rc = launch_conv_pc<bf16, 128>(pa, p, st);
+  else if (p.bn == 64) rc = launch_conv_pc<bf16, 64>(pa, p, st);
+  else rc = launch_conv_pc<bf16, 32>(pa, p, st);
+  if (rc != CY_OK || p.ksplit == 1) return rc;
+  ConvPlan fp = {};
+  fp.ksplit = p.ksplit, fp.finish_blocks = p.finish_blocks;
+  return launch_finish<bf16>(a, fp, st);
 }
 
 int cy_conv3x3_first_num_partials(int N, int H, int W, int Cout) {

@@ -20,6 +20,10 @@
 #pragma once
 #include "cy_conv_tile.h"
 
+#ifndef CY_PLANE_INTERLEAVE
+#define CY_PLANE_INTERLEAVE 0
+#endif
+
 namespace {
 
 template <int V> struct TapC {
@@ -37,6 +41,13 @@ template <int V> struct TapC {
     { constexpr int TAP_ = 7; STMT; }       \
     { constexpr int TAP_ = 8; STMT; }       \
   } while (0)
+
+template <int I, int N, typename F> __device__ __forceinline__ void plane_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(TapC<I>{});
+    plane_static_for<I + 1, N>(f);
+  }
+}
 
 template <typename T, int TH, int BN, int WGM, int WGN, int PITCHB, bool ALLT>
 struct PlaneCfg {
@@ -84,6 +95,7 @@ __global__ void __launch_bounds__(256, PREFA ? 1 : 2)
   constexpr int M_REP = C::M_REP, N_REP = C::N_REP, NA = C::NA;
   constexpr int APLB = C::APL * 16, BPLB = C::BPL * 16;  // plane pitches in bytes
   constexpr int TW = C::TW;
+  constexpr bool INTERLEAVE = sizeof(T) == 2 && CY_PLANE_INTERLEAVE;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
@@ -294,14 +306,37 @@ __global__ void __launch_bounds__(256, PREFA ? 1 : 2)
         for (int m = 0; m < M_REP; ++m)
           af[nxt][m] = frag(sAt + abase[m][d] + (ks + 1) * 2 * NCH * APLB, APLB);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
+      if constexpr (INTERLEAVE) {
+        // bf16: the LDS reads of k-step ks+1 are issued BETWEEN the MFMAs of k-step ks (an MFMA holds the
+        // SIMD's issue port for 8 of its 32 cycles), not as a burst in front of them during which the matrix
+        // pipe idles: in-kernel stamps of the same loop in cy_conv_pc.h, 48 -> 40 cycles per MFMA
 #pragma unroll
-      for (int m = 0; m < M_REP; ++m)
+        for (int m = 0; m < M_REP; ++m)
 #pragma unroll
-        for (int n = 0; n < N_REP; ++n) M::mma(bf[cur][n], af[cur][m], acc[m][n]);  // rows = couts
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
+          for (int n = 0; n < N_REP; ++n) M::mma(bf[cur][n], af[cur][m], acc[m][n]);  // rows = couts
+        constexpr int NM = M_REP * N_REP;
+        const int NR = (ks + 1 < KS) ? (M_REP + N_REP) * NCH : 0;
+        (void)NR;
+        if (ks + 1 < KS) {
+          plane_static_for<0, NM>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int NRC = (M_REP + N_REP) * NCH;
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            constexpr int nr = ((j + 1) * NRC) / NM - (j * NRC) / NM;
+            if constexpr (nr > 0) __builtin_amdgcn_sched_group_barrier(0x100, nr, 0);
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+          for (int n = 0; n < N_REP; ++n) M::mma(bf[cur][n], af[cur][m], acc[m][n]);  // rows = couts
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 

@@ -69,6 +69,12 @@ _SIGS = {
     "cy_conv3x3_wgrad_plan": (c_int, [_PCD, c_int, POINTER(WgradPlan)]),
     "cy_conv3x3_fwd_ws_bytes": (c_size_t, [_PCD]),
     "cy_conv3x3_fwd": (c_int, [_PCD, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "cy_conv3x3_pc_packed_elems": (C.c_longlong, [c_int, c_int]),
+    "cy_debug_pc_stamps": (c_int, [_P]),
+    "cy_conv3x3_pc_pack": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "cy_conv3x3_pc_num_partials": (c_int, [_PCD]),
+    "cy_conv3x3_pc_ws_bytes": (c_size_t, [_PCD]),
+    "cy_conv3x3_pc_fwd": (c_int, [_PCD, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "cy_conv3x3_wgrad_ws_bytes": (c_size_t, [_PCD]),
     "cy_conv3x3_wgrad": (c_int, [_PCD, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "cy_conv3x3_wgrad_pair_ws_bytes": (c_size_t, [_PCD, c_int]),
@@ -138,7 +144,7 @@ _SIGS = {
 }
 
 # functions whose int return is a count / size, not a status
-_COUNT_FUNCS = {"cy_abi_version", "cy_conv3x3_num_partials", "cy_conv3x3_first_num_partials",
+_COUNT_FUNCS = {"cy_abi_version", "cy_conv3x3_num_partials", "cy_conv3x3_first_num_partials", "cy_conv3x3_pc_num_partials",
                 "cy_bn_bwd_num_partials"}
 
 _lib = None

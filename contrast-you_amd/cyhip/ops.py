@@ -290,6 +290,58 @@ def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, 
     return out, stats
 
 
+def pack_weights_pc(w: Tensor, dtype: torch.dtype, want_dgrad: bool = True):
+    """w [Cout,Cin,3,3] f32 -> (forward image, data-gradient image or None) in the stage-contiguous layout of
+    the persistent producer / consumer kernel (cy_conv3x3_pc_fwd)"""
+    require_gpu(w)
+    Cout, Cin = w.shape[0], w.shape[1]
+    w = w.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    lib = _lib.load()
+    wf = torch.empty(lib.cy_conv3x3_pc_packed_elems(Cout, Cin), dtype=dtype, device=w.device)
+    wd = torch.empty(lib.cy_conv3x3_pc_packed_elems(Cin, Cout), dtype=dtype, device=w.device) if want_dgrad else None
+    _lib.call("cy_conv3x3_pc_pack", w.data_ptr(), wf.data_ptr(), _ptr(wd), Cout, Cin, dtype_code(dtype), _stream())
+    return wf, wd
+
+
+def conv3x3_pc_fwd(src1: Tensor, src2: Optional[Tensor], wpc: Tensor, Cout: int, *, mode: int = 0,
+                   scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
+                   want_stats: bool = True, split: Optional[int] = None):
+    """conv3x3_fwd on the persistent producer / consumer kernel (same contract; `wpc` from pack_weights_pc)"""
+    require_gpu(src1, wpc)
+    N, C1 = src1.shape[0], src1.shape[1]
+    C2 = 0 if src2 is None else src2.shape[1]
+    H, W = _out_hw(src1, mode)
+    dt = dtype_code(src1.dtype)
+    dev = src1.device
+    prologue = 1 if scale is not None else 0
+    if split:
+        out = empty_nhwc(N, split, H, W, src1.dtype, dev)
+        out2 = empty_nhwc(N, Cout - split, H, W, src1.dtype, dev)
+        d = _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, C1, C2, split, split, Cout - split)
+    else:
+        out = empty_nhwc(N, Cout, H, W, src1.dtype, dev)
+        out2 = None
+        d = _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, C1, C2, Cout)
+    stats = None
+    if want_stats:
+        npart = _lib.call("cy_conv3x3_pc_num_partials", d.ref)
+        stats = _f32(npart * 2 * Cout, dev).view(npart, 2, Cout)
+    nbytes = _lib.load().cy_conv3x3_pc_ws_bytes(d.ref)
+    ws = _ws(nbytes, dev) if nbytes else None
+    ev = _prof_begin()
+    _lib.call("cy_conv3x3_pc_fwd", d.ref, src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
+              wpc.data_ptr(), out.data_ptr(), _ptr(out2), _ptr(stats), _ptr(ws), nbytes, _stream())
+    if ev is not None:
+        esz = src1.element_size()
+        nb = esz * (src1.numel() + (0 if src2 is None else src2.numel()) + N * H * W * Cout + 9 * (C1 + C2) * Cout)
+        _prof_end(ev, "conv3x3_igemm", 2.0 * N * H * W * 9 * (C1 + C2) * Cout, float(nb))
+    if split:
+        return (out, out2), None
+    return out, stats
+
+
 # ---- side stream for weight gradients ------------------------------------------------------------
 # A layer's weight-gradient kernels do not feed the rest of the backward pass (only the optimizer
 # reads them), and at the configured batch sizes neither they nor the data-gradient kernels fill

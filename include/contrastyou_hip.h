@@ -131,6 +131,23 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
                    const float* shift, const void* w_packed, void* out, void* out2, float* stats,
                    void* ws, size_t ws_bytes, void* stream);
 
+/* The same convolution on the persistent producer / consumer kernel (csrc/cy_conv_pc.h; bf16, widths that
+ * are multiples of 14): one 512-thread workgroup per CU walks a list of (tile, cout block, K split) units,
+ * four loader waves keep a double-buffered LDS ring full (weights by LDS-DMA), four MFMA waves compute.
+ * It reads its own stage-contiguous weight image: cy_conv3x3_pc_packed_elems(Cout, Cin) elements for the
+ * forward GEMM, cy_conv3x3_pc_packed_elems(Cin, Cout) for the data-gradient GEMM (wpc_d may be NULL).
+ * Statistic partials: cy_conv3x3_pc_num_partials(d) rows (one per workgroup and wave row). */
+long long cy_conv3x3_pc_packed_elems(int Cout, int Cin);
+/* development aid: workgroup 0 of every following cy_conv3x3_pc_fwd launch records shader-clock stamps of
+ * its 8 waves into dev_buf[8][128] (DEVICE memory; NULL switches it off again). */
+int cy_debug_pc_stamps(unsigned long long* dev_buf);
+int cy_conv3x3_pc_pack(const float* w, void* wpc_f, void* wpc_d, int Cout, int Cin, int dtype, void* stream);
+int cy_conv3x3_pc_num_partials(const cy_conv_desc* d);
+size_t cy_conv3x3_pc_ws_bytes(const cy_conv_desc* d);
+int cy_conv3x3_pc_fwd(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
+                      const float* shift, const void* w_pc, void* out, void* out2, float* stats, void* ws,
+                      size_t ws_bytes, void* stream);
+
 /* Weight gradient dw[Cout][Cin][3][3] (f32, reference layout) =
  *   sum_p dy[p][co] * in[p+tap][ci]  with `in` addressed exactly as in
  * cy_conv3x3_fwd (same desc; desc.out_dtype/ldo describe dy).  ws is a
