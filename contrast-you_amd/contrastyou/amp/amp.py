@@ -1,7 +1,13 @@
 """`AMPScaler` (contrastyou/amp/amp.py:13-45): loss scaling with gradient accumulation and the
-autocast context of the step.  The reference autocasts to fp16; the MI355X build computes the
-U-Net in bf16 under autocast (no loss scaling needed, the scaler may be disabled) -- see
-cyhip.functions.compute_dtype_for."""
+autocast context of the step.  Two mixed-precision modes:
+
+* the reference's own: fp16 autocast + `torch.amp.GradScaler` (loss scaling, inf check, skipped steps) --
+  selected by handing an ENABLED GradScaler; the U-Net kernels then run their float16 instantiation
+  (`mfma_f32_32x32x16_f16`, f32 accumulation, f32 BN statistics and f32 weight / BN gradients);
+* the build's default: bf16 autocast with the pass-through `BF16Scaler` (bf16 has the f32 exponent
+  range: nothing to scale, no host sync per step).
+
+The autocast dtype follows the scaler unless given explicitly (cyhip.functions.compute_dtype_for reads it)."""
 from __future__ import annotations
 
 import torch
@@ -9,10 +15,13 @@ import torch
 
 class AMPScaler:
 
-    def __init__(self, *, scaler, accumulate_iter: int = 1, autocast_dtype: torch.dtype = torch.bfloat16) -> None:
+    def __init__(self, *, scaler, accumulate_iter: int = 1, autocast_dtype: torch.dtype = None) -> None:
         assert accumulate_iter >= 1
         self.scaler = scaler
         self._accumulate_iter = accumulate_iter
+        if autocast_dtype is None:
+            real = isinstance(scaler, torch.amp.GradScaler) and scaler.is_enabled()
+            autocast_dtype = torch.float16 if real else torch.bfloat16
         self._autocast_dtype = autocast_dtype
 
     def scale_loss(self, loss):
@@ -21,6 +30,11 @@ class AMPScaler:
     def optimizer_step(self, optimizer, *, cur_iter: int):
         """step optimizer and scaler on the last micro-batch of an accumulation window"""
         if cur_iter % self._accumulate_iter == (self._accumulate_iter - 1):
+            # data-parallel + loss scaling: the gradient mean must be taken BEFORE the scaler's inf check, so
+            # that every rank sees the same infs and skips (or takes) the same step (what DDP's in-backward
+            # all-reduce gives the reference); FusedRAdam.step() then does not reduce a second time
+            if hasattr(optimizer, "all_reduce_grads") and isinstance(self.scaler, torch.amp.GradScaler):
+                optimizer.all_reduce_grads()
             self.scaler.step(optimizer)
             self.scaler.update()
 

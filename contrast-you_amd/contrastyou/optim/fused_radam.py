@@ -145,13 +145,19 @@ class FusedRAdam(torch.optim.Optimizer):
         ops.join_side_streams(torch.cuda.current_stream() if torch.cuda.is_available() else None)
         if self._needs_flat():
             self._ensure_flat()
+        self._reduced = False
         for f in self._flat:
             f.zero_grad()
 
     def all_reduce_grads(self):
         """mean over data-parallel ranks; one collective per parameter group"""
-        if not self._dp:
+        if not self._dp or getattr(self, "_reduced", False):
             return
+        if self._needs_flat():
+            self._ensure_flat()
+        if torch.cuda.is_available():
+            ops.join_side_streams(torch.cuda.current_stream())
+        self._reduced = True
         world = dist.get_world_size(self._pg)
         for f in self._flat:
             if f.grad.is_cuda:
@@ -198,6 +204,7 @@ class FusedRAdam(torch.optim.Optimizer):
         if torch.cuda.is_available():  # weight gradients are produced on a side stream
             ops.join_side_streams(torch.cuda.current_stream())
         self.all_reduce_grads()
+        self._reduced = False
         for i, g in enumerate(self.param_groups):
             f, st = self._flat[i], self._flat_state[i]
             st["step"] += 1

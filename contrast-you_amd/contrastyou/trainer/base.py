@@ -63,7 +63,7 @@ class Trainer(DDPMixin, ModuleBase):
 
     def __init__(self, *, model: nn.Module, criterion, tra_loader, val_loader, save_dir: str, max_epoch: int = 100,
                  num_batches: int = 100, device="cpu", config: Dict[str, Any], enable_scale: bool = False,
-                 accumulate_iter: int = 1, **kwargs) -> None:
+                 accumulate_iter: int = 1, amp_dtype="bf16", **kwargs) -> None:
         super().__init__()
         # modules (checkpointed under module_state)
         self._model = self._inference_model = model
@@ -81,7 +81,12 @@ class Trainer(DDPMixin, ModuleBase):
         self._start_epoch = Buffer(0)
         self._best_score = Buffer(0.0)
         # objects with their own state_dict (checkpointed under other_state)
-        self.scaler = BF16Scaler() if enable_scale else torch.amp.GradScaler("cuda", enabled=False)
+        # enable_scale: mixed precision.  amp_dtype "bf16" (default of this build): bf16 autocast, pass-through
+        # scaler; "fp16": the reference's mode, fp16 autocast + torch GradScaler (contrastyou/amp/amp.py:13-45)
+        if enable_scale and amp_dtype in ("fp16", "float16", torch.float16):
+            self.scaler = torch.amp.GradScaler("cuda", enabled=True)
+        else:
+            self.scaler = BF16Scaler() if enable_scale else torch.amp.GradScaler("cuda", enabled=False)
         self._storage = Storage(save_dir=self.save_dir)
         self._optimizer: Optional[torch.optim.Optimizer] = None
         self._scheduler: Optional[GradualWarmupScheduler] = None

@@ -8,7 +8,9 @@
 #include "../../include/contrastyou_hip.h"
 
 typedef __bf16 bf16;
+typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -27,6 +29,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 template <typename T> struct ElemTr;
 template <> struct ElemTr<bf16> {
   static constexpr int EPC = 8;  // elements per 16-byte chunk
+};
+template <> struct ElemTr<f16> {
+  static constexpr int EPC = 8;
 };
 template <> struct ElemTr<float> {
   static constexpr int EPC = 4;
@@ -60,6 +65,20 @@ template <> struct Chunk<bf16> {
     return v;
   }
 };
+template <> struct Chunk<f16> {
+  static constexpr int N = 8;
+  __device__ __forceinline__ static void unpack(const u32x4& v, float* f) {
+    const f16x8 h = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)h[i];
+  }
+  __device__ __forceinline__ static u32x4 pack(const float* f) {
+    f16x8 h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (f16)f[i];
+    return __builtin_bit_cast(u32x4, h);
+  }
+};
 template <> struct Chunk<float> {
   static constexpr int N = 4;
   __device__ __forceinline__ static void unpack(const u32x4& v, float* f) {
@@ -77,9 +96,11 @@ template <> struct Chunk<float> {
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+template <> __device__ __forceinline__ float to_f32<f16>(f16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }
 
 // round a float through the storage type (identity for f32)
 template <typename T> __device__ __forceinline__ float round_through(float v) {

@@ -394,6 +394,9 @@ int cy_avgpool_fwd(const void* x, float* pooled, int N, int HW, int C, int dtype
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(avgpool_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, pooled,
                        HW, C);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(avgpool_fwd_kernel<f16>, grid, dim3(256), 0, st, (const f16*)x, pooled,
+                       HW, C);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(avgpool_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, pooled,
                        HW, C);
@@ -409,6 +412,9 @@ int cy_avgpool_bwd(const float* dpooled, void* dx, int N, int HW, int C, int dty
   const int grid = grid_for((long)N * HW * C);
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(avgpool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, dpooled, (bf16*)dx,
+                       N, HW, C);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(avgpool_bwd_kernel<f16>, dim3(grid), dim3(256), 0, st, dpooled, (f16*)dx,
                        N, HW, C);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, dpooled,

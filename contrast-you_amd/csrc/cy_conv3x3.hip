@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(256)
         TO* dst = (split_c > 0 && co >= split_c) ? out2 + (size_t)p * ldo2 + (co - split_c)
                                                  : out + (size_t)p * ldo + co;
         if constexpr (sizeof(TO) == 2) {
-          st16(dst, Chunk<bf16>::pack(f));
+          st16(dst, Chunk<TO>::pack(f));
         } else {
           st16(dst, Chunk<float>::pack(f));
           st16(dst + 4, Chunk<float>::pack(f + 4));
@@ -766,7 +766,7 @@ __global__ void __launch_bounds__(256)
     }
     TO* op = out + (size_t)p * Cout + cg * 8;
     if constexpr (sizeof(TO) == 2) {
-      st16(op, Chunk<bf16>::pack(acc));
+      st16(op, Chunk<TO>::pack(acc));
     } else {
       st16(op, Chunk<float>::pack(acc));
       st16(reinterpret_cast<float*>(op) + 4, Chunk<float>::pack(acc + 4));
@@ -845,6 +845,9 @@ int cy_conv3x3_pack_weights(const float* w, void* wf, void* wd, int Cout, int Ci
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, (bf16*)wf,
                        (bf16*)wd, Cout, Cin, co_pad, ci_pad, ci_pad2, co_pad2);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(pack_weights_kernel<f16>, dim3(blocks), dim3(256), 0, st, w, (f16*)wf,
+                       (f16*)wd, Cout, Cin, co_pad, ci_pad, ci_pad2, co_pad2);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, w, (float*)wf,
                        (float*)wd, Cout, Cin, co_pad, ci_pad, ci_pad2, co_pad2);
@@ -862,6 +865,9 @@ int cy_conv3x3_pack_weights_batched(const cy_pack_item* items, int n_items, long
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(pack_weights_batched_kernel<bf16>, dim3((unsigned)total), dim3(256), 0, st, items,
                        n_items, (bf16*)wf_arena, (bf16*)wd_arena);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(pack_weights_batched_kernel<f16>, dim3((unsigned)total), dim3(256), 0, st, items,
+                       n_items, (f16*)wf_arena, (f16*)wd_arena);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3((unsigned)total), dim3(256), 0, st, items,
                        n_items, (float*)wf_arena, (float*)wd_arena);
@@ -876,8 +882,8 @@ static int conv_check(const cy_conv_desc* d) {
   if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C1 <= 0 || d->C2 < 0 || d->Cout <= 0)
     return CY_ERR_SHAPE;
   if (d->in_dtype != d->out_dtype) return CY_ERR_DTYPE;
-  if (d->in_dtype != CY_F32 && d->in_dtype != CY_BF16) return CY_ERR_DTYPE;
-  const int epc = d->in_dtype == CY_BF16 ? 8 : 4;
+  if (d->in_dtype != CY_F32 && d->in_dtype != CY_BF16 && d->in_dtype != CY_F16) return CY_ERR_DTYPE;
+  const int epc = d->in_dtype == CY_F32 ? 4 : 8;
   if (d->C1 % epc || d->C2 % epc || d->Cout % epc) return CY_ERR_SHAPE;
   if (d->ld1 % epc || (d->C2 && d->ld2 % epc) || d->ldo % epc) return CY_ERR_SHAPE;
   if (d->ld1 < d->C1 || (d->C2 && d->ld2 < d->C2)) return CY_ERR_SHAPE;
@@ -889,7 +895,7 @@ static int conv_check(const cy_conv_desc* d) {
 }
 
 static ConvPlan plan_of(const cy_conv_desc* d) {
-  return plan_conv(d->N, d->H, d->W, d->C1 + d->C2, d->Cout, d->in_dtype == CY_BF16 ? 2 : 4);
+  return plan_conv(d->N, d->H, d->W, d->C1 + d->C2, d->Cout, d->in_dtype == CY_F32 ? 4 : 2);
 }
 
 int cy_conv3x3_num_partials(const cy_conv_desc* d) {
@@ -938,9 +944,11 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
   a.ws = (float*)ws;
   if (p.ksplit > 1 && (!ws || ws_bytes < p.ws_bytes)) return CY_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  rc = d->in_dtype == CY_BF16 ? dispatch_conv<bf16>(a, p, st) : dispatch_conv<float>(a, p, st);
+  rc = d->in_dtype == CY_BF16 ? dispatch_conv<bf16>(a, p, st)
+       : d->in_dtype == CY_F16 ? dispatch_conv<f16>(a, p, st) : dispatch_conv<float>(a, p, st);
   if (rc != CY_OK || p.ksplit == 1) return rc;
-  return d->in_dtype == CY_BF16 ? launch_finish<bf16>(a, p, st) : launch_finish<float>(a, p, st);
+  return d->in_dtype == CY_BF16 ? launch_finish<bf16>(a, p, st)
+         : d->in_dtype == CY_F16 ? launch_finish<f16>(a, p, st) : launch_finish<float>(a, p, st);
 }
 
 // ---- persistent producer / consumer kernel (cy_conv_pc.h) ------------------------------------------
@@ -1043,6 +1051,9 @@ int cy_conv3x3_first_fwd(const float* x, const float* w, void* out, float* stats
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == CY_BF16)
     hipLaunchKernelGGL(conv3x3_first_kernel<bf16>, dim3(np), dim3(256), 0, st, x, w, (bf16*)out,
+                       stats, N, Cin, H, W, Cout);
+  else if (out_dtype == CY_F16)
+    hipLaunchKernelGGL(conv3x3_first_kernel<f16>, dim3(np), dim3(256), 0, st, x, w, (f16*)out,
                        stats, N, Cin, H, W, Cout);
   else if (out_dtype == CY_F32)
     hipLaunchKernelGGL(conv3x3_first_kernel<float>, dim3(np), dim3(256), 0, st, x, w, (float*)out,

@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
 
   auto frag = [&](const unsigned char* p) {
     typename M::Frag f;
-    f.v = *reinterpret_cast<const bf16x8*>(p);
+    f.v = *reinterpret_cast<const decltype(f.v)*>(p);
     return f;
   };
 

@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256, PREFA ? 1 : 2)
   auto frag = [&](const unsigned char* p, int plane_bytes) {
     typename M::Frag f;
     if constexpr (NCH == 1) {
-      f.v = *reinterpret_cast<const bf16x8*>(p);
+      f.v = *reinterpret_cast<const decltype(f.v)*>(p);
     } else {
       f.lo = *reinterpret_cast<const f32x4*>(p);
       f.hi = *reinterpret_cast<const f32x4*>(p + plane_bytes);

@@ -51,6 +51,20 @@ template <> struct Mma<bf16> {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
   }
 };
+template <> struct Mma<f16> {
+  static constexpr int NCHUNK = 1;
+  struct Frag {
+    f16x8 v;
+  };
+  __device__ __forceinline__ static Frag load(const unsigned char* pix, int fi, int swz) {
+    Frag f;
+    f.v = *reinterpret_cast<const f16x8*>(pix + ((fi ^ swz) << 4));
+    return f;
+  }
+  __device__ __forceinline__ static void mma(const Frag& a, const Frag& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, b.v, c, 0, 0, 0);
+  }
+};
 template <> struct Mma<float> {
   static constexpr int NCHUNK = 2;
   struct Frag {

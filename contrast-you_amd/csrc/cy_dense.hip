@@ -354,6 +354,9 @@ int cy_dense_proj_fwd(const void* x, const float* w1, const float* b1, const int
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(dense_proj_fwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)x, w1,
                        b1, bins, hpool, H, W, C, ldx, hid, sh, sw, slope);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(dense_proj_fwd_kernel<f16>, dim3(nb), dim3(256), 0, st, (const f16*)x, w1,
+                       b1, bins, hpool, H, W, C, ldx, hid, sh, sw, slope);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(dense_proj_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x,
                        w1, b1, bins, hpool, H, W, C, ldx, hid, sh, sw, slope);
@@ -376,7 +379,7 @@ int cy_dense_proj_bwd(const void* x, const float* w1, const float* b1, const int
       sw > W)
     return CY_ERR_SHAPE;
   if (!bins && nb != N * sh * sw) return CY_ERR_SHAPE;
-  if (dtype != CY_BF16 && dtype != CY_F32) return CY_ERR_DTYPE;
+  if (dtype != CY_BF16 && dtype != CY_F32 && dtype != CY_F16) return CY_ERR_DTYPE;
   if (!ws || ws_bytes < cy_dense_proj_bwd_ws_bytes(nb, C, hid)) return CY_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int G = dp_bwd_blocks(nb);
@@ -386,6 +389,10 @@ int cy_dense_proj_bwd(const void* x, const float* w1, const float* b1, const int
     if (dtype == CY_BF16)
       hipLaunchKernelGGL((dense_proj_bwd_kernel<bf16, true>), dim3(G), dim3(256), 0, st, (const bf16*)x,
                          w1, b1, bins, nb, dhpool, (bf16*)nullptr, (float*)ws, H, W, C, ldx, hid, sh, sw,
+                         slope, -1);
+    else if (dtype == CY_F16)
+      hipLaunchKernelGGL((dense_proj_bwd_kernel<f16, true>), dim3(G), dim3(256), 0, st, (const f16*)x,
+                         w1, b1, bins, nb, dhpool, (f16*)nullptr, (float*)ws, H, W, C, ldx, hid, sh, sw,
                          slope, -1);
     else
       hipLaunchKernelGGL((dense_proj_bwd_kernel<float, true>), dim3(G), dim3(256), 0, st,
@@ -397,6 +404,10 @@ int cy_dense_proj_bwd(const void* x, const float* w1, const float* b1, const int
     if (dtype == CY_BF16)
       hipLaunchKernelGGL((dense_proj_bwd_kernel<bf16, false>), dim3(G), dim3(256), 0, st,
                          (const bf16*)x, w1, b1, bins, nb, dhpool, (bf16*)dx, (float*)ws, H, W, C, ldx,
+                         hid, sh, sw, slope, colour);
+    else if (dtype == CY_F16)
+      hipLaunchKernelGGL((dense_proj_bwd_kernel<f16, false>), dim3(G), dim3(256), 0, st,
+                         (const f16*)x, w1, b1, bins, nb, dhpool, (f16*)dx, (float*)ws, H, W, C, ldx,
                          hid, sh, sw, slope, colour);
     else
       hipLaunchKernelGGL((dense_proj_bwd_kernel<float, false>), dim3(G), dim3(256), 0, st,
@@ -421,6 +432,9 @@ int cy_adaptive_avgpool_fwd(const void* x, const int32_t* bins, int nb, float* o
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(adaptive_pool_fwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)x,
                        bins, out, H, W, C, ldx, sh, sw);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(adaptive_pool_fwd_kernel<f16>, dim3(nb), dim3(256), 0, st, (const f16*)x,
+                       bins, out, H, W, C, ldx, sh, sw);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(adaptive_pool_fwd_kernel<float>, dim3(nb), dim3(256), 0, st,
                        (const float*)x, bins, out, H, W, C, ldx, sh, sw);
@@ -439,6 +453,9 @@ int cy_adaptive_avgpool_bwd(const float* dpool, void* dx, int N, int H, int W, i
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(adaptive_pool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, dpool,
                        (bf16*)dx, N, H, W, C, ldx, sh, sw);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(adaptive_pool_bwd_kernel<f16>, dim3(grid), dim3(256), 0, st, dpool,
+                       (f16*)dx, N, H, W, C, ldx, sh, sw);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(adaptive_pool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, dpool,
                        (float*)dx, N, H, W, C, ldx, sh, sw);

@@ -15,7 +15,7 @@ constexpr int GN_SPLIT = 32;  // pixel splits per image in the reduction kernels
 
 template <typename T> __device__ __forceinline__ void load8(const T* p, float* f) {
   if constexpr (sizeof(T) == 2) {
-    Chunk<bf16>::unpack(ld16(p), f);
+    Chunk<T>::unpack(ld16(p), f);
   } else {
     Chunk<float>::unpack(ld16(p), f);
     Chunk<float>::unpack(ld16(p + 4), f + 4);
@@ -23,7 +23,7 @@ template <typename T> __device__ __forceinline__ void load8(const T* p, float* f
 }
 template <typename T> __device__ __forceinline__ void store8(T* p, const float* f) {
   if constexpr (sizeof(T) == 2) {
-    st16(p, Chunk<bf16>::pack(f));
+    st16(p, Chunk<T>::pack(f));
   } else {
     st16(p, Chunk<float>::pack(f));
     st16(p + 4, Chunk<float>::pack(f + 4));
@@ -310,7 +310,7 @@ int cy_gn_silu_fwd(const void* y, int ldy, const float* bias, const float* gamma
   if (!y || !gamma || !beta || !out || !mean_rstd || N <= 0 || HW <= 0) return CY_ERR_ARG;
   if (C % 8 || G <= 0 || C % G || ldy % 8 || ldo % 8 || ldy < C || ldo < C || C / G > 256 || C > 2048)
     return CY_ERR_SHAPE;
-  if (dtype != CY_BF16 && dtype != CY_F32) return CY_ERR_DTYPE;
+  if (dtype != CY_BF16 && dtype != CY_F32 && dtype != CY_F16) return CY_ERR_DTYPE;
   if (!ws || ws_bytes < cy_gn_ws_bytes(N, C)) return CY_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)ws;
@@ -325,6 +325,15 @@ int cy_gn_silu_fwd(const void* y, int ldy, const float* bias, const float* gamma
     CY_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_silu_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, ldy,
                        bias, gamma, beta, (const float*)mean_rstd, (bf16*)out, ldo, N, HW, C, G);
+  } else if (dtype == CY_F16) {
+    hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(GN_SPLIT, N), dim3(256), smem, st, (const f16*)y,
+                       ldy, bias, HW, C, part);
+    CY_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(cy_cdiv((long)N * G, 256)), dim3(256), 0, st,
+                       (const float*)part, mean_rstd, N, C, G, HW, eps);
+    CY_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_silu_apply_kernel<f16>, dim3(grid), dim3(256), 0, st, (const f16*)y, ldy,
+                       bias, gamma, beta, (const float*)mean_rstd, (f16*)out, ldo, N, HW, C, G);
   } else {
     hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(GN_SPLIT, N), dim3(256), smem, st,
                        (const float*)y, ldy, bias, HW, C, part);
@@ -347,7 +356,7 @@ int cy_gn_silu_bwd(const void* y, int ldy, const void* dz, int ldd, const float*
   if (C % 8 || G <= 0 || C % G || ldy % 8 || ldd % 8 || ldu % 8 || ldy < C || ldd < C || ldu < C ||
       C / G > 256 || C > 2048)
     return CY_ERR_SHAPE;
-  if (dtype != CY_BF16 && dtype != CY_F32) return CY_ERR_DTYPE;
+  if (dtype != CY_BF16 && dtype != CY_F32 && dtype != CY_F16) return CY_ERR_DTYPE;
   if (!ws || ws_bytes < cy_gn_ws_bytes(N, C)) return CY_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)ws;
@@ -358,6 +367,10 @@ int cy_gn_silu_bwd(const void* y, int ldy, const void* dz, int ldd, const float*
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16>, dim3(GN_SPLIT, N), dim3(256), smem, st,
                        (const bf16*)y, ldy, (const bf16*)dz, ldd, bias, gamma, beta, mean_rstd, HW, C,
+                       G, part);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<f16>, dim3(GN_SPLIT, N), dim3(256), smem, st,
+                       (const f16*)y, ldy, (const f16*)dz, ldd, bias, gamma, beta, mean_rstd, HW, C,
                        G, part);
   else
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(GN_SPLIT, N), dim3(256), smem, st,
@@ -376,6 +389,10 @@ int cy_gn_silu_bwd(const void* y, int ldy, const void* dz, int ldd, const float*
     hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, ldy,
                        (const bf16*)dz, ldd, bias, gamma, beta, mean_rstd, (const float*)coef,
                        (bf16*)du, ldu, N, HW, C, G);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<f16>, dim3(grid), dim3(256), 0, st, (const f16*)y, ldy,
+                       (const f16*)dz, ldd, bias, gamma, beta, mean_rstd, (const float*)coef,
+                       (f16*)du, ldu, N, HW, C, G);
   else
     hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y, ldy,
                        (const float*)dz, ldd, bias, gamma, beta, mean_rstd, (const float*)coef,
@@ -392,6 +409,9 @@ int cy_bilinear_fwd(const void* x, void* out, int N, int H, int W, int C, int h,
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(bilinear_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x,
                        (bf16*)out, N, H, W, C, h, w);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(bilinear_kernel<f16>, dim3(grid), dim3(256), 0, st, (const f16*)x,
+                       (f16*)out, N, H, W, C, h, w);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(bilinear_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x,
                        (float*)out, N, H, W, C, h, w);

@@ -15,7 +15,7 @@ constexpr int KWIDE = 128;  // stacked cluster-head outputs
 
 template <typename T> __device__ __forceinline__ void load8h(const T* p, float* f) {
   if constexpr (sizeof(T) == 2) {
-    Chunk<bf16>::unpack(ld16(p), f);
+    Chunk<T>::unpack(ld16(p), f);
   } else {
     Chunk<float>::unpack(ld16(p), f);
     Chunk<float>::unpack(ld16(p + 4), f + 4);
@@ -23,7 +23,7 @@ template <typename T> __device__ __forceinline__ void load8h(const T* p, float* 
 }
 template <typename T> __device__ __forceinline__ void store8h(T* p, const float* f) {
   if constexpr (sizeof(T) == 2) {
-    st16(p, Chunk<bf16>::pack(f));
+    st16(p, Chunk<T>::pack(f));
   } else {
     st16(p, Chunk<float>::pack(f));
     st16(p + 4, Chunk<float>::pack(f + 4));
@@ -440,7 +440,7 @@ int cy_head1x1_fwd(const void* x, const float* w, const float* b, float* logits,
                    int K, int x_dtype, void* stream) {
   if (!x || !w || !logits || npix <= 0) return CY_ERR_ARG;
   if (C % 8 || K < 1 || K > KWIDE || (size_t)(K * C + K) * 4 > 60000) return CY_ERR_SHAPE;
-  if (x_dtype != CY_BF16 && x_dtype != CY_F32) return CY_ERR_DTYPE;
+  if (x_dtype != CY_BF16 && x_dtype != CY_F32 && x_dtype != CY_F16) return CY_ERR_DTYPE;
   hipStream_t st = (hipStream_t)stream;
   const int grid = loss_blocks(npix) * 2;
   const size_t smem = (size_t)(K * C + K) * sizeof(float);
@@ -449,6 +449,9 @@ int cy_head1x1_fwd(const void* x, const float* w, const float* b, float* logits,
     if (h)
       hipLaunchKernelGGL((head_fwd_kernel<bf16, KMAX>), dim3(grid), dim3(256), smem, st,
                          (const bf16*)x, w, b, logits, npix, C, K);
+    else if (x_dtype == CY_F16)
+      hipLaunchKernelGGL((head_fwd_kernel<f16, KMAX>), dim3(grid), dim3(256), smem, st,
+                         (const f16*)x, w, b, logits, npix, C, K);
     else
       hipLaunchKernelGGL((head_fwd_kernel<float, KMAX>), dim3(grid), dim3(256), smem, st,
                          (const float*)x, w, b, logits, npix, C, K);
@@ -456,6 +459,9 @@ int cy_head1x1_fwd(const void* x, const float* w, const float* b, float* logits,
     if (h)
       hipLaunchKernelGGL((head_fwd_kernel<bf16, KWIDE>), dim3(grid), dim3(256), smem, st,
                          (const bf16*)x, w, b, logits, npix, C, K);
+    else if (x_dtype == CY_F16)
+      hipLaunchKernelGGL((head_fwd_kernel<f16, KWIDE>), dim3(grid), dim3(256), smem, st,
+                         (const f16*)x, w, b, logits, npix, C, K);
     else
       hipLaunchKernelGGL((head_fwd_kernel<float, KWIDE>), dim3(grid), dim3(256), smem, st,
                          (const float*)x, w, b, logits, npix, C, K);
@@ -473,7 +479,7 @@ int cy_head1x1_bwd(const void* x, const float* w, const float* dlogits, void* dx
                    void* stream) {
   if (!x || !w || !dlogits || npix <= 0) return CY_ERR_ARG;
   if (C % 8 || K < 1 || K > KWIDE || (size_t)(K * C + K) * 4 > 60000) return CY_ERR_SHAPE;
-  if (x_dtype != CY_BF16 && x_dtype != CY_F32) return CY_ERR_DTYPE;
+  if (x_dtype != CY_BF16 && x_dtype != CY_F32 && x_dtype != CY_F16) return CY_ERR_DTYPE;
   hipStream_t st = (hipStream_t)stream;
   if (dx) {
     const long total = npix * (C / 8);
@@ -486,12 +492,18 @@ int cy_head1x1_bwd(const void* x, const float* w, const float* dlogits, void* dx
       if (x_dtype == CY_BF16)
         hipLaunchKernelGGL(head_bwd_dx_wide_kernel<bf16>, dim3((int)bw), dim3(256), smem, st, dlogits,
                            w, (bf16*)dx, npix, C, K);
+      else if (x_dtype == CY_F16)
+        hipLaunchKernelGGL(head_bwd_dx_wide_kernel<f16>, dim3((int)bw), dim3(256), smem, st, dlogits,
+                           w, (f16*)dx, npix, C, K);
       else
         hipLaunchKernelGGL(head_bwd_dx_wide_kernel<float>, dim3((int)bw), dim3(256), smem, st, dlogits,
                            w, (float*)dx, npix, C, K);
     } else if (x_dtype == CY_BF16)
       hipLaunchKernelGGL(head_bwd_dx_kernel<bf16>, dim3((int)b), dim3(256), smem, st, dlogits, w,
                          (bf16*)dx, npix, C, K);
+    else if (x_dtype == CY_F16)
+      hipLaunchKernelGGL(head_bwd_dx_kernel<f16>, dim3((int)b), dim3(256), smem, st, dlogits, w,
+                         (f16*)dx, npix, C, K);
     else
       hipLaunchKernelGGL(head_bwd_dx_kernel<float>, dim3((int)b), dim3(256), smem, st, dlogits, w,
                          (float*)dx, npix, C, K);
@@ -510,6 +522,9 @@ int cy_head1x1_bwd(const void* x, const float* w, const float* dlogits, void* dx
       if (h)
         hipLaunchKernelGGL((head_bwd_dw_kernel<bf16, 4>), dim3(nblk), dim3(256), smem, st,
                            (const bf16*)x, dlogits, (float*)ws, npix, C, K);
+      else if (x_dtype == CY_F16)
+        hipLaunchKernelGGL((head_bwd_dw_kernel<f16, 4>), dim3(nblk), dim3(256), smem, st,
+                           (const f16*)x, dlogits, (float*)ws, npix, C, K);
       else
         hipLaunchKernelGGL((head_bwd_dw_kernel<float, 4>), dim3(nblk), dim3(256), smem, st,
                            (const float*)x, dlogits, (float*)ws, npix, C, K);
@@ -517,6 +532,9 @@ int cy_head1x1_bwd(const void* x, const float* w, const float* dlogits, void* dx
       if (h)
         hipLaunchKernelGGL((head_bwd_dw_kernel<bf16, 16>), dim3(nblk), dim3(256), smem, st,
                            (const bf16*)x, dlogits, (float*)ws, npix, C, K);
+      else if (x_dtype == CY_F16)
+        hipLaunchKernelGGL((head_bwd_dw_kernel<f16, 16>), dim3(nblk), dim3(256), smem, st,
+                           (const f16*)x, dlogits, (float*)ws, npix, C, K);
       else
         hipLaunchKernelGGL((head_bwd_dw_kernel<float, 16>), dim3(nblk), dim3(256), smem, st,
                            (const float*)x, dlogits, (float*)ws, npix, C, K);

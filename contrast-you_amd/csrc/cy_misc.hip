@@ -171,6 +171,9 @@ int cy_affine_nearest_fwd(const void* x, void* out, const float* theta, const fl
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(affine_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x,
                        (bf16*)out, theta, gamma, N, C, H, W);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(affine_fwd_kernel<f16>, dim3(grid), dim3(256), 0, st, (const f16*)x,
+                       (f16*)out, theta, gamma, N, C, H, W);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(affine_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x,
                        (float*)out, theta, gamma, N, C, H, W);
@@ -188,6 +191,9 @@ int cy_affine_nearest_bwd(const void* dout, void* dx, const float* theta, int N,
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(affine_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout,
                        (bf16*)dx, theta, N, C, H, W);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(affine_bwd_kernel<f16>, dim3(grid), dim3(256), 0, st, (const f16*)dout,
+                       (f16*)dx, theta, N, C, H, W);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(affine_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout,
                        (float*)dx, theta, N, C, H, W);

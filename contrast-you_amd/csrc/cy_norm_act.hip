@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256)
     float f[8];
     const TI* yp = y + p * C + g * 8;
     if constexpr (sizeof(TI) == 2) {
-      Chunk<bf16>::unpack(ld16(yp), f);
+      Chunk<TI>::unpack(ld16(yp), f);
     } else {
       Chunk<float>::unpack(ld16(yp), f);
       Chunk<float>::unpack(ld16(yp + 4), f + 4);
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256)
     }
     TO* op = out + p * C + g * 8;
     if constexpr (sizeof(TO) == 2) {
-      st16(op, Chunk<bf16>::pack(f));
+      st16(op, Chunk<TO>::pack(f));
     } else {
       st16(op, Chunk<float>::pack(f));
       st16(op + 4, Chunk<float>::pack(f + 4));
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256)
 // ------------------------------------------------------------------ backward
 template <typename T> __device__ __forceinline__ void load8(const T* p, float* f) {
   if constexpr (sizeof(T) == 2) {
-    Chunk<bf16>::unpack(ld16(p), f);
+    Chunk<T>::unpack(ld16(p), f);
   } else {
     Chunk<float>::unpack(ld16(p), f);
     Chunk<float>::unpack(ld16(p + 4), f + 4);
@@ -113,7 +113,7 @@ template <typename T> __device__ __forceinline__ void load8(const T* p, float* f
 }
 template <typename T> __device__ __forceinline__ void store8(T* p, const float* f) {
   if constexpr (sizeof(T) == 2) {
-    st16(p, Chunk<bf16>::pack(f));
+    st16(p, Chunk<T>::pack(f));
   } else {
     st16(p, Chunk<float>::pack(f));
     st16(p + 4, Chunk<float>::pack(f + 4));
@@ -384,6 +384,12 @@ int cy_bn_relu_apply(const void* y, const float* scale, const float* shift, void
   else if (y_dtype == CY_BF16 && out_dtype == CY_F32)
     hipLaunchKernelGGL((bn_relu_apply_kernel<bf16, float>), dim3(grid), dim3(256), 0, st,
                        (const bf16*)y, scale, shift, (float*)out, npix, C);
+  else if (y_dtype == CY_F16 && out_dtype == CY_F16)
+    hipLaunchKernelGGL((bn_relu_apply_kernel<f16, f16>), dim3(grid), dim3(256), 0, st,
+                       (const f16*)y, scale, shift, (f16*)out, npix, C);
+  else if (y_dtype == CY_F16 && out_dtype == CY_F32)
+    hipLaunchKernelGGL((bn_relu_apply_kernel<f16, float>), dim3(grid), dim3(256), 0, st,
+                       (const f16*)y, scale, shift, (float*)out, npix, C);
   else
     return CY_ERR_DTYPE;
   CY_CHECK_LAUNCH();
@@ -412,6 +418,10 @@ int cy_bn_relu_bwd_reduce(const void* da, int ld_da, const void* y, const float*
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), smem, st,
                        (const bf16*)da, ld_da, (const bf16*)y, scale, shift, mean, invstd,
+                       partials, npix, C);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<f16>, dim3(grid), dim3(256), smem, st,
+                       (const f16*)da, ld_da, (const f16*)y, scale, shift, mean, invstd,
                        partials, npix, C);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<float>, dim3(grid), dim3(256), smem, st,
@@ -446,6 +456,10 @@ int cy_bn_relu_bwd_apply(const void* da, int ld_da, const void* y, const float* 
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st,
                        (const bf16*)da, ld_da, (const bf16*)y, scale, shift, coef, (bf16*)dy, npix,
                        C);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<f16>, dim3(grid), dim3(256), 0, st,
+                       (const f16*)da, ld_da, (const f16*)y, scale, shift, coef, (f16*)dy, npix,
+                       C);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st,
                        (const float*)da, ld_da, (const float*)y, scale, shift, coef, (float*)dy,
@@ -465,6 +479,9 @@ int cy_maxpool2_bwd(const void* x, const void* dpool, const void* add, int ld_ad
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x,
                        (const bf16*)dpool, (const bf16*)add, ld_add, (bf16*)dx, N, H, W, C);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<f16>, dim3(grid), dim3(256), 0, st, (const f16*)x,
+                       (const f16*)dpool, (const f16*)add, ld_add, (f16*)dx, N, H, W, C);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x,
                        (const float*)dpool, (const float*)add, ld_add, (float*)dx, N, H, W, C);
@@ -483,6 +500,9 @@ int cy_upsample2_bwd(const void* dup, int ld_dup, void* dx, int N, int H, int W,
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(upsample2_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dup,
                        ld_dup, (bf16*)dx, N, H, W, C);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(upsample2_bwd_kernel<f16>, dim3(grid), dim3(256), 0, st, (const f16*)dup,
+                       ld_dup, (f16*)dx, N, H, W, C);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(upsample2_bwd_kernel<float>, dim3(grid), dim3(256), 0, st,
                        (const float*)dup, ld_dup, (float*)dx, N, H, W, C);

@@ -46,19 +46,21 @@ struct WgradArgs {
 template <typename T> struct WFrag;
 
 // bf16: two transposed reads give k = 8h + {0..3} and 8h + {4..7} for column (lane&31)
-template <> struct WFrag<bf16> {
-  __device__ __forceinline__ static Mma<bf16>::Frag load(const unsigned char* row_lo,
-                                                         const unsigned char* row_hi) {
+template <typename T16> struct WFrag16 {
+  __device__ __forceinline__ static typename Mma<T16>::Frag load(const unsigned char* row_lo,
+                                                                 const unsigned char* row_hi) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(row_lo));
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(row_hi));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    Mma<bf16>::Frag f;
-    f.v = __builtin_bit_cast(bf16x8, v);
+    typename Mma<T16>::Frag f;
+    f.v = __builtin_bit_cast(decltype(f.v), v);
     return f;
   }
 };
+template <> struct WFrag<bf16> : WFrag16<bf16> {};
+template <> struct WFrag<f16> : WFrag16<f16> {};
 
 template <typename T, int WCO, int WCI, int WK>
 struct WgCfg {
@@ -183,7 +185,7 @@ __global__ void __launch_bounds__(256, 2)
         const int acol = ((wco * 32 + 16 * gsel + 4 * p) * 2) ^ (SWA == 2 ? (((k1 >> 1) & 1) << 6) : 0);
         const unsigned char* a_lo = sDy + k1 * PA + acol;
         const unsigned char* a_hi = a_lo + 4 * PA;
-        const Mma<bf16>::Frag af = WFrag<bf16>::load(a_lo, a_hi);
+        const typename Mma<T>::Frag af = WFrag<T>::load(a_lo, a_hi);
         const int colb = (wci * 32 + 16 * gsel + 4 * p) * 2;
         const int p1 = s_ktab[k1], p2 = s_ktab[k2];  // (pad pixels map to pixel 0; their dy rows are zero)
         // swizzle term of pixel p + dh*HW2 + dw depends on dw only (HW2 % 4 == 0)
@@ -205,8 +207,8 @@ __global__ void __launch_bounds__(256, 2)
         for (int tap = 0; tap < 9; ++tap) {
           constexpr int dummy = 0;
           const int off = ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) * PB + dummy;
-          const Mma<bf16>::Frag bf = WFrag<bf16>::load(b1[tap % 3] + off, b2[tap % 3] + off);
-          Mma<bf16>::mma(af, bf, acc[tap]);
+          const typename Mma<T>::Frag bf = WFrag<T>::load(b1[tap % 3] + off, b2[tap % 3] + off);
+          Mma<T>::mma(af, bf, acc[tap]);
         }
       } else {
         // f32: element j of lane (r,h) is pixel kb + 8h + j
@@ -299,11 +301,10 @@ struct Wg12Cfg {
   static_assert(SMEM <= 160 * 1024, "LDS");
 };
 
-template <int WCO, int WCI, int WK>
+template <int WCO, int WCI, int WK, typename T = bf16>
 __global__ void __launch_bounds__(768, 1)
     wgrad12_kernel(const WgradArgs g) {
   using C = Wg12Cfg<WCO, WCI, WK>;
-  using T = bf16;
   constexpr int PA = C::PA, PB = C::PB, CPA = C::CPA, CPB = C::CPB, NT = C::NT;
   constexpr int EPC = 8;
   constexpr int SWA = PA == 128 ? 2 : 0, SWB = PB == 128 ? 2 : 0;  // pair swizzle of 128-byte pixels
@@ -510,19 +511,19 @@ __global__ void __launch_bounds__(768, 1)
       // (k1 >> 1) & 1 == ((k1 + 4) >> 1) & 1: both rows share the swizzle term
       const int acol = acol0 ^ (SWA == 2 ? (((k1 >> 1) & 1) << 6) : 0);
       const unsigned char* a_lo = sDy + k1 * PA + acol;
-      const Mma<bf16>::Frag af = WFrag<bf16>::load(a_lo, a_lo + 4 * PA);
+      const typename Mma<T>::Frag af = WFrag<T>::load(a_lo, a_lo + 4 * PA);
       const int p1 = s_ktab[k1], p2 = s_ktab[k2];  // (pad pixels map to pixel 0; their dy rows are zero)
-      Mma<bf16>::Frag bfr[3];
+      typename Mma<T>::Frag bfr[3];
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         // the swizzle term of pixel p + dh*HW2 + dw depends on dw only (HW2 % 4 == 0)
         const int c1 = bcol0 ^ (SWB == 2 ? ((((p1 + d - 1) >> 1) & 1) << 6) : 0);
         const int c2 = bcol0 ^ (SWB == 2 ? ((((p2 + d - 1) >> 1) & 1) << 6) : 0);
-        bfr[d] = WFrag<bf16>::load(sIn + (p1 + d - 1) * PB + dhoff + c1, sIn + (p2 + d - 1) * PB + dhoff + c2);
+        bfr[d] = WFrag<T>::load(sIn + (p1 + d - 1) * PB + dhoff + c1, sIn + (p2 + d - 1) * PB + dhoff + c2);
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int d = 0; d < 3; ++d) Mma<bf16>::mma(af, bfr[d], acc[d]);
+      for (int d = 0; d < 3; ++d) Mma<T>::mma(af, bfr[d], acc[d]);
       __builtin_amdgcn_s_setprio(0);
     }
     if (next < ntiles) commit(next, smem + (cur ^ 1) * C::BUF, smem + (cur ^ 1) * C::BUF + C::A_BYTES);
@@ -632,7 +633,7 @@ WgPlan plan_wgrad(const cy_conv_desc* d) {
     const char* e = getenv("CY_WGRAD12");
     return !(e && e[0] == '0');
   }();
-  p.twelve = twelve_enabled && d->in_dtype == CY_BF16;
+  p.twelve = twelve_enabled && d->in_dtype != CY_F32;
   const int Cin = d->C1 + d->C2;
   if (d->in_dtype == CY_F32) {
     p.wco = 1, p.wci = 1, p.wk = 4;
@@ -691,10 +692,10 @@ int launch_wgrad(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
   return CY_OK;
 }
 
-template <int WCO, int WCI, int WK>
+template <int WCO, int WCI, int WK, typename T = bf16>
 int launch_wgrad12(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
   using C = Wg12Cfg<WCO, WCI, WK>;
-  auto kern = wgrad12_kernel<WCO, WCI, WK>;
+  auto kern = wgrad12_kernel<WCO, WCI, WK, T>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -738,7 +739,7 @@ __global__ void __launch_bounds__(256)
       const int hq = (int)(row - (unsigned)n * (unsigned)H);
       float d[8];
       if constexpr (sizeof(T) == 2) {
-        Chunk<bf16>::unpack(ld16(dy + p * Cout + cg * 8), d);
+        Chunk<T>::unpack(ld16(dy + p * Cout + cg * 8), d);
       } else {
         Chunk<float>::unpack(ld16(dy + p * Cout + cg * 8), d);
         Chunk<float>::unpack(ld16(dy + p * Cout + cg * 8 + 4), d + 4);
@@ -835,8 +836,8 @@ static int wgrad_impl(const cy_conv_desc* d, const void* src1, const void* src2,
   if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C1 <= 0 || d->C2 < 0 || d->Cout <= 0)
     return CY_ERR_SHAPE;
   if (d->in_dtype != d->out_dtype) return CY_ERR_DTYPE;
-  if (d->in_dtype != CY_F32 && d->in_dtype != CY_BF16) return CY_ERR_DTYPE;
-  const int epc = d->in_dtype == CY_BF16 ? 8 : 4;
+  if (d->in_dtype != CY_F32 && d->in_dtype != CY_BF16 && d->in_dtype != CY_F16) return CY_ERR_DTYPE;
+  const int epc = d->in_dtype == CY_F32 ? 4 : 8;
   if (d->C1 % epc || d->C2 % epc || d->Cout % epc || d->ld1 % epc || d->ldo % epc)
     return CY_ERR_SHAPE;
   if (d->C2 && (!src2 || d->ld2 % epc)) return CY_ERR_ARG;
@@ -868,6 +869,13 @@ static int wgrad_impl(const cy_conv_desc* d, const void* src1, const void* src2,
   int rc;
   if (d->in_dtype == CY_F32) {
     rc = launch_wgrad<float, 1, 1, 4>(g, p, st);
+  } else if (p.twelve && d->in_dtype == CY_F16) {
+    if (p.wco == 2 && p.wci == 2) rc = launch_wgrad12<2, 2, 1, f16>(g, p, st);
+    else if (p.wco == 2) rc = launch_wgrad12<2, 1, 2, f16>(g, p, st);
+    else if (p.wci == 2) rc = launch_wgrad12<1, 2, 2, f16>(g, p, st);
+    else rc = launch_wgrad12<1, 1, 4, f16>(g, p, st);
+  } else if (d->in_dtype == CY_F16) {
+    return CY_ERR_DTYPE;  // (f16 runs the twelve-wave kernel only)
   } else if (p.twelve) {
     if (p.wco == 2 && p.wci == 2) rc = launch_wgrad12<2, 2, 1>(g, p, st);
     else if (p.wco == 2) rc = launch_wgrad12<2, 1, 2>(g, p, st);
@@ -935,6 +943,9 @@ int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int accumu
   hipStream_t st = (hipStream_t)stream;
   if (dy_dtype == CY_BF16)
     hipLaunchKernelGGL(first_wgrad_kernel<bf16>, dim3(nblk), dim3(256), 0, st, x, (const bf16*)dy,
+                       (float*)ws, N, Cin, H, W, Cout);
+  else if (dy_dtype == CY_F16)
+    hipLaunchKernelGGL(first_wgrad_kernel<f16>, dim3(nblk), dim3(256), 0, st, x, (const f16*)dy,
                        (float*)ws, N, Cin, H, W, Cout);
   else if (dy_dtype == CY_F32)
     hipLaunchKernelGGL(first_wgrad_kernel<float>, dim3(nblk), dim3(256), 0, st, x,

@@ -9,7 +9,7 @@ import ctypes as C
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
 from pathlib import Path
 
-CY_F32, CY_BF16 = 0, 1
+CY_F32, CY_BF16, CY_F16 = 0, 1, 2
 CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2 = 0, 1, 2
 ABI_VERSION = 6
 

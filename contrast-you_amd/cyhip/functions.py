@@ -178,7 +178,7 @@ def wgrad_into_sink(w: Tensor, sink: Tensor, src1: Tensor, src2: Optional[Tensor
     if p is not None:  # not the same layer geometry after all: issue it on its own
         _parked[id(w)] = p
         _flush_parked()
-    if PAIR_WGRAD and uses > 0 and pass_id != _step_first_pass and src1.dtype == torch.bfloat16:
+    if PAIR_WGRAD and uses > 0 and pass_id != _step_first_pass and src1.dtype in ops.HALF_TYPES:
         q = _Parked()
         q.w, q.sink, q.src1, q.src2, q.dy, q.mode, q.scale, q.shift = w, sink, src1, src2, dy, mode, scale, shift
         q.stream, q.event, q.capid = cur, torch.cuda.Event(), ops._capture_id(cur)
@@ -192,14 +192,16 @@ def wgrad_into_sink(w: Tensor, sink: Tensor, src1: Tensor, src2: Optional[Tensor
 
 
 def compute_dtype_for(x: Tensor, requested: Optional[torch.dtype]) -> torch.dtype:
-    """bf16 under autocast (AMPScaler.autocast, contrastyou/amp/amp.py:44), else the requested
-    dtype, else f32 (verification mode)."""
+    """the requested dtype; else, under autocast (AMPScaler.autocast, contrastyou/amp/amp.py:44), the
+    autocast dtype -- float16 in the reference's own mode (fp16 + GradScaler), bfloat16 in the build's
+    default mode; else the input's half type; else f32 (verification mode)."""
     if requested is not None:
         return requested
     if torch.is_autocast_enabled():
-        return torch.bfloat16
-    if x.dtype == torch.bfloat16:
-        return torch.bfloat16
+        dt = torch.get_autocast_dtype("cuda")
+        return dt if dt in ops.HALF_TYPES else torch.bfloat16
+    if x.dtype in ops.HALF_TYPES:
+        return x.dtype
     return torch.float32
 
 
@@ -548,7 +550,7 @@ class DenseProjHiddenFn(torch.autograd.Function):
     def forward(ctx, x: Tensor, w1: Tensor, b1: Tensor, size, bins: Optional[Tensor]):
         ops.require_gpu(x, w1)
         x = ops.to_nhwc(x)
-        if x.dtype not in (torch.float32, torch.bfloat16):
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
             x = x.float()
         w = w1.detach().reshape(w1.shape[0], -1).float().contiguous()
         b = b1.detach().float().contiguous()
@@ -697,6 +699,6 @@ def bilinear_resize(x: Tensor, size) -> Tensor:
     gradient -- the reference resizes input images only (semi_seg/hooks/cc.py:132)"""
     if x.requires_grad:
         raise RuntimeError("bilinear_resize: the HIP kernel is forward-only (input images carry no gradient)")
-    if x.dtype not in (torch.float32, torch.bfloat16):
+    if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         x = x.float()
     return ops.bilinear_fwd(x, tuple(size))

@@ -14,9 +14,10 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import CY_BF16, CY_F32, CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2, ConvDesc  # noqa: F401
+from ._lib import CY_BF16, CY_F16, CY_F32, CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2, ConvDesc  # noqa: F401
 
-_DT = {torch.float32: CY_F32, torch.bfloat16: CY_BF16}
+_DT = {torch.float32: CY_F32, torch.bfloat16: CY_BF16, torch.float16: CY_F16}
+HALF_TYPES = (torch.bfloat16, torch.float16)
 
 # bench.py instrumentation: when a list, every conv launch appends (family, algorithmic FLOPs,
 # start event, end event); events are recorded on the launch stream (torch's current stream).
@@ -43,7 +44,7 @@ def dtype_code(dt: torch.dtype) -> int:
     try:
         return _DT[dt]
     except KeyError:
-        raise TypeError(f"unsupported dtype {dt}: the HIP path computes in float32 or bfloat16") from None
+        raise TypeError(f"unsupported dtype {dt}: the HIP path computes in float32, bfloat16 or float16") from None
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)

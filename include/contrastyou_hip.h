@@ -13,7 +13,8 @@
  *   - activations are NHWC ("channels_last"): element (n,h,w,c) lives at
  *     ((n*H + h)*W + w)*ld + c, ld >= C the pixel pitch in elements;
  *   - dtype codes: CY_F32 (verification mode, f32 MFMA, exact fmaf chains)
- *     and CY_BF16 (production mode, bf16 MFMA with f32 accumulation);
+ *     CY_BF16 (production mode, bf16 MFMA with f32 accumulation) and CY_F16
+ *     (the reference's fp16 autocast mode, f16 MFMA with f32 accumulation);
  *   - return value 0 = enqueued, <0 = argument/shape error (nothing was
  *     launched), see CY_ERR_*.
  */
@@ -36,6 +37,8 @@ extern "C" {
 
 #define CY_F32 0
 #define CY_BF16 1
+#define CY_F16 2 /* IEEE half: the reference's own autocast dtype (contrastyou/amp/amp.py:13-45); same kernels as
+                  * CY_BF16 with mfma_f32_32x32x16_f16, f32 accumulation; needs loss scaling (torch GradScaler) */
 
 /* how source 1 of a 3x3 conv is addressed (arch/unet.py:67-70 MaxPool2d,
  * :38 Upsample(scale_factor=2) nearest, both folded into the conv's loads) */

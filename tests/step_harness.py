@@ -67,7 +67,7 @@ class RawTaps:
 
 
 def compare_step_with_oracle(device="cuda:0", n_l=2, n_unl=3, hw=32, max_channel=128, dtype=torch.float32,
-                             two_stage=True, lr=1e-3, py_seed=0, pin_routing=False):
+                             two_stage=True, lr=1e-3, py_seed=0, pin_routing=False, num_classes=4, return_grads=False):
     """pin_routing: the oracle differentiates the function the device evaluated (the device's ReLU / max-pool
     decisions and activation values, oracle.unet.unet_forward(force=)): deterministic gradient parity"""
     from contrastyou.amp import BF16Scaler
@@ -83,12 +83,12 @@ def compare_step_with_oracle(device="cuda:0", n_l=2, n_unl=3, hw=32, max_channel
     from semi_seg.hooks import create_infonce_hooks
 
     dev = torch.device(device)
-    sd0 = ou.init_state_dict(1, 4, max_channel, seed=7)
+    sd0 = ou.init_state_dict(1, num_classes, max_channel, seed=7)
     psd0 = ol.init_projector_sd(max_channel, 256, 256, seed=8)
-    b = ostep.synthetic_batch(n_l, n_unl, hw, 4, seed=99)
+    b = ostep.synthetic_batch(n_l, n_unl, hw, num_classes, seed=99)
 
     # ---------------- product ----------------
-    model = UNet(input_dim=1, num_classes=4, max_channel=max_channel, momentum=0.01)
+    model = UNet(input_dim=1, num_classes=num_classes, max_channel=max_channel, momentum=0.01)
     model.load_state_dict(sd0, strict=True)
     model.to(dev)
     type(TrainerHook).names.clear()
@@ -99,7 +99,10 @@ def compare_step_with_oracle(device="cuda:0", n_l=2, n_unl=3, hw=32, max_channel
     hook.to(dev)
     opt = RAdam([{"params": list(model.parameters())}, {"params": list(hook.parameters())}], lr=lr,
                 weight_decay=1e-5)
-    scaler = BF16Scaler() if dtype == torch.bfloat16 else torch.amp.GradScaler("cuda", enabled=False)
+    if dtype == torch.float16:  # the reference's own mode: fp16 autocast + loss scaling
+        scaler = torch.amp.GradScaler("cuda", enabled=True, init_scale=256.0)
+    else:
+        scaler = BF16Scaler() if dtype == torch.bfloat16 else torch.amp.GradScaler("cuda", enabled=False)
     lab = {"img": [b["labeled_image"], b["labeled_image"]], "gt": [b["labeled_target"], b["labeled_target"]],
            "filename": [[f"l{i}" for i in range(n_l)]] * 2, "partition": [["0"] * n_l] * 2,
            "scan_num": [b["labeled_scan"]] * 2}
@@ -149,7 +152,7 @@ def compare_step_with_oracle(device="cuda:0", n_l=2, n_unl=3, hw=32, max_channel
                           unlabeled_image_tf=ol.affine_nearest(b["unlabeled_image_cf"], theta.float(), gam).to(od),
                           theta=theta,
                           labels=labels, momentum=0.01, two_stage=two_stage,
-                          round_dtype=torch.bfloat16 if dtype == torch.bfloat16 else None,
+                          round_dtype=dtype if dtype in (torch.bfloat16, torch.float16) else None,
                           force=taps.force if pin_routing else None)
     out["total"].backward()
     names = [k for k, v in sd.items() if v.requires_grad]
@@ -174,12 +177,22 @@ def compare_step_with_oracle(device="cuda:0", n_l=2, n_unl=3, hw=32, max_channel
     # gradients are consumed by the fused optimizer in place; compare through the update instead,
     # plus the raw flat gradient buffer that is still intact after step()
     flat = opt._flat[0]
-    off, worst = 0, 0.0
+    off, worst, num, den = 0, 0.0, 0.0, 0.0
     for k, p in model.named_parameters():
         n = p.numel()
         g = flat.grad[off:off + n].view(p.shape)
         worst = max(worst, rel(g, grads[k]))
+        num += (g.detach().double().cpu() - grads[k].double()).pow(2).sum().item()
+        den += grads[k].double().pow(2).sum().item()
         off += n
-    res["rel_grad_worst"] = worst
+    res["rel_grad_worst"] = worst              # worst parameter, max-norm relative to that parameter's own gradient
+    res["rel_grad_l2"] = (num / den) ** 0.5    # whole gradient vector (what the optimizer step sees)
+    if return_grads:
+        off, dev_g = 0, {}
+        for k, p in model.named_parameters():
+            dev_g[k] = flat.grad[off:off + p.numel()].view(p.shape).detach().double().cpu()
+            off += p.numel()
+        res["_grads"] = (dev_g, {k: v.detach().double() for k, v in grads.items()})
     res["dice"] = semi["sup_dice"]["DSC_mean"]
+    res["scale_after"] = scaler.get_scale() if isinstance(scaler, torch.amp.GradScaler) and scaler.is_enabled() else None
     return res

@@ -43,7 +43,10 @@ def assert_close(a, b, rel, what=""):
     assert err <= rel * scale, f"{what}: max err {err:.3e} > {rel:.1e} * {scale:.3e}"
 
 
-TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2}
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2, torch.float16: 2e-3}
+WTOL = {torch.float32: 2e-5, torch.bfloat16: 2e-3, torch.float16: 5e-4}   # f32 weight gradients
+ATOL = {torch.float32: 1e-5, torch.bfloat16: 1e-2, torch.float16: 2e-3}   # elementwise activations
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 CONV_CASES = [
     # N, H, W, C1, C2, Cout, mode, prologue
@@ -97,14 +100,14 @@ def make_conv_case(case, dtype, seed):
     return x1, x2, w, scale, shift
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3x3_fwd_and_stats(case, dtype):
     ops = _ops()
     N, H, W, C1, C2, Cout, mode, pro = case
     x1, x2, w, scale, shift = make_conv_case(case, dtype, 1)
-    if pro and dtype == torch.bfloat16:
-        # the kernel rounds relu(scale*x+shift) to bf16 before the MFMA: do the same
+    if pro and dtype != torch.float32:
+        # the kernel rounds relu(scale*x+shift) to the storage type before the MFMA: do the same
         a = F.relu(x1 * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(dtype).float()
         ref = F.conv2d(a, w, None, 1, 1)
     else:
@@ -123,7 +126,7 @@ def test_conv3x3_fwd_and_stats(case, dtype):
     assert_close(s[1] / count, (o * o).sum(dim=(0, 2, 3)) / count, 1e-4, "stat sumsq")
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 16, 16, 32, 64, 64), (2, 14, 14, 64, 64, 256), (1, 28, 28, 128, 128, 128)])
 def test_conv3x3_dgrad_with_split(shape, dtype):
     """data gradient with the two-destination (concat) epilogue, incl. the split-K path"""
@@ -154,7 +157,7 @@ WGRAD_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", WGRAD_CASES)
 def test_conv3x3_wgrad(case, dtype):
     ops = _ops()
@@ -163,7 +166,7 @@ def test_conv3x3_wgrad(case, dtype):
     g = torch.Generator().manual_seed(9)
     dy = rnd(N, Cout, H, W, gen=g).to(dtype).float()
     wv = w.clone().requires_grad_(True)
-    if pro and dtype == torch.bfloat16:
+    if pro and dtype != torch.float32:
         a = F.relu(x1 * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(dtype).float()
         y = F.conv2d(a, wv, None, 1, 1)
     else:
@@ -172,10 +175,10 @@ def test_conv3x3_wgrad(case, dtype):
     dw = ops.conv3x3_wgrad(nhwc(x1, dtype), None if x2 is None else nhwc(x2, dtype), nhwc(dy, dtype),
                            mode=mode, scale=None if scale is None else scale.to(DEV),
                            shift=None if shift is None else shift.to(DEV))
-    assert_close(dw, wv.grad, 2e-5 if dtype == torch.float32 else 2e-3, f"wgrad {case} {dtype}")
+    assert_close(dw, wv.grad, WTOL[dtype], f"wgrad {case} {dtype}")
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout", [(1, 32), (3, 8), (1, 16)])
 def test_first_conv_fwd_wgrad(cin, cout, dtype):
     ops = _ops()
@@ -192,10 +195,10 @@ def test_first_conv_fwd_wgrad(cin, cout, dtype):
     dy = rnd(3, cout, 24, 40, gen=g).to(dtype).float()
     (ref * dy).sum().backward()
     dw = ops.conv_first_wgrad(x.to(DEV), nhwc(dy, dtype))
-    assert_close(dw, w.grad, 2e-5 if dtype == torch.float32 else 2e-3, "first conv wgrad")
+    assert_close(dw, w.grad, WTOL[dtype], "first conv wgrad")
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C,hw", [(32, 24), (8, 12), (512, 6), (40, 10)])
 def test_bn_relu_fwd_bwd(C, hw, dtype):
     ops = _ops()
@@ -219,21 +222,21 @@ def test_bn_relu_fwd_bwd(C, hw, dtype):
     assert_close(rvd, rv, 1e-5, "running var")
     yg = nhwc(y.detach(), dtype)
     out = ops.bn_relu_apply(yg, scale, shift)
-    assert_close(out, out_ref, 1e-5 if dtype == torch.float32 else 1e-2, "bn relu apply")
+    assert_close(out, out_ref, ATOL[dtype], "bn relu apply")
     dy, dgamma, dbeta = ops.bn_relu_bwd(nhwc(da, dtype), yg, scale, shift, mean, invstd, True)
     assert_close(dgamma, gamma.grad, 1e-4, "dgamma")
     assert_close(dbeta, beta.grad, 1e-4, "dbeta")
-    assert_close(dy, y.grad, 1e-4 if dtype == torch.float32 else 1.2e-2, "bn bwd dy")
+    assert_close(dy, y.grad, 1e-4 if dtype == torch.float32 else TOL[dtype], "bn bwd dy")
     # eval-mode scale/shift from running stats, no update
     rm2, rv2 = rmd.clone(), rvd.clone()
     s2, h2, _, _ = ops.bn_finalize(None, count, gamma.detach().to(DEV), beta.detach().to(DEV), rm2, rv2, 0.01,
                                    1e-5, False, False, C, DEV)
     ref_eval = F.relu(F.batch_norm(y.detach(), cpu(rmd), cpu(rvd), gamma.detach(), beta.detach(), False, 0.0, 1e-5))
-    assert_close(ops.bn_relu_apply(yg, s2, h2), ref_eval, 1e-5 if dtype == torch.float32 else 1e-2, "bn eval")
+    assert_close(ops.bn_relu_apply(yg, s2, h2), ref_eval, ATOL[dtype], "bn eval")
     assert torch.equal(rm2, rmd) and torch.equal(rv2, rvd)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_pool_upsample_bwd(dtype):
     ops = _ops()
     g = torch.Generator().manual_seed(5)
@@ -245,14 +248,14 @@ def test_pool_upsample_bwd(dtype):
     assert_close(dx, x.grad, 1e-6, "maxpool bwd")
     add = rnd(2, 16, 12, 20, gen=g).to(dtype).float()
     dx2 = ops.maxpool2_bwd(nhwc(x.detach(), dtype), nhwc(dp, dtype), nhwc(add, dtype))
-    assert_close(dx2, x.grad + add, 1e-6 if dtype == torch.float32 else 1e-2, "maxpool bwd + add")
+    assert_close(dx2, x.grad + add, 1e-6 if dtype == torch.float32 else ATOL[dtype], "maxpool bwd + add")
     u = rnd(2, 16, 6, 10, gen=g).requires_grad_(True)
     du = rnd(2, 16, 12, 20, gen=g).to(dtype).float()
     (F.interpolate(u, scale_factor=2, mode="nearest") * du).sum().backward()
-    assert_close(ops.upsample2_bwd(nhwc(du, dtype)), u.grad, 1e-6 if dtype == torch.float32 else 1e-2, "upsample bwd")
+    assert_close(ops.upsample2_bwd(nhwc(du, dtype)), u.grad, 1e-6 if dtype == torch.float32 else ATOL[dtype], "upsample bwd")
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("K", [4, 2, 5, 8])
 def test_head_and_losses(K, dtype):
     ops = _ops()
@@ -276,7 +279,7 @@ def test_head_and_losses(K, dtype):
     dx, dw, db = ops.head_bwd(xg, w.detach().to(DEV), dl, True, True)
     assert_close(dw, w.grad, 1e-4, "head dw")
     assert_close(db, b.grad, 1e-4, "head db")
-    assert_close(dx, x.grad, 1e-4 if dtype == torch.float32 else 1e-2, "head dx")
+    assert_close(dx, x.grad, 1e-4 if dtype == torch.float32 else ATOL[dtype], "head dx")
     # softmax-MSE pair
     a = rnd(N, K, H, W, gen=g).requires_grad_(True)
     c = rnd(N, K, H, W, gen=g).requires_grad_(True)
@@ -380,7 +383,7 @@ def test_supcon_large_against_oracle():
     assert_close(dP, torch.cat([a.grad, b.grad]).float(), 1e-4, "large supcon dP")
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_affine_fwd_bwd(dtype):
     ops = _ops()
     from oracle.losses import affine_nearest, make_theta
@@ -397,7 +400,7 @@ def test_affine_fwd_bwd(dtype):
     out = ops.affine_fwd(nhwc(x.detach(), dtype), thetas.to(DEV))
     assert_close(out, ref, 1e-6, "affine fwd")
     dx = ops.affine_bwd(nhwc(dout, dtype), thetas.to(DEV))
-    assert_close(dx, x.grad, 1e-6 if dtype == torch.float32 else 1e-2, "affine bwd")
+    assert_close(dx, x.grad, 1e-6 if dtype == torch.float32 else ATOL[dtype], "affine bwd")
     if dtype == torch.float32:
         img = torch.rand(N, 1, 32, 32, generator=g)
         gam = torch.tensor([0.5, 1.0, 1.7, 2.0])
@@ -426,7 +429,7 @@ def test_ema_and_radam():
         assert_close(pg, p.detach(), 1e-6, f"radam step {step}")
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_batched_weight_pack_equals_per_layer_pack(dtype):
     """cy_conv3x3_pack_weights_batched (one launch for all layers) writes the same packed images as
     cy_conv3x3_pack_weights layer by layer"""

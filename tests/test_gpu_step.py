@@ -25,7 +25,7 @@ def test_f32_step_gradients_with_pinned_routing(two_stage):
     from tests.step_harness import compare_step_with_oracle
     r = compare_step_with_oracle(n_l=2, n_unl=3, hw=32, max_channel=128, dtype=torch.float32, two_stage=two_stage,
                                  pin_routing=True)
-    assert r["rel_grad_worst"] < 2e-4, r
+    assert r["rel_grad_worst"] < 2e-4 and r["rel_grad_l2"] < 1e-5, r
     assert r["rel_param_after_step"] < 1e-4 and r["rel_proj_after_step"] < 1e-4, r
 
 
@@ -41,3 +41,27 @@ def test_bf16_step_runs_and_tracks_oracle():
     # bf16 storage: losses agree to a few percent with the oracle's bf16-rounded emulation
     assert r["rel_sup"] < 5e-2 and r["rel_reg"] < 8e-2, r
     assert 0.0 <= r["dice"] <= 1.0
+
+
+def test_fp16_gradscaler_step_c4_geometry():
+    """BASELINE config 4 in small: 8 classes, 256 x 256 (the igemm kernels), the reference's own AMP mode --
+    fp16 autocast + torch GradScaler (contrastyou/amp/amp.py:13-45) -- against the oracle with fp16 storage
+    rounding.  fp16 storage: losses within a few percent; the scaled step was taken (no inf), the gradients
+    handed to RAdam are the unscaled ones."""
+    from tests.step_harness import compare_step_with_oracle
+    r = compare_step_with_oracle(n_l=2, n_unl=2, hw=256, max_channel=128, dtype=torch.float16, num_classes=8)
+    assert r["rel_sup"] < 2e-2 and r["rel_reg"] < 5e-2, r
+    assert r["scale_after"] == 256.0, r                   # GradScaler.update() saw no inf: the step was taken
+    assert r["rel_param_after_step"] < 2e-2, r            # RAdam moved the weights like the oracle's (lr-sized step)
+    assert 0.0 <= r["dice"] <= 1.0
+    # gradients: routing pinned to the device's own decisions (fp16 noise flips many ReLUs otherwise), f64 oracle;
+    # what RAdam is handed are the UNSCALED gradients, within fp16 activation rounding of the exact ones
+    g = compare_step_with_oracle(n_l=2, n_unl=2, hw=256, max_channel=128, dtype=torch.float16, num_classes=8,
+                                 pin_routing=True)
+    assert g["scale_after"] == 256.0, g
+    # whole gradient vector within fp16 activation rounding.  (Per parameter the bar cannot be tight in half
+    # precision: the high-resolution decoder's BN biases have gradients ~1e-4 -- sums of 10^5 cancelling terms
+    # ~1e3 x larger -- which move by 100 % between the f32 and the fp16-rounded forward pass of the ORACLE
+    # itself; in f32 mode the same harness holds every parameter to 2e-4, see the pinned f32 tests)
+    assert g["rel_grad_l2"] < 1e-2, g
+    assert g["rel_grad_worst"] < 0.5, g
