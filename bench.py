@@ -93,7 +93,43 @@ def build_step(device, rank: int, n_l: int, n_unl: int, hw: int, max_channel: in
                 criterion=KL_div(), scaler=scaler)
 
 
+def build_step_c5(device, rank: int, n_unl: int, hw: int, max_channel: int):
+    """BASELINE config 5: encoder pre-training, `until="Conv5"`, n_unl slices x 2 views per rank, InfoNCE with
+    the embeddings of every rank as negatives (all-gather over RCCL when world > 1), decoder frozen
+    (main.py:93-100: switch_grad(False, start=until, include_start=False))"""
+    from contrastyou.amp import BF16Scaler
+    from contrastyou.arch import UNet
+    from contrastyou.hooks.base import TrainerHook
+    from contrastyou.losses.kl import KL_div
+    from contrastyou.optim import RAdam
+    from semi_seg.hooks import create_infonce_hooks
+
+    torch.manual_seed(10)
+    model = UNet(input_dim=1, num_classes=4, max_channel=max_channel, momentum=0.01).to(device)
+    for name in model.decoder_names:
+        model.get_module(name).requires_grad_(False)
+    type(TrainerHook).names.clear()
+    hook = create_infonce_hooks(model=model, feature_names="Conv5", weights=1.0, contrast_ons="partition",
+                                spatial_size=1, data_name="acdc", global_negatives=True).to(device)
+    params = [p for p in model.parameters() if p.requires_grad]
+    optimizer = RAdam([{"params": params}, {"params": list(hook.parameters())}], lr=3e-5, weight_decay=1e-5)
+    chain = SyntheticLoader(n_unl, hw, 4, device, 4321 + rank, "unl")
+    return dict(model=model, hook=hook, optimizer=optimizer, labeled=chain, unlabeled=chain, chain=chain,
+                criterion=KL_div(), scaler=BF16Scaler(), workload="c5")
+
+
 def run_epoch(ctx, device, num_batches: int, epoch: int):
+    if ctx.get("workload") == "c5":
+        from semi_seg.epochers import PretrainDecoderEpocher
+        ep = PretrainDecoderEpocher(model=ctx["model"], optimizer=ctx["optimizer"], labeled_loader=ctx["labeled"],
+                                    unlabeled_loader=ctx["unlabeled"], sup_criterion=ctx["criterion"],
+                                    num_batches=num_batches, cur_epoch=epoch, device=device, two_stage=False,
+                                    disable_bn=False, chain_dataloader=ctx["chain"], inference_until="Conv5",
+                                    scaler=ctx["scaler"], accumulate_iter=1)
+        ep.init()
+        with ep.register_hook(ctx["hook"]()):
+            ep.run()
+        return ep
     from semi_seg.epochers import SemiSupervisedEpocher
     ep = SemiSupervisedEpocher(model=ctx["model"], optimizer=ctx["optimizer"], labeled_loader=ctx["labeled"],
                                unlabeled_loader=ctx["unlabeled"], sup_criterion=ctx["criterion"],
@@ -200,6 +236,9 @@ def main():
     ap.add_argument("--n-unlabeled", type=int, default=16)
     ap.add_argument("--hw", type=int, default=224)
     ap.add_argument("--max-channel", type=int, default=512)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5"],
+                    help="c2 (default, the BASELINE metric's config): semi-supervised step; c5: encoder "
+                         "pre-training, 256 slices x 2 views per GPU, until=Conv5, global negatives")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -220,7 +259,13 @@ def main():
             print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
     t_start = time.perf_counter()
-    ctx = build_step(device, rank, a.n_labeled, a.n_unlabeled, a.hw, a.max_channel)
+    if a.workload == "c5":
+        n_c5 = a.n_unlabeled if a.n_unlabeled != 16 else 256
+        ctx = build_step_c5(device, rank, n_c5, a.hw, a.max_channel)
+        a.n_labeled, a.n_unlabeled = 0, n_c5
+        a.no_cpu_baseline = True
+    else:
+        ctx = build_step(device, rank, a.n_labeled, a.n_unlabeled, a.hw, a.max_channel)
     note("model / hooks / optimizer built")
 
     def barrier():
@@ -261,15 +306,19 @@ def main():
         # where a loss reaches: the decoder of the unlabeled pass gets no gradient in this config),
         # summed over the instrumented launches; falls back to the SURVEY formula without them
         flops_step = sum(v["tflop_per_step"] for v in detail.values()) * 1e12 if detail else (
-            passes * 75.04e9 * (a.hw / 224.0) ** 2 if a.max_channel == 512 else None)
+            passes * 75.04e9 * (a.hw / 224.0) ** 2 if (a.max_channel == 512 and a.workload == "c2") else None)
         line = {
             "metric": "2D slices/sec on ACDC U-Net+InfoNCE step", "value": round(slices / per_step, 2),
             "unit": "slices/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(per_step * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "C2: ACDC SemiSupervisedEpocher + InfoNCE@Conv5 (partition), two-stage, "
-                                   f"{a.n_labeled} labeled + {a.n_unlabeled} unlabeled 1x{a.hw}x{a.hw} per GPU, "
-                                   f"4 classes, UNet max_channel={a.max_channel}, RAdam",
+            "config": {"workload": (f"C5: encoder pre-training (PretrainDecoderEpocher, until=Conv5), {a.n_unlabeled} "
+                                    f"slices x 2 views 1x{a.hw}x{a.hw} per GPU, InfoNCE over {2 * a.n_unlabeled * world} "
+                                    f"embeddings (all-gather), UNet max_channel={a.max_channel}, decoder frozen, RAdam")
+                       if a.workload == "c5" else
+                       ("C2: ACDC SemiSupervisedEpocher + InfoNCE@Conv5 (partition), two-stage, "
+                        f"{a.n_labeled} labeled + {a.n_unlabeled} unlabeled 1x{a.hw}x{a.hw} per GPU, "
+                        f"4 classes, UNet max_channel={a.max_channel}, RAdam"),
                        "global_batch": slices, "network_passes_per_step_per_gpu": passes,
                        "parallelism": f"dp{world}",
                        "step_tflops_per_gpu": None if flops_step is None else round(flops_step / 1e12, 3),

@@ -58,6 +58,35 @@ def _worker(rank: int, world: int, port: int, q):
         dist.all_gather(both, flat)
         assert torch.equal(both[0], both[1]), "parameters differ across ranks after the broadcast"
         assert torch.equal(flat, mine) == (rank == 0)
+        # InfoNCE with global negatives (BASELINE config 5): every rank evaluates the loss on the embeddings of
+        # ALL ranks (gather_cat: values from everywhere, autograd into the local rows), scaled by world_size;
+        # the gradient MEAN the optimizer takes over ranks must equal the gradient of the single-process loss
+        # on the union batch (semi_seg/hooks/infonce.py uses exactly this composition)
+        sys.path.insert(0, str(REPO))
+        from oracle.losses import supcon_loss
+        torch.manual_seed(5)
+        enc = torch.nn.Linear(6, 8).double()
+        gx = torch.Generator().manual_seed(77)
+        xs = [torch.randn(4, 6, generator=gx, dtype=torch.float64) for _ in range(2 * world)]  # (view1, view2) per rank
+        norm = torch.nn.functional.normalize
+        z1 = norm(enc(xs[2 * rank]), dim=1)
+        z2 = norm(enc(xs[2 * rank + 1]), dim=1)
+        tgt = parallel.gather_labels([(rank * 4 + i) % 3 for i in range(4)])
+        loss = supcon_loss(parallel.gather_cat(z1), parallel.gather_cat(z2), target=tgt) * world
+        enc.zero_grad()
+        loss.backward()
+        gdp = [p.grad.clone() for p in enc.parameters()]
+        for t_ in gdp:
+            dist.all_reduce(t_)
+            t_.div_(world)
+        enc.zero_grad()
+        z1a = norm(enc(torch.cat([xs[2 * r] for r in range(world)])), dim=1)
+        z2a = norm(enc(torch.cat([xs[2 * r + 1] for r in range(world)])), dim=1)
+        single = supcon_loss(z1a, z2a, target=[(r * 4 + i) % 3 for r in range(world) for i in range(4)])
+        single.backward()
+        assert abs(loss.item() / world - single.item()) < 1e-12
+        for a_, p_ in zip(gdp, enc.parameters()):
+            assert torch.allclose(a_, p_.grad, rtol=1e-10, atol=1e-12), (a_ - p_.grad).abs().max()
         labels = parallel.gather_labels([f"r{rank}_{i}" for i in range(2)])
         assert labels == ["r0_0", "r0_1", "r1_0", "r1_1"]
         q.put((rank, "ok"))

@@ -383,6 +383,26 @@ def test_supcon_large_against_oracle():
     assert_close(dP, torch.cat([a.grad, b.grad]).float(), 1e-4, "large supcon dP")
 
 
+def test_supcon_c5_size_against_oracle():
+    """BASELINE config 5: 4096 global embeddings (2 x 2048 rows, D = 256), partition labels, f64 oracle"""
+    ops = _ops()
+    from oracle.losses import supcon_loss
+    g = torch.Generator().manual_seed(11)
+    n, D = 2048, 256
+    z1 = F.normalize(torch.randn(n, D, generator=g), dim=1)
+    z2 = F.normalize(z1 + 0.5 * torch.randn(n, D, generator=g), dim=1)
+    target = [i % 3 for i in range(n)]
+    a, b = z1.double().requires_grad_(True), z2.double().requires_grad_(True)
+    ref = supcon_loss(a, b, target=target)
+    ref.backward()
+    P = torch.cat([z1, z2]).to(DEV)
+    lab = torch.tensor(target, dtype=torch.int32, device=DEV)
+    loss, S, stats = ops.supcon_fwd(P, lab, None, 0.07)
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item()), (loss.item(), ref.item())
+    dP = ops.supcon_bwd(P, lab, None, S, stats, torch.ones(1, device=DEV), 0.07)
+    assert_close(dP, torch.cat([a.grad, b.grad]).float(), 1e-4, "C5 supcon dP")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_affine_fwd_bwd(dtype):
     ops = _ops()
