@@ -3,9 +3,17 @@ Conv2d(3x3, padding 1, bias) -> GroupNorm(groups, C) -> SiLU, on the HIP kernels
 
 `proj` / `norm` / `act` are parameter holders with the reference's names (checkpoints
 interchange); forward runs the bias-free implicit-GEMM convolution and folds the conv bias into
-the GroupNorm+SiLU kernels (cyhip.functions.Conv3x3Fn / GNSiLUFn).  The rest of UNet2 (linear
-attention, 4x4 strided / transposed convolutions, time embeddings) is outside this build's scope
-("not reachable from the InfoNCE hook"); `get_arch("unet2")` says so.
+the GroupNorm+SiLU kernels (cyhip.functions.Conv3x3Fn / GNSiLUFn).
+
+`UNet2` (contrastyou/arch/unet2.py:22-135), the second `get_arch` target: every ResnetBlock's two
+3x3 conv + GroupNorm + SiLU stages -- 18 of them, where the network's FLOPs are -- run on those HIP
+kernels; the glue around them (7x7 stem, 1x1 residual / qkv / output projections, 4x4 stride-2
+down / transposed up convolutions, channel LayerNorm, the linear- and softmax-attention contractions)
+is plain library work (MIOpen / rocBLAS through torch): it is not on the SemiSupervisedEpocher +
+InfoNCE hot path (UNet2 has no `until=` / `arch_elements`, semi_seg/hooks/infonce.py:98 cannot
+attach to it), so it gets no hand-written kernels.  Module and parameter names are the
+reference's (checkpoints interchange); time embeddings are not supported (the segmentation
+configs never enable them).
 """
 from __future__ import annotations
 
@@ -17,14 +25,14 @@ from torch import Tensor, nn
 from cyhip import ops
 from cyhip.functions import Conv3x3Fn, GNSiLUFn, compute_dtype_for
 
-__all__ = ["Block"]
+__all__ = ["Block", "UNet2"]
 
 
 class Block(nn.Module):
     def __init__(self, dim, dim_out, groups=8):
         super().__init__()
-        if dim % 8 or dim_out % 8 or dim_out % groups:
-            raise NotImplementedError("the HIP block needs channel counts that are multiples of 8 "
+        if dim_out % 8 or dim_out % groups:
+            raise NotImplementedError("the HIP block needs output channel counts that are multiples of 8 "
                                       f"(and of `groups`), got {dim} -> {dim_out}, groups={groups}")
         self.proj = nn.Conv2d(dim, dim_out, 3, padding=1)
         self.norm = nn.GroupNorm(groups, dim_out)
@@ -36,7 +44,185 @@ class Block(nn.Module):
             raise NotImplementedError("time-embedding scale/shift is not used by the segmentation path")
         ops.require_gpu(x)
         dt = compute_dtype_for(x, self.compute_dtype)
+        w = self.proj.weight
+        pad = (-x.shape[1]) % 8
+        if pad:  # (UNet2's stem has 10 channels: zero channels change nothing, the kernels load 8 at a time)
+            x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, pad))
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, pad))
         x = ops.to_nhwc(x if x.dtype == dt else x.to(dt))
-        y = Conv3x3Fn.apply(x, self.proj.weight)
+        y = Conv3x3Fn.apply(x, w)
         return GNSiLUFn.apply(y, self.proj.bias, self.norm.weight, self.norm.bias, self.norm.num_groups,
                               self.norm.eps)
+
+
+# ---- the rest of UNet2: library ops around the HIP blocks ---------------------------------------------
+class _Residual(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, x):
+        return self.fn(x) + x
+
+
+class _ChanLayerNorm(nn.Module):
+    """normalisation over the channel axis of an NCHW map with [1,C,1,1] affine (unet2.py:183-194)"""
+
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.g = nn.Parameter(torch.ones(1, dim, 1, 1))
+        self.b = nn.Parameter(torch.zeros(1, dim, 1, 1))
+
+    def forward(self, x):
+        mu = x.mean(dim=1, keepdim=True)
+        var = (x - mu).pow(2).mean(dim=1, keepdim=True)
+        return (x - mu) * torch.rsqrt(var + self.eps) * self.g + self.b
+
+
+class _PreNorm(nn.Module):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.fn = fn
+        self.norm = _ChanLayerNorm(dim)
+
+    def forward(self, x):
+        return self.fn(self.norm(x))
+
+
+def _heads(t: Tensor, heads: int) -> Tensor:
+    b, c, h, w = t.shape
+    return t.reshape(b, heads, c // heads, h * w)  # "b (h c) x y -> b h c (x y)"
+
+
+class _LinearAttention(nn.Module):
+    """softmax(q over channels), softmax(k over positions), out = (k v^T)^T q (unet2.py:245-271)"""
+
+    def __init__(self, dim, heads=4, dim_head=32):
+        super().__init__()
+        self.scale, self.heads = dim_head ** -0.5, heads
+        hidden = dim_head * heads
+        self.to_qkv = nn.Conv2d(dim, hidden * 3, 1, bias=False)
+        self.to_out = nn.Sequential(nn.Conv2d(hidden, dim, 1), _ChanLayerNorm(dim))
+
+    def forward(self, x):
+        b, _, h, w = x.shape
+        q, k, v = (_heads(t, self.heads) for t in self.to_qkv(x).chunk(3, dim=1))
+        q = q.softmax(dim=-2) * self.scale
+        k = k.softmax(dim=-1)
+        context = torch.matmul(k, v.transpose(-1, -2))         # [b,h,d,e]
+        out = torch.matmul(context.transpose(-1, -2), q)       # [b,h,e,n]
+        return self.to_out(out.reshape(b, -1, h, w))
+
+
+class _Attention(nn.Module):
+    """plain softmax attention over all positions of the bottleneck map (unet2.py:274-304)"""
+
+    def __init__(self, dim, heads=4, dim_head=32):
+        super().__init__()
+        self.scale, self.heads = dim_head ** -0.5, heads
+        hidden = dim_head * heads
+        self.to_qkv = nn.Conv2d(dim, hidden * 3, 1, bias=False)
+        self.to_out = nn.Conv2d(hidden, dim, 1)
+
+    def forward(self, x):
+        b, _, h, w = x.shape
+        q, k, v = (_heads(t, self.heads) for t in self.to_qkv(x).chunk(3, dim=1))
+        sim = torch.matmul((q * self.scale).transpose(-1, -2), k)                 # [b,h,i,j]
+        attn = (sim - sim.amax(dim=-1, keepdim=True).detach()).softmax(dim=-1)
+        out = torch.matmul(attn, v.transpose(-1, -2))                             # [b,h,i,d]
+        return self.to_out(out.transpose(-1, -2).reshape(b, -1, h, w))            # "b h (x y) d -> b (h d) x y"
+
+
+class ResnetBlock(nn.Module):
+    """Block -> Block + (1x1 conv | identity) shortcut (unet2.py:227-243, without the time-embedding MLP)"""
+
+    def __init__(self, dim, dim_out, *, time_emb_dim=None, groups=8):
+        super().__init__()
+        if time_emb_dim is not None:
+            raise NotImplementedError("time embeddings are not used by the segmentation path")
+        self.mlp = None
+        self.block1 = Block(dim, dim_out, groups=groups)
+        self.block2 = Block(dim_out, dim_out, groups=groups)
+        self.res_conv = nn.Conv2d(dim, dim_out, 1) if dim != dim_out else nn.Identity()
+
+    def forward(self, x, time_emb=None):
+        h = self.block2(self.block1(x))
+        return h + self.res_conv(x).to(h.dtype)
+
+
+class UNet2(nn.Module):
+    def __init__(self, init_dim=None, num_classes=None, dim_mults=(1, 2, 4, 8), input_dim=3, dim=16,
+                 with_time_emb=False, resnet_block_groups=8, learned_variance=False, **kwargs):
+        super().__init__()
+        if with_time_emb:
+            raise NotImplementedError("time embeddings are not used by the segmentation path")
+        self.channels = input_dim
+        init_dim = init_dim if init_dim is not None else dim // 3 * 2
+        self.init_conv = nn.Conv2d(input_dim, init_dim, 7, padding=3)
+        dims = [init_dim] + [dim * m for m in dim_mults]
+        in_out = list(zip(dims[:-1], dims[1:]))
+        self.time_mlp = None
+        g = resnet_block_groups
+        n_res = len(in_out)
+        self.downs, self.ups = nn.ModuleList([]), nn.ModuleList([])
+        for i, (cin, cout) in enumerate(in_out):
+            last = i >= n_res - 1
+            self.downs.append(nn.ModuleList([
+                ResnetBlock(cin, cout, groups=g), ResnetBlock(cout, cout, groups=g),
+                _Residual(_PreNorm(cout, _LinearAttention(cout))),
+                nn.Identity() if last else nn.Conv2d(cout, cout, 4, 2, 1)]))
+        mid = dims[-1]
+        self.mid_block1 = ResnetBlock(mid, mid, groups=g)
+        self.mid_attn = _Residual(_PreNorm(mid, _Attention(mid)))
+        self.mid_block2 = ResnetBlock(mid, mid, groups=g)
+        for i, (cin, cout) in enumerate(reversed(in_out[1:])):
+            last = i >= n_res - 1
+            self.ups.append(nn.ModuleList([
+                ResnetBlock(cout * 2, cin, groups=g), ResnetBlock(cin, cin, groups=g),
+                _Residual(_PreNorm(cin, _LinearAttention(cin))),
+                nn.Identity() if last else nn.ConvTranspose2d(cin, cin, 4, 2, 1)]))
+        self.out_dim = num_classes if num_classes is not None else input_dim * (2 if learned_variance else 1)
+        self.num_classes = num_classes
+        self.final_conv = nn.Sequential(ResnetBlock(dim, dim, groups=g), nn.Conv2d(dim, self.out_dim, 1))
+        self._compute_dtype: Optional[torch.dtype] = None
+
+    @property
+    def compute_dtype(self):
+        return self._compute_dtype
+
+    @compute_dtype.setter
+    def compute_dtype(self, dt):
+        self._compute_dtype = dt
+        for m in self.modules():
+            if isinstance(m, Block):
+                m.compute_dtype = dt
+
+    def forward(self, x, time=None):
+        ops.require_gpu(x)
+        dt = self._compute_dtype
+        if dt in ops.HALF_TYPES and not torch.is_autocast_enabled():
+            # forced half-precision mode outside an autocast region: the library glue follows the blocks' dtype
+            with torch.autocast("cuda", dtype=dt):
+                return self._forward(x)
+        return self._forward(x)
+
+    def _forward(self, x):
+        x = self.init_conv(x)
+        skips = []
+        for block1, block2, attn, down in self.downs:
+            x = attn(block2(block1(x)))
+            skips.append(x)
+            x = down(x)
+        x = self.mid_block2(self.mid_attn(self.mid_block1(x)))
+        for block1, block2, attn, up in self.ups:
+            x = up(attn(block2(block1(torch.cat((x, skips.pop()), dim=1)))))
+        return self.final_conv(x)
+
+    def switch_grad(self, **kwargs):
+        from contextlib import nullcontext
+        return nullcontext()
+
+    def switch_bn_track(self, **kwargs):
+        from contextlib import nullcontext
+        return nullcontext()

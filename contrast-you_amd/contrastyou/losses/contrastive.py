@@ -19,7 +19,7 @@ import torch
 from torch import Tensor, nn
 
 from cyhip import ops
-from cyhip.functions import SupConFn
+from cyhip.functions import SgemmFn, SupConFn
 
 
 def is_normalized(feature: Tensor, dim=1) -> bool:
@@ -121,3 +121,70 @@ class SupConLoss1(nn.Module):
     @property
     def neg_mask(self) -> Tensor:
         return self._matrices()[3]
+
+
+class SelfPacedSupConLoss(nn.Module):
+    """`SelfPacedSupConLoss` (contrastyou/losses/contrastive.py:103-212): SupConLoss1 whose positive pairs are
+    weighted by a self-paced mask computed (without gradient) from their own log-likelihood,
+    hard: [l_ij <= gamma], soft: max(1 - l_ij / gamma, 0); gamma -> infinity recovers SupConLoss1 (the identity
+    the reference checks in its __main__, :241-248).  The similarity GEMM P P^T / t runs on the f32 MFMA kernel
+    (cyhip.functions.SgemmFn, differentiable); the 2n x 2n elementwise part is plain autograd -- this loss is
+    used at a few dozen rows by SelfPacedINFONCEHook, never at C5 sizes."""
+
+    def __init__(self, temperature=0.07, weight_update="hard", correct_grad=False, **kwargs):
+        super().__init__()
+        assert weight_update in ("hard", "soft"), weight_update
+        self._t, self._weight_update, self._correct_grad = temperature, weight_update, correct_grad
+        self._gamma = 1e6
+
+    def __repr__(self):
+        return f"{self.__class__.__name__} with T: {self._t}, method: {self._weight_update} gamma: {self._gamma}"
+
+    def set_gamma(self, gamma):
+        self._gamma = float(gamma)
+
+    @property
+    def age_param(self):
+        return self._gamma
+
+    def forward(self, proj_feat1: Tensor, proj_feat2: Tensor, target=None, mask: Optional[Tensor] = None, **kwargs):
+        assert proj_feat1.shape == proj_feat2.shape, (proj_feat1.shape, proj_feat2.shape)
+        ops.require_gpu(proj_feat1, proj_feat2)
+        n, dev = proj_feat1.shape[0], proj_feat1.device
+        if mask is not None:
+            assert mask.shape == torch.Size([n, n])
+            pos = (mask == 1).float().to(dev)
+        elif target is not None:
+            t = _encode_target(target, n, dev)
+            pos = torch.eq(t[:, None], t[None, :]).float()
+        else:
+            pos = torch.eye(n, dtype=torch.float, device=dev)
+        neg = 1 - pos
+        R = 2 * n
+        off_diag = 1 - torch.eye(R, dtype=torch.float, device=dev)
+        pos_mask, neg_mask = pos.repeat(2, 2) * off_diag, neg.repeat(2, 2) * off_diag
+        P = torch.cat([proj_feat1, proj_feat2], dim=0)
+        sim = SgemmFn.apply(P, P, 1.0 / self._t)
+        norm_err = (sim.diagonal().detach() * self._t - 1).abs().max()
+        assert norm_err.item() < 1e-4, "features need to be normalized first"
+        sim_logits = sim - sim.max().detach()
+        sim_exp = torch.exp(sim_logits)
+        self.sim_exp, self.sim_logits, self.pos_mask, self.neg_mask = sim_exp, sim_logits, pos_mask, neg_mask
+        pos_count = pos_mask.sum(1)
+        denom = ((sim_exp * pos_mask).sum(1, keepdim=True) + (sim_exp * neg_mask).sum(1, keepdim=True))
+        llh = sim_logits - torch.log(denom + 1e-16)
+        with torch.no_grad():
+            l_ij = -llh
+            if self._weight_update == "hard":
+                w = (l_ij <= self._gamma).float()
+            else:
+                w = torch.clamp(1 - l_ij / self._gamma, min=0)
+            sp_mask = torch.max(w, 1 - pos_mask)
+        self.sp_mask = sp_mask
+        self.downgrade_ratio = torch.masked_select(sp_mask, pos_mask.bool()).mean().item()
+        loss = -(((llh * sp_mask) * pos_mask).sum(1) / pos_count).mean()
+        if self._correct_grad and self.downgrade_ratio > 0:
+            loss = loss / self.downgrade_ratio
+        if torch.isnan(loss):
+            raise RuntimeError(loss)
+        return loss

@@ -139,14 +139,32 @@ class _ClusterBase(nn.Module):
                  normalize: bool, hidden_dim: int = 64):
         super().__init__()
         assert head_type in ("mlp", "linear"), head_type
-        if head_type != "linear" or normalize:
-            raise NotImplementedError("the HIP cluster heads implement head_type='linear', normalize=False "
-                                      "(what DiscreteMITrainHook creates, semi_seg/hooks/discretemi.py:43-46)")
         self._input_dim, self._output_dim = input_dim, num_clusters
         self._head_type, self._normalize = head_type, normalize
         self._num_clusters, self._num_subheads, self._T = num_clusters, num_subheads, T
         self._headers = nn.ModuleList([_sub_header(self._dense, head_type, input_dim, hidden_dim, num_clusters,
                                                    normalize, T) for _ in range(num_subheads)])
+
+    def _normalise_groups(self, logits: Tensor) -> Tensor:
+        """F.normalize(., dim=1) inside every sub-head's k outputs of stacked [M, S*k] logits"""
+        M = logits.shape[0]
+        return L2NormFn.apply(logits.reshape(M * self._num_subheads, self._num_clusters)).view(M, -1)
+
+    def _logits(self, rows: Tensor, lin1: int, lin2: int) -> Tensor:
+        """stacked [M, S*k] logits of all sub-heads on f32 rows [M, C] (pooled features, or pixels).
+        linear: one stacked Linear; mlp: Linear(C, hidden) -> LeakyReLU(0.01) (stacked over the sub-heads, one
+        launch) -> each sub-head's own Linear(hidden, k); then the optional per-sub-head L2 normalisation"""
+        if self._head_type == "linear":
+            w, b = self._stacked(lin1)
+            out = LinearFn.apply(rows, w, b, 0, 0.0)
+        else:
+            w1 = torch.cat([h[lin1].weight.reshape(h[lin1].weight.shape[0], -1) for h in self._headers], dim=0)
+            b1 = torch.cat([h[lin1].bias for h in self._headers], dim=0)
+            hid = LinearFn.apply(rows, w1, b1, 1, 0.01)
+            H = hid.shape[1] // self._num_subheads
+            out = torch.cat([LinearFn.apply(hid[:, i * H:(i + 1) * H], h[lin2].weight.reshape(self._num_clusters, -1),
+                                            h[lin2].bias, 0, 0.0) for i, h in enumerate(self._headers)], dim=1)
+        return self._normalise_groups(out) if self._normalize else out
 
     def _stacked(self, idx: int):
         """all sub-heads as ONE [S*k, C] weight so the 1x1 conv / linear runs once"""
@@ -165,8 +183,8 @@ class ClusterHead(_ClusterBase):
 
     def forward(self, features: Tensor) -> List[Tensor]:
         ops.require_gpu(features)
-        w, b = self._stacked(2)
-        logits = LinearFn.apply(AvgPoolFn.apply(features), w, b, 0, 0.0)
+        pooled = AvgPoolFn.apply(features)
+        logits = self._logits(pooled, lin1=2, lin2=4)
         probs = GroupSoftmaxFn.apply(logits, self._num_subheads, self._num_clusters, float(self._T))
         return list(probs.unbind(0))
 
@@ -184,8 +202,14 @@ class DenseClusterHead(_ClusterBase):
     def forward(self, features: Tensor) -> List[Tensor]:
         ops.require_gpu(features)
         n, _, h, w_ = features.shape
-        w, b = self._stacked(0)
-        logits = HeadFn.apply(features, w.view(w.shape[0], w.shape[1], 1, 1), b)  # [n, S*k, h, w] NHWC f32
-        flat = logits.permute(0, 2, 3, 1).reshape(n * h * w_, -1)
+        if self._head_type == "linear":
+            w, b = self._stacked(0)
+            logits = HeadFn.apply(features, w.view(w.shape[0], w.shape[1], 1, 1), b)  # [n, S*k, h, w] NHWC f32
+            flat = logits.permute(0, 2, 3, 1).reshape(n * h * w_, -1)
+            if self._normalize:
+                flat = self._normalise_groups(flat)
+        else:  # per sub-head Conv1x1(C, hidden) -> LeakyReLU -> Conv1x1(hidden, k): pixels as rows of two linears
+            rows = ops.to_nhwc(features).permute(0, 2, 3, 1).reshape(n * h * w_, -1).float()
+            flat = self._logits(rows, lin1=0, lin2=2)
         probs = GroupSoftmaxFn.apply(flat, self._num_subheads, self._num_clusters, float(self._T))
         return [p.view(n, h, w_, self._num_clusters).permute(0, 3, 1, 2) for p in probs.unbind(0)]

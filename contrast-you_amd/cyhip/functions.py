@@ -647,6 +647,49 @@ class IIDFn(torch.autograd.Function):
         return d1, d2, None, None, None, None, None
 
 
+class JointFn(torch.autograd.Function):
+    """the k x k joint of two probability maps, (1/npix) sum_p x1[p,:] x2[p,:]^T, as its own autograd node
+    (compute_joint_2D_with_padding_zeros, contrastyou/losses/discreteMI.py:246-261, before symmetrisation):
+    the pixel contraction on the HIP joint kernels, whatever follows on the k x k result in plain autograd.
+    x1, x2: f32 [N,H,W,k] contiguous."""
+
+    @staticmethod
+    def forward(ctx, x1: Tensor, x2: Tensor):
+        ops.require_gpu(x1, x2)
+        N, H, W, k = x1.shape
+        ctx.save_for_backward(x1, x2)
+        return ops.joint_fwd(x1, x2, N, H, W, k, 0, True).view(k, k)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x1, x2 = ctx.saved_tensors
+        N, H, W, k = x1.shape
+        one = torch.ones(1, device=g.device, dtype=torch.float32)
+        d1, d2 = ops.joint_bwd(x1, x2, g.float().contiguous().view(1, k, k), one, N, H, W, k, 0, True,
+                               ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return d1, d2
+
+
+class SgemmFn(torch.autograd.Function):
+    """alpha * A @ B^T on the exact f32 MFMA kernel, differentiable in both operands"""
+
+    @staticmethod
+    def forward(ctx, A: Tensor, B: Tensor, alpha: float):
+        ops.require_gpu(A, B)
+        A, B = A.float().contiguous(), B.float().contiguous()
+        ctx.save_for_backward(A, B)
+        ctx.alpha = alpha
+        return ops.sgemm(A, B, alpha, True)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        A, B = ctx.saved_tensors
+        g = g.float().contiguous()
+        dA = ops.sgemm(g, B, ctx.alpha, False) if ctx.needs_input_grad[0] else None
+        dB = ops.sgemm(g.t().contiguous(), A, ctx.alpha, False) if ctx.needs_input_grad[1] else None
+        return dA, dB, None
+
+
 class GNSiLUFn(torch.autograd.Function):
     """GroupNorm(G, C)(y + bias) -> SiLU on a raw (bias-free) conv output (arch/unet2.py:208-224)"""
 

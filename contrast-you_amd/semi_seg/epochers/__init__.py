@@ -1,3 +1,4 @@
-from .epocher import EpocherBase, EvalEpocher, FineTuneEpocher, SemiSupervisedEpocher  # noqa: F401
+from .epocher import (EpocherBase, EvalEpocher, FineTuneEpocher, InferenceEpocher,  # noqa: F401
+                      SemiSupervisedEpocher)
 from .pretrain import (PretrainDecoderEpocher, PretrainDecoderEpocherInference,  # noqa: F401
                        PretrainEncoderEpocher)

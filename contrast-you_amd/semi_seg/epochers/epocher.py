@@ -332,3 +332,44 @@ class EvalEpocher(EpocherBase):
             loss = _sup_loss(self._sup_criterion, logits, eval_target, self.num_classes)
         self.meters["loss"].add(loss.detach())
         self.meters["dice"].add_logits(logits, eval_target, group_name=eval_group)
+
+
+class InferenceEpocher(EvalEpocher):
+    """`InferenceEpocher` (semi_seg/epochers/epocher.py:174-204): the evaluation epoch of `Trainer.inference`,
+    with an optional prediction saver.  The reference's saver writes PNGs through its dataset tooling and its
+    extra "ASD" surface meter needs the un-vendored `medpy`; here the predictions (class-index maps) are written
+    as one `.npy` per input file under `<save_dir>/predictions/` and the Dice / loss meters are the ones of
+    `EvalEpocher` (the surface meter is out of scope)."""
+    meter_focus = "infer"
+
+    def __init__(self, *, model: nn.Module, loader, sup_criterion, cur_epoch=0, device="cpu", scaler,
+                 accumulate_iter: int, enable_prediction_saver: bool = True, save_dir=None) -> None:
+        super().__init__(model=model, loader=loader, sup_criterion=sup_criterion, cur_epoch=cur_epoch, device=device,
+                         scaler=scaler, accumulate_iter=accumulate_iter)
+        self.enable_prediction_saver = enable_prediction_saver
+        self._save_dir = save_dir
+
+    def _prediction_dir(self):
+        base = self._save_dir
+        if base is None and getattr(self, "trainer", None) is not None:
+            base = self.trainer.absolute_save_dir
+        if base is None:
+            return None
+        import os
+        out = os.path.join(str(base), "predictions")
+        os.makedirs(out, exist_ok=True)
+        return out
+
+    def _batch_update(self, *, eval_img, eval_target, eval_group, file_names):
+        with self.autocast:
+            logits = self._model(eval_img)
+            loss = _sup_loss(self._sup_criterion, logits, eval_target, self.num_classes)
+        self.meters["loss"].add(loss.detach())
+        self.meters["dice"].add_logits(logits, eval_target, group_name=eval_group)
+        out_dir = self._prediction_dir() if self.enable_prediction_saver else None
+        if out_dir is not None:
+            import os
+            import numpy as np
+            pred = logits.argmax(1).to(torch.uint8).cpu().numpy()
+            for name, p in zip(file_names, pred):
+                np.save(os.path.join(out_dir, f"{os.path.basename(str(name))}.npy"), p)

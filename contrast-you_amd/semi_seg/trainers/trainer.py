@@ -11,7 +11,8 @@ from typing import Any, Dict, Type
 from torch import nn
 
 from contrastyou.trainer.base import Trainer
-from semi_seg.epochers.epocher import EpocherBase, EvalEpocher, FineTuneEpocher, SemiSupervisedEpocher
+from semi_seg.epochers.epocher import (EpocherBase, EvalEpocher, FineTuneEpocher, InferenceEpocher,
+                                       SemiSupervisedEpocher)
 from semi_seg.hooks import MeanTeacherTrainerHook
 
 
@@ -53,15 +54,22 @@ class SemiTrainer(Trainer):
         return epocher
 
     def inference(self, checkpoint_path: str = None, checkpoint_name: str = "best.pth", save_dir: str = None,
-                  **kwargs):
+                  enable_prediction_save=False, **kwargs):
         """load `checkpoint_name`, evaluate the test loader, write inference_result.json
         (trainer.py:71-113; per-scan re-batching of the loader is the data layer's job)"""
         checkpoint_path = checkpoint_path or self.absolute_save_dir
         if not os.path.isabs(checkpoint_path):
             raise ValueError(f"`checkpoint_path` must be an absolute path, given {checkpoint_path}")
         self.resume_from_path(str(checkpoint_path), name=checkpoint_name)
-        metrics, score = self.eval_epoch(model=self._model, loader=self._test_loader)
         save_dir = save_dir or self.absolute_save_dir
+        # (trainer.py:107-123 `_inference`: an InferenceEpocher over the test loader)
+        epocher = InferenceEpocher(model=self._model, loader=self._test_loader, sup_criterion=self._criterion,
+                                   cur_epoch=self._cur_epoch, device=self._device, scaler=self.scaler,
+                                   accumulate_iter=self._accumulate_iter,
+                                   enable_prediction_saver=enable_prediction_save, save_dir=save_dir)
+        epocher.init(trainer=self)
+        epocher.run()
+        metrics, score = epocher.get_metric(), epocher.get_score()
         Path(save_dir).mkdir(exist_ok=True, parents=True)
         with open(os.path.join(save_dir, "inference_result.json"), "w") as f:
             json.dump(metrics, f, indent=4)

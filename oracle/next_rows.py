@@ -191,3 +191,70 @@ def _cosine_chain(lr: float, t: int, t_max: int, eta_min: float, base: float) ->
     if (t - 1 - t_max) % (2 * t_max) == 0:
         return lr + (base - eta_min) * (1 - math.cos(math.pi / t_max)) / 2
     return (1 + math.cos(math.pi * t / t_max)) / (1 + math.cos(math.pi * (t - 1) / t_max)) * (lr - eta_min) + eta_min
+
+
+# ---------------------------------------------------------------- round 2: f2 / f4 leftovers
+def cluster_head_general(sds: Sequence[Dict[str, Tensor]], feat: Tensor, *, dense: bool, head_type: str,
+                         normalize: bool, T: float = 1.0) -> List[Tensor]:
+    """projectors/heads.py:44-78 `init_sub_header` / `init_dense_sub_header` in all four variants:
+    [pool ->] Linear/Conv1x1 [-> LeakyReLU(0.01) -> Linear/Conv1x1] [-> F.normalize(dim=1)] -> softmax(./T).
+    `sds[i]` is sub-head i's state dict with the Sequential's own indices as keys."""
+    outs = []
+    for sd in sds:
+        if dense:
+            i0, i1 = ("0", "2")
+            x = F.conv2d(feat, sd[f"{i0}.weight"], sd[f"{i0}.bias"])
+            if head_type == "mlp":
+                x = F.conv2d(F.leaky_relu(x, 0.01), sd[f"{i1}.weight"], sd[f"{i1}.bias"])
+        else:
+            i0, i1 = ("2", "4")
+            x = F.linear(feat.mean(dim=(2, 3)), sd[f"{i0}.weight"], sd[f"{i0}.bias"])
+            if head_type == "mlp":
+                x = F.linear(F.leaky_relu(x, 0.01), sd[f"{i1}.weight"], sd[f"{i1}.bias"])
+        if normalize:
+            x = F.normalize(x, p=2, dim=1)
+        outs.append(F.softmax(x / T, dim=1))
+    return outs
+
+
+def redundancy_criterion(x_out: Tensor, x_tf_out: Tensor, *, alpha: float, lamda: float = 1.0, eps: float = 1e-5,
+                         symmetric: bool = True) -> Tensor:
+    """losses/redundancy_reduction.py:21-33 on the joint of losses/discreteMI.py:246-261"""
+    k = x_out.shape[1]
+    a = x_out.swapaxes(0, 1).reshape(k, -1)
+    b = x_tf_out.swapaxes(0, 1).reshape(k, -1)
+    n = a.shape[1]
+    p = (a / math.sqrt(n)) @ (b.t() / math.sqrt(n))
+    if symmetric:
+        p = (p + p.t()) / 2.0
+    target = torch.eye(k, dtype=p.dtype) / k * alpha + p * (1 - alpha)
+    p_i = p.sum(dim=1).view(k, 1).expand(k, k)
+    p_j = p.sum(dim=0).view(1, k).expand(k, k)
+    constrained = (-p * (-lamda * torch.log(p_j + eps) - lamda * torch.log(p_i + eps))).sum()
+    return -(target * (p + eps).log()).sum() + constrained
+
+
+def self_paced_supcon(z1: Tensor, z2: Tensor, target: Sequence[int], *, gamma: float, weight_update: str = "hard",
+                      correct_grad: bool = False, t: float = 0.07):
+    """losses/contrastive.py:103-212: SupConLoss1 with the positives weighted by a no-grad self-paced mask;
+    returns (loss, downgrade ratio)"""
+    n = z1.shape[0]
+    lab = torch.as_tensor(list(target))
+    pos = torch.eq(lab[:, None], lab[None, :]).to(z1.dtype)
+    off = 1 - torch.eye(2 * n, dtype=z1.dtype)
+    pos_mask, neg_mask = pos.repeat(2, 2) * off, (1 - pos).repeat(2, 2) * off
+    P = torch.cat([z1, z2], 0)
+    sim = P @ P.t() / t
+    logits = sim - sim.max().detach()
+    e = torch.exp(logits)
+    denom = (e * pos_mask).sum(1, keepdim=True) + (e * neg_mask).sum(1, keepdim=True)
+    llh = logits - torch.log(denom + 1e-16)
+    with torch.no_grad():
+        l = -llh
+        w = (l <= gamma).to(z1.dtype) if weight_update == "hard" else torch.clamp(1 - l / gamma, min=0)
+        sp = torch.max(w, 1 - pos_mask)
+    ratio = torch.masked_select(sp, pos_mask.bool()).mean().item()
+    loss = -(((llh * sp) * pos_mask).sum(1) / pos_mask.sum(1)).mean()
+    if correct_grad and ratio > 0:
+        loss = loss / ratio
+    return loss, ratio

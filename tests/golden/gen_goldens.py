@@ -164,8 +164,99 @@ def gen_next_rows(scratch):
     np.savez_compressed(OUT / "next_rows.npz", **out)
 
 
+def gen_round2(scratch):
+    """rows finished in round 2: cluster heads with head_type="mlp" / normalize=True, RedundancyCriterion,
+    SelfPacedSupConLoss, UNet2 -> round2.npz (inputs, the reference modules' own random state dicts, outputs,
+    gradients)"""
+    import types
+
+    from contrastyou.losses.kl import Entropy
+    from contrastyou.projectors.heads import ClusterHead, DenseClusterHead
+    midl = types.ModuleType("semi_seg.hooks.midl")
+    midl.entropy_criterion = Entropy(reduction="none", eps=1e-8)
+    hooks_pkg = types.ModuleType("semi_seg.hooks")
+    hooks_pkg.midl = midl
+    hooks_pkg.__path__ = []
+    sys.modules.setdefault("semi_seg.hooks", hooks_pkg)
+    sys.modules.setdefault("semi_seg.hooks.midl", midl)
+    from contrastyou.arch.unet2 import UNet2
+    from contrastyou.losses.contrastive import SelfPacedSupConLoss, SupConLoss1
+    from contrastyou.losses.redundancy_reduction import RedundancyCriterion
+
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    torch.manual_seed(123)
+    for dense, cls, tag in ((False, ClusterHead, "ch"), (True, DenseClusterHead, "dch")):
+        for head_type, normalize in (("mlp", False), ("mlp", True), ("linear", True)):
+            t = f"{tag}_{head_type}_{int(normalize)}"
+            kw = dict(hidden_dim=24) if dense else {}
+            head = cls(input_dim=16, num_clusters=6, num_subheads=3, head_type=head_type, T=1, normalize=normalize, **kw)
+            for k, v in head.state_dict().items():
+                out[f"{t}_sd_{k}"] = npy(v)
+            x = torch.randn(4, 16, 8, 8, generator=g).requires_grad_(True)
+            probs = head(x)
+            sum((p * torch.linspace(-1, 1, p.numel()).view_as(p)).sum() for p in probs).backward()
+            out[f"{t}_feat"], out[f"{t}_dfeat"] = npy(x), npy(x.grad)
+            for i, pr in enumerate(probs):
+                out[f"{t}_prob{i}"] = npy(pr)
+            for n, p in head.named_parameters():
+                out[f"{t}_grad_{n}"] = npy(p.grad)
+
+    xa = torch.randn(2, 5, 9, 11, generator=g).softmax(1)
+    xb = torch.randn(2, 5, 9, 11, generator=g).softmax(1)
+    out["rr_a"], out["rr_b"] = npy(xa), npy(xb)
+    for sym in (False, True):
+        for alpha in (0.0, 0.4, 1.0):
+            pa, pb = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+            l = RedundancyCriterion(symmetric=sym, lamda=1.3, alpha=alpha)(pa, pb)
+            l.backward()
+            t = f"rr_s{int(sym)}_a{int(alpha * 10)}"
+            out[f"{t}_loss"], out[f"{t}_da"], out[f"{t}_db"] = npy(l), npy(pa.grad), npy(pb.grad)
+
+    n = 10
+    z1 = torch.nn.functional.normalize(torch.randn(n, 32, generator=g), dim=1)
+    z2 = torch.nn.functional.normalize(z1 + 0.4 * torch.randn(n, 32, generator=g), dim=1)
+    out["sp_z1"], out["sp_z2"] = npy(z1), npy(z2)
+    target = [0, 1, 2, 0, 1, 2, 0, 1, 2, 0]
+    out["sp_target"] = np.array(target)
+    a, b = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+    ref = SupConLoss1()(a, b, target=target)
+    out["sp_supcon_loss"] = npy(ref)
+    for mode in ("hard", "soft"):
+        for gamma in (1e10, 3.0, 1.5):
+            for cg in (False, True):
+                a, b = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+                crit = SelfPacedSupConLoss(temperature=0.07, weight_update=mode, correct_grad=cg)
+                crit.set_gamma(gamma)
+                l = crit(a, b, target=target)
+                l.backward()
+                t = f"sp_{mode}_g{gamma:g}_c{int(cg)}"
+                out[f"{t}_loss"], out[f"{t}_dz1"], out[f"{t}_dz2"] = npy(l), npy(a.grad), npy(b.grad)
+                out[f"{t}_ratio"] = np.array(crit.downgrade_ratio)
+
+    torch.manual_seed(321)
+    net = UNet2(input_dim=1, num_classes=4, dim=8)
+    for k, v in net.state_dict().items():
+        out[f"u2_sd_{k}"] = npy(v)
+    x = torch.rand(2, 1, 32, 32, generator=g)
+    y = net(x)
+    (y * torch.linspace(-1, 1, y.numel()).view_as(y)).sum().backward()
+    out["u2_x"], out["u2_y"] = npy(x), npy(y)
+    for name in ("init_conv.weight", "downs.0.0.block1.proj.weight", "downs.1.1.block2.norm.weight",
+                 "downs.2.2.fn.fn.to_qkv.weight", "mid_attn.fn.fn.to_out.weight", "ups.0.0.block1.proj.weight",
+                 "ups.2.3.weight", "final_conv.1.bias"):
+        out[f"u2_grad_{name}"] = npy(dict(net.named_parameters())[name].grad)
+    np.savez_compressed(OUT / "round2.npz", **out)
+
+
 def main():
     sys.path.insert(0, str(REPO))
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "round2":
+        scratch = setup_reference()
+        gen_round2(scratch)
+        shutil.rmtree(scratch, ignore_errors=True)
+        print("wrote round2.npz")
+        return
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "next":
         scratch = setup_reference()
         gen_next_rows(scratch)
@@ -277,6 +368,7 @@ def main():
     np.savez_compressed(OUT / "heads_losses.npz", **out)
 
     gen_next_rows(scratch)
+    gen_round2(scratch)
     shutil.rmtree(scratch, ignore_errors=True)
     print("wrote", sorted(p.name for p in OUT.glob("*.npz")))
 

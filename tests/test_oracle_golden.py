@@ -170,3 +170,50 @@ def test_region_points_follow_numpy_choice_stream():
     np.random.set_state(state)
     assert pts == exp
     assert all(len({p[0] for p in im}) == 5 and len({p[1] for p in im}) == 5 for im in pts)
+
+
+# ---------------------------------------------------------------- round-2 rows (tests/golden/round2.npz)
+def _sub_sds(g, tag, n_sub):
+    """per-sub-head state dicts (keys = the reference Sequential's own indices) from the saved reference state"""
+    pre = f"{tag}_sd__headers."
+    sds = [dict() for _ in range(n_sub)]
+    for k in g.files:
+        if k.startswith(pre):
+            i, rest = k[len(pre):].split(".", 1)
+            sds[int(i)][rest] = torch.from_numpy(g[k])
+    return sds
+
+
+def test_round2_cluster_heads_redundancy_selfpaced(golden_dir):
+    from oracle import next_rows as onr
+    g = np.load(golden_dir / "round2.npz")
+    for dense, tag0 in ((False, "ch"), (True, "dch")):
+        for head_type, normalize in (("mlp", False), ("mlp", True), ("linear", True)):
+            tag = f"{tag0}_{head_type}_{int(normalize)}"
+            probs = onr.cluster_head_general(_sub_sds(g, tag, 3), torch.from_numpy(g[f"{tag}_feat"]), dense=dense,
+                                             head_type=head_type, normalize=normalize)
+            for i, p in enumerate(probs):
+                assert torch.allclose(p, torch.from_numpy(g[f"{tag}_prob{i}"]), rtol=1e-5, atol=1e-6), (tag, i)
+    xa, xb = torch.from_numpy(g["rr_a"]), torch.from_numpy(g["rr_b"])
+    for sym in (False, True):
+        for alpha in (0.0, 0.4, 1.0):
+            t = f"rr_s{int(sym)}_a{int(alpha * 10)}"
+            pa, pb = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+            l = onr.redundancy_criterion(pa, pb, alpha=alpha, lamda=1.3, symmetric=sym)
+            l.backward()
+            assert abs(l.item() - float(g[f"{t}_loss"])) < 1e-5 * abs(float(g[f"{t}_loss"])), t
+            assert torch.allclose(pa.grad, torch.from_numpy(g[f"{t}_da"]), rtol=1e-4, atol=1e-7), t
+    z1, z2 = torch.from_numpy(g["sp_z1"]), torch.from_numpy(g["sp_z2"])
+    target = g["sp_target"].tolist()
+    for mode in ("hard", "soft"):
+        for gamma in (1e10, 3.0, 1.5):
+            for cg in (False, True):
+                t = f"sp_{mode}_g{gamma:g}_c{int(cg)}"
+                a, b = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+                l, ratio = onr.self_paced_supcon(a, b, target, gamma=gamma, weight_update=mode, correct_grad=cg)
+                l.backward()
+                assert abs(l.item() - float(g[f"{t}_loss"])) < 1e-5 * abs(float(g[f"{t}_loss"])), t
+                assert abs(ratio - float(g[f"{t}_ratio"])) < 1e-6, t
+                assert torch.allclose(a.grad, torch.from_numpy(g[f"{t}_dz1"]), rtol=1e-4, atol=1e-6), t
+    # the one numeric identity the reference's own files hold (contrastive.py:241-248): gamma -> inf == SupConLoss1
+    assert abs(float(g["sp_soft_g1e+10_c0_loss"]) - float(g["sp_supcon_loss"])) < 1e-6
