@@ -149,8 +149,27 @@ class FusedRAdam(torch.optim.Optimizer):
         for f in self._flat:
             f.zero_grad()
 
-    def all_reduce_grads(self):
-        """mean over data-parallel ranks; one collective per parameter group"""
+    BUCKET_ELEMS = 2 << 20  # ~8 MB of f32 gradients per collective
+
+    def _buckets(self, f: "FlatParams"):
+        """parameter-aligned slices [a, b) of a flat buffer, in REVERSE parameter order (the order the backward
+        pass completes gradients in: 1x1 head and decoder first, Conv1 last), ~BUCKET_ELEMS each"""
+        cuts, hi = [], f.numel
+        j = len(f.params)
+        while j > 0:
+            i = j
+            while i > 0 and f.offsets[j] - f.offsets[i - 1] <= self.BUCKET_ELEMS:
+                i -= 1
+            if i == j:  # a single parameter larger than a bucket
+                i = j - 1
+            cuts.append((f.offsets[i], f.offsets[j], i, j))
+            j = i
+        return cuts
+
+    def all_reduce_grads(self, wait: bool = True):
+        """gradient mean over the data-parallel ranks: bucketed, asynchronous collectives over xGMI (RCCL) in the
+        order the backward pass finishes the gradients; `wait=False` leaves the handles for `step()`, which
+        consumes bucket k (RAdam on its parameters) while bucket k+1 is still on the wire"""
         if not self._dp or getattr(self, "_reduced", False):
             return
         if self._needs_flat():
@@ -159,12 +178,28 @@ class FusedRAdam(torch.optim.Optimizer):
             ops.join_side_streams(torch.cuda.current_stream())
         self._reduced = True
         world = dist.get_world_size(self._pg)
-        for f in self._flat:
-            if f.grad.is_cuda:
-                dist.all_reduce(f.grad, op=dist.ReduceOp.AVG, group=self._pg)
-            else:
-                dist.all_reduce(f.grad, op=dist.ReduceOp.SUM, group=self._pg)
-                f.grad.div_(world)
+        avg = dist.get_backend(self._pg) == "nccl"  # (gloo has no AVG: sum, then scale)
+        self._inflight = []
+        for gi, f in enumerate(self._flat):
+            for a, b, i, j in self._buckets(f):
+                view = f.grad[a:b]
+                h = dist.all_reduce(view, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self._pg,
+                                    async_op=True)
+                self._inflight.append((gi, i, j, view, h, None if avg else world))
+        if wait:
+            self._wait_inflight()
+
+    def _wait_inflight(self, upto=None):
+        """wait for (and finish) the collectives in flight; `upto` = (group, first param) stops after that bucket"""
+        pend = getattr(self, "_inflight", None) or []
+        while pend:
+            gi, i, j, view, h, div = pend.pop(0)
+            h.wait()
+            if div:
+                view.div_(div)
+            if upto is not None and (gi, i) == upto:
+                break
+        self._inflight = pend
 
     def state_dict(self):
         """{"param_groups": [...], "flat": {group: {step, steps, exp_avg, exp_avg_sq}}}"""
@@ -203,19 +238,28 @@ class FusedRAdam(torch.optim.Optimizer):
             self._ensure_flat()
         if torch.cuda.is_available():  # weight gradients are produced on a side stream
             ops.join_side_streams(torch.cuda.current_stream())
-        self.all_reduce_grads()
+        self.all_reduce_grads(wait=False)
         self._reduced = False
-        for i, g in enumerate(self.param_groups):
-            f, st = self._flat[i], self._flat_state[i]
-            st["step"] += 1
-            steps, touched = st["steps"], f.touched()
-            j, n = 0, len(steps)
-            while j < n:  # runs of consecutive updated parameters that share a step count
+        # buckets in the order their collectives were launched (reverse parameter order); without data parallelism
+        # one "bucket" per group.  Runs of consecutive updated parameters that share a step count -> one launch.
+        plan = []
+        for gi, f in enumerate(self._flat):
+            plan += [(gi, i, j) for _, _, i, j in self._buckets(f)] if self._dp else [(gi, 0, len(f.params))]
+        for gi in range(len(self.param_groups)):
+            self._flat_state[gi]["step"] += 1
+        touched_all = [f.touched() for f in self._flat]
+        for gi, lo, hi in plan:
+            if self._dp:
+                self._wait_inflight(upto=(gi, lo))
+            g, f, st = self.param_groups[gi], self._flat[gi], self._flat_state[gi]
+            steps, touched = st["steps"], touched_all[gi]
+            j = lo
+            while j < hi:
                 if not touched[j]:
                     j += 1
                     continue
                 e = j
-                while e + 1 < n and touched[e + 1] and steps[e + 1] == steps[j]:
+                while e + 1 < hi and touched[e + 1] and steps[e + 1] == steps[j]:
                     e += 1
                 a, b = f.offsets[j], f.offsets[e + 1]
                 ops.radam_step(f.data[a:b], f.grad[a:b], st["exp_avg"][a:b], st["exp_avg_sq"][a:b], g["lr"],
@@ -223,5 +267,6 @@ class FusedRAdam(torch.optim.Optimizer):
                 for q in range(j, e + 1):
                     steps[q] += 1
                 j = e + 1
+        self._wait_inflight()
         bump_weights_epoch()
         return loss
