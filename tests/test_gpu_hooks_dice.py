@@ -162,6 +162,71 @@ def test_dice_of_trained_weights_matches_oracle():
     assert abs(d16 - ref) < 0.002, (d16, ref)
 
 
+def test_dice_after_training_bf16_within_the_oracles_seed_spread():
+    """BASELINE.json "Dice within +-0.002 of reference": a trained network's Dice depends on the initialisation
+    seed by far more than 0.002 (the spread is printed and recorded in DESIGN.md), so "train both, compare" is a
+    statement about distributions: over K = 5 seeds each, the mean DSC of the HIP bf16 path (and of the HIP f32
+    path) must lie within the oracle's own seed-to-seed spread -- no systematic Dice loss from bf16 training."""
+    from contrastyou.amp import BF16Scaler
+    from contrastyou.arch import UNet
+    from contrastyou.losses.kl import KL_div
+    from contrastyou.optim import RAdam
+    from oracle import losses as ol
+    from oracle import unet as ou
+    from semi_seg.epochers import EvalEpocher, FineTuneEpocher
+    C, K, steps = 4, 5, 120
+    g = torch.Generator().manual_seed(70)
+    batches = [blob_batch(8, 32, C, g) for _ in range(8)]
+    eval_batches = [blob_batch(8, 32, C, g) for _ in range(6)]
+    single = [{k: (v[0] if isinstance(v, list) else v) for k, v in b.items()} for b in eval_batches]
+
+    def oracle_run(seed):
+        sd = ou.clone_state_dict(ou.init_state_dict(1, C, 128, seed=seed), requires_grad=True)
+        params = [v for v in sd.values() if v.requires_grad]
+        opt = torch.optim.RAdam(params, lr=5e-3, weight_decay=1e-5)
+        for i in range(steps):
+            b = batches[i % 8]
+            opt.zero_grad()
+            ol.sup_loss(ou.unet_forward(sd, b["img"][0], training=True, momentum=0.1), b["gt"][0].squeeze(1)).backward()
+            opt.step()
+        preds, tgts, groups = [], [], []
+        with torch.no_grad():
+            for b in eval_batches:
+                preds.append(ou.unet_forward(sd, b["img"][0], training=False).argmax(1))
+                tgts.append(b["gt"][0].squeeze(1))
+                groups.append(b["scan_num"][0])
+        return ol.dice_summary(preds, tgts, groups, C, [1, 2, 3])["DSC_mean"]
+
+    def hip_run(seed, scaler_factory):
+        model = UNet(input_dim=1, num_classes=C, max_channel=128, momentum=0.1)
+        model.load_state_dict(ou.init_state_dict(1, C, 128, seed=seed))
+        model.to(DEV)
+        opt = RAdam([{"params": list(model.parameters())}], lr=5e-3, weight_decay=1e-5)
+        ep = FineTuneEpocher(model=model, optimizer=opt, labeled_loader=Loader([batches[i % 8] for i in range(steps)]),
+                             sup_criterion=KL_div(), num_batches=steps, device=DEV, scaler=scaler_factory(),
+                             accumulate_iter=1)
+        ep.init()
+        ep.run()
+        ev = EvalEpocher(model=model, loader=Loader(single), sup_criterion=KL_div(), device=DEV,
+                         scaler=scaler_factory(), accumulate_iter=1)
+        ev.init()
+        ev.run()
+        return ev.get_score()
+
+    seeds = [301 + i for i in range(K)]
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    d_or = torch.tensor([oracle_run(s) for s in seeds], dtype=torch.float64)
+    d_32 = torch.tensor([hip_run(s, lambda: torch.amp.GradScaler("cuda", enabled=False)) for s in seeds], dtype=torch.float64)
+    d_16 = torch.tensor([hip_run(s, BF16Scaler) for s in seeds], dtype=torch.float64)
+    print(f"DSC over {K} seeds: oracle {d_or.mean():.4f} +- {d_or.std():.4f} [{d_or.min():.4f}, {d_or.max():.4f}]  "
+          f"hip-f32 {d_32.mean():.4f} +- {d_32.std():.4f}  hip-bf16 {d_16.mean():.4f} +- {d_16.std():.4f}")
+    assert d_or.mean() > 0.6, "the task must be learned for the comparison to mean anything"
+    spread = max(d_or.std().item(), 0.002)
+    assert abs(d_32.mean().item() - d_or.mean().item()) < 2 * spread, (d_32.tolist(), d_or.tolist())
+    assert abs(d_16.mean().item() - d_or.mean().item()) < 2 * spread, (d_16.tolist(), d_or.tolist())
+    assert d_or.min().item() - 2 * spread <= d_16.mean().item() <= d_or.max().item() + 2 * spread
+
+
 def test_mean_teacher_hard_clip_and_update_bn_follow_the_reference():
     """reference semi_seg/hooks/mt.py:162-166 (update_bn: every teacher BatchNorm runs in eval mode on the
     EMA'd running statistics and leaves them alone) and :190-192 (hard_clip: the teacher's arg-max one-hot
