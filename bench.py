@@ -35,6 +35,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_BPS = 8.0e12      # HBM3E peak (same table)
 
 
 class _Transforms:
@@ -173,17 +174,32 @@ def kernel_roofline(ctx, device, steps: int = 3):
     ach = fl / sec / 1e12
     # HBM bytes per launch of the same family from the two PMC passes (FETCH_SIZE, WRITE_SIZE) of this
     # command, summarised by tools/traffic_summary.py into profiles/ (a profiler cannot wrap itself)
-    traffic = None
-    tfile = REPO / "profiles" / "r01_traffic.json"
-    if tfile.exists():
-        traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
+    def latest(suffix):
+        files = sorted((REPO / "profiles").glob(f"r*_{suffix}.json"))
+        return json.load(open(files[-1])) if files else {}
+
+    traffic_all, mfma_all = latest("traffic"), latest("mfma")
+    traffic = traffic_all.get(dom, {}).get("hbm_bytes_per_launch")
+    avg_s = sec / cnt
     roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": round(fam_bytes.get(dom, 0.0) / cnt) if fam_bytes.get(dom) else None,
-            "launches_per_step": cnt // steps, "avg_launch_ms": round(sec / cnt * 1e3, 4)}
-    detail = {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / steps * 1e3, 3),
-                  "launches_per_step": v[2] // steps, "tflop_per_step": round(v[0] / steps / 1e12, 4)}
-              for k, v in fam.items()}
+            "launches_per_step": cnt // steps, "avg_launch_ms": round(avg_s * 1e3, 4),
+            # north_star: "rocprof HBM GB/s and MFMA-busy reported against MI355X peak" (PMC passes of the same
+            # command, profiles/rNN_traffic.json and rNN_mfma.json; durations from this run's HIP events)
+            "hbm_gbps": None if traffic is None else round(traffic / avg_s / 1e9, 1),
+            "hbm_frac": None if traffic is None else round(traffic / avg_s / PEAK_HBM_BPS, 4),
+            "mfma_busy": mfma_all.get(dom, {}).get("mfma_busy")}
+    detail = {}
+    for k, v in fam.items():
+        d = {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / steps * 1e3, 3),
+             "launches_per_step": v[2] // steps, "tflop_per_step": round(v[0] / steps / 1e12, 4),
+             "algorithmic_bytes_per_launch": round(fam_bytes[k] / v[2]) if fam_bytes.get(k) else None,
+             "hbm_bytes_per_launch": traffic_all.get(k, {}).get("hbm_bytes_per_launch"),
+             "mfma_busy": mfma_all.get(k, {}).get("mfma_busy")}
+        if d["hbm_bytes_per_launch"]:
+            d["hbm_gbps"] = round(d["hbm_bytes_per_launch"] / (v[1] / v[2]) / 1e9, 1)
+        detail[k] = d
     return roof, detail
 
 

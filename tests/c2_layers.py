@@ -46,7 +46,7 @@ def conv_kernel_name(plan: dict, dtype_tag: str = "DF16b") -> str:
 
 def wgrad_kernel_name(plan: dict) -> str:
     base = "wgrad12_kernel" if plan["twelve"] else "wgrad_kernel"
-    return f"{base}<{plan['wco']}, {plan['wci']}, {plan['wk']}>"
+    return f"{base}<{plan['wco']}, {plan['wci']}, {plan['wk']}"  # (prefix: a trailing type argument may follow)
 
 
 def profiled_conv_kernels(path: Path):
@@ -58,9 +58,12 @@ def profiled_conv_kernels(path: Path):
         m = re.search(r"(conv3x3_(?:plane|igemm|pc)_kernelI\w+?)Ev", tok)
         if m:
             names.add(m.group(1))
-        m = re.match(r"(wgrad(?:12)?_kernel<[\d, ]+>)", tok)
+        m = re.match(r"(wgrad(?:12)?_kernel<)(?:[A-Za-z_]\w*, )?(\d+, \d+, \d+)", tok)
         if m:
-            names.add(m.group(1))
+            names.add(m.group(1) + m.group(2))
+        m = re.search(r"(wgrad(?:12)?_kernel)I(?:DF16[b_]|f)?Li(\d+)ELi(\d+)ELi(\d+)E", tok)  # mangled form
+        if m:
+            names.add(f"{m.group(1)}<{m.group(2)}, {m.group(3)}, {m.group(4)}")
     return names
 
 

@@ -24,6 +24,10 @@ echo "[profile] FETCH_SIZE pass done"
 ( export CY_GRAPH_STEP=0 CY_ASYNC_WGRAD=0 CY_TWO_STREAM=0
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/write.log 2>&1 )
 echo "[profile] WRITE_SIZE pass done"
+# 5. matrix-core busy cycles (north_star: "rocprof ... MFMA-busy reported against MI355X peak"), its own pass
+( export CY_GRAPH_STEP=0 CY_ASYNC_WGRAD=0 CY_TWO_STREAM=0
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/mfma.log 2>&1 )
+echo "[profile] MFMA-busy pass done"
 cd $ROOT
 python tools/prof_summary.py $OUT/single 60 > $OUT/${TAG}_bench_c2_kernel_stats_single_stream.txt
 python tools/prof_summary.py $OUT/overlap 60 > $OUT/${TAG}_bench_c2_kernel_stats_overlapped.txt
@@ -31,5 +35,7 @@ python tools/trace_overlap.py $OUT/overlap > $OUT/${TAG}_bench_c2_stream_overlap
 python tools/pmc_summary.py $OUT/fetch > $OUT/${TAG}_pmc_fetch_size.txt
 python tools/pmc_summary.py $OUT/write > $OUT/${TAG}_pmc_write_size.txt
 python tools/traffic_summary.py $OUT/fetch $OUT/write $OUT/${TAG}_traffic.json
+python tools/pmc_summary.py $OUT/mfma > $OUT/${TAG}_pmc_mfma.txt
+python tools/mfma_summary.py $OUT/mfma $OUT/${TAG}_mfma.json
 python tools/step_timeline.py > $OUT/${TAG}_step_timeline.txt 2>&1
 echo "[profile] summaries written to $OUT"
