@@ -958,6 +958,7 @@ static int pc_check(const cy_conv_desc* d) {
   if (d->in_dtype != CY_BF16) return CY_ERR_DTYPE;
   if (d->W % 14) return CY_ERR_SHAPE;
   if (d->mode1 == CY_SRC_POOL2 && d->C2) return CY_ERR_ARG;
+  if (d->prologue && d->C1 > 512) return CY_ERR_SHAPE;  // (prologue coefficients are LDS-resident: 512 channels)
   return CY_OK;
 }
 static PcPlan pc_plan_of(const cy_conv_desc* d) { return plan_pc(d->N, d->H, d->W, d->C1 + d->C2, d->Cout); }
@@ -1027,7 +1028,8 @@ int cy_conv3x3_pc_fwd(const cy_conv_desc* d, const void* src1, const void* src2,
   pa.inv_h = 1.0f / (float)d->H;
   pa.inv_ks = 1.0f / (float)p.ksplit, pa.inv_tiles = 1.0f / (float)p.tiles, pa.inv_tiles_w = 1.0f / (float)(d->W / 14);
   hipStream_t st = (hipStream_t)stream;
-  if (p.bn == 128) rc = launch_conv_pc<bf16, 128>(pa, p, st);
+  if (p.bn == 128 && p.ncw == 8) rc = launch_conv_pc<bf16, 128, 8>(pa, p, st);
+  else if (p.bn == 128) rc = launch_conv_pc<bf16, 128>(pa, p, st);
   else if (p.bn == 64) rc = launch_conv_pc<bf16, 64>(pa, p, st);
   else rc = launch_conv_pc<bf16, 32>(pa, p, st);
   if (rc != CY_OK || p.ksplit == 1) return rc;

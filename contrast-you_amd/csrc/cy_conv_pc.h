@@ -39,28 +39,39 @@ struct PcArgs {
   int debug;         // what-if timing switches (CY_PC_DEBUG): 2 no activation loads, 4 no stores, 8 no weight DMA
 };
 
-template <int BN> struct PcCfg {
+template <int BN, int NCW = 4> struct PcCfg {
+  static constexpr int NT = (NCW + 4) * 64;                             // consumer waves + four producer waves
   static constexpr int TH = 16, TW = 14, HP = 16;
   static constexpr int NPOS = (TH + 2) * HP;                            // 288 halo positions
   static constexpr int ZB = NPOS + 2;                                   // all-zero row
-  static constexpr int CPA = 8;                                         // planes per activation chunk (64 ch)
+  // activation chunk: 64 channels with four consumer waves; 32 channels with eight (BN = 128), which buys a
+  // THIRD weight slot: the LDS-DMA of a 36 KB stage needs ~2000 cycles to issue and ~1000 to land (in-kernel
+  // stamps) -- with two slots it must start and finish inside one stage interval and the consumers wait for it
+  static constexpr int KCA = NCW == 8 ? 32 : 64;
+  static constexpr int CPA = KCA / 8;                                   // planes per activation chunk
+  static constexpr int CPAL = CPA == 8 ? 3 : 2;                         // log2(CPA)
+  static constexpr int NBS = NCW == 8 ? 3 : 2;                          // weight slots
   static constexpr int SKEW = 16 / CPA;
-  static constexpr int APL = ((ZB + 18 - SKEW + 15) / 16) * 16 + SKEW;  // 322 positions per plane
+  static constexpr int APL = ((ZB + 18 - SKEW + 15) / 16) * 16 + SKEW;  // positions per plane (322 / 308)
   static constexpr int APLB = APL * 16;
-  static constexpr int A_BYTES = CPA * APLB;                            // 41,216
-  static constexpr int KCB = 2048 / BN;                                 // channels per weight stage
+  static constexpr int A_BYTES = CPA * APLB;                            // 41,216 / 19,712
+  static constexpr int KCB = 2048 / BN < KCA ? 2048 / BN : KCA;         // channels per weight stage
   static constexpr int PPB = KCB / 8;                                   // planes per stage
   static constexpr int KSB = KCB / 16;                                  // MFMA k-steps per stage and tap
-  static constexpr int SPA = 64 / KCB;                                  // stages per activation chunk
+  static constexpr int SPA = KCA / KCB;                                 // stages per activation chunk
   static constexpr int BPLB = BN * 16;                                  // bytes per weight plane (one tap)
   static constexpr int TAPB = PPB * BPLB;                               // bytes per tap
   static constexpr int B_BYTES = 9 * TAPB;                              // 36,864
-  static constexpr int WGM = BN == 128 ? 2 : 4, WGN = BN == 128 ? 2 : 1;
+  static constexpr int NPW = B_BYTES / 1024 / 4;                        // LDS-DMA instructions per producer wave and stage
+  static constexpr int WGN = BN == 128 ? 2 : 1, WGM = NCW / WGN;
   static constexpr int M_REP = 8 / WGM, N_REP = BN / (32 * WGN);
-  static constexpr int NA = NPOS * CPA / 256;                           // 9 items per producer thread
+  static_assert(WGM * WGN == NCW && M_REP >= 1 && N_REP >= 1, "consumer wave grid");
+  static constexpr int RSTEP = 256 / (CPA * 16);                        // halo rows between a producer thread's items
+  static constexpr int NA = (TH + 2 + RSTEP - 1) / RSTEP;               // items per producer thread (9 / 5)
   static constexpr int DEPTH = BN == 128 ? 2 : 3;                        // fragment register sets of the consumers
-  static constexpr int SMEM = 2 * A_BYTES + 2 * B_BYTES;
-  static_assert(B_BYTES == 36864 && NPOS * CPA % 256 == 0, "stage geometry");
+  static constexpr int COEF_MAX = 512;                                  // channels with a BN+ReLU prologue
+  static constexpr int SMEM = 2 * A_BYTES + NBS * B_BYTES + 2 * COEF_MAX * 4;
+  static_assert(B_BYTES == 36864 && B_BYTES % 4096 == 0 && SMEM <= 160 * 1024, "stage geometry");
 };
 
 // workgroup barrier that leaves the `VM` youngest vector-memory operations of this wave in flight
@@ -140,9 +151,9 @@ static unsigned long long* g_pc_stamp_buf = nullptr;  // device buffer [8][128],
     if (a.stamps && blockIdx.x == 0 && lane == 0 && sl__ < 128) a.stamps[wave * 128 + sl__] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
-template <typename T, int BN>
-__global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
-  using C = PcCfg<BN>;
+template <typename T, int BN, int NCW>
+__global__ void __launch_bounds__((NCW + 4) * 64, NCW == 8 ? 3 : 2) conv3x3_pc_kernel(const PcArgs a) {
+  using C = PcCfg<BN, NCW>;
   using M = Mma<T>;
   constexpr int EPC = 8;
   constexpr int M_REP = C::M_REP, N_REP = C::N_REP, WGN = C::WGN;
@@ -160,24 +171,34 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
   const int Cin = a.c.C1 + a.c.C2;
   const PcUnits ul = pc_units(a, blockIdx.x, gridDim.x);
 
+  // BN+ReLU prologue coefficients of all input channels: LDS-resident (the producers' register budget is
+  // the consumers': two activation chunks in flight leave no room for 16 more floats per set)
+  float* const s_coef = reinterpret_cast<float*>(smem + 2 * C::A_BYTES + C::NBS * C::B_BYTES);
+  if (a.c.prologue) {
+    for (int c = tid; c < a.c.C1 && c < C::COEF_MAX; c += C::NT) {
+      s_coef[c] = a.c.scale[c];
+      s_coef[C::COEF_MAX + c] = a.c.shift[c];
+    }
+  }
   // zero rows of both activation buffers (never overwritten: halo positions end at index NPOS)
-  for (int idx = tid; idx < 2 * C::CPA * 18; idx += 512) {
+  for (int idx = tid; idx < 2 * C::CPA * 18; idx += C::NT) {
     const int b = idx / (C::CPA * 18), rem = idx % (C::CPA * 18);
     st16(sA0 + b * C::A_BYTES + (rem / 18) * APLB + (C::ZB + rem % 18) * 16, u32x4{0u, 0u, 0u, 0u});
   }
 
-  if (wave >= 4) {
+  if (wave >= NCW) {
     // ======================================= PRODUCERS =======================================
     // They share each SIMD's issue port with one consumer wave that runs its MFMA bursts at priority 1;
     // at equal or lower priority their address / transform arithmetic gets the leftover slots only and a
     // chunk commit takes 4-8k cycles (in-kernel stamps).  They are memory-bound and mostly asleep: let
     // them win the port whenever they are awake.
     __builtin_amdgcn_s_setprio(3);
-    const int pt = tid - 256;
-    const int pw = wave - 4;
-    const int ch = pt & 7;           // plane (8 channels) of this thread's items
-    const int hc = (pt >> 3) & 15;   // halo column
-    const int hr0 = pt >> 7;         // halo rows hr0, hr0 + 2, ... (9 of 18)
+    const int pt = tid - NCW * 64;
+    const int pw = wave - NCW;
+    constexpr int RSTEP = C::RSTEP;
+    const int ch = pt & (C::CPA - 1);           // plane (8 channels) of this thread's items
+    const int hc = (pt >> C::CPAL) & 15;        // halo column
+    const int hr0 = pt >> (C::CPAL + 4);        // halo rows hr0, hr0 + RSTEP, ... (NA of them; rows >= 18 do not exist)
     const T* s1p = reinterpret_cast<const T*>(a.c.src1);
     const T* s2p = reinterpret_cast<const T*>(a.c.src2);
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.wpc);
@@ -212,7 +233,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
     // (set k feeds activation buffer k); what a set holds is described by its RegChunk
     struct RegChunk {
       u32x4 v[C::NA];
-      float sc[8], sh[8];  // BN+ReLU prologue coefficients of this thread's 8 channels
       unsigned aok;
       int unit, c0, R0, w0, len;  // len: stages the chunk covers
     };
@@ -227,20 +247,21 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
     };
     auto row_begin = [&](int R0) -> RowIt {
       RowIt it;
-      const int Rb = R0 + 1 + hr0;  // (= first row + 2 >= 1: the first row itself may be -1)
+      const int Rb = R0 - 1 + hr0 + RSTEP;  // (= first row + RSTEP >= 1: the first row itself may be -1)
       const int nb = pc_fdiv(Rb, a.inv_h);
-      it.R = Rb - 2;
+      it.R = Rb - RSTEP;
       it.n = nb;
-      it.hh = Rb - nb * a.c.H - 2;
+      it.hh = Rb - nb * a.c.H - RSTEP;
       if (it.hh < 0) it.hh += a.c.H, --it.n;
       return it;
     };
     auto row_next = [&](RowIt& it) {
-      it.R += 2;
-      it.hh += 2;
+      it.R += RSTEP;
+      it.hh += RSTEP;
       if (it.hh >= a.c.H) it.hh -= a.c.H, ++it.n;
     };
-    auto row_base = [&](const RowIt& it, bool second) -> int {
+    auto row_base = [&](const RowIt& it, int i, bool second) -> int {
+      if (hr0 + RSTEP * i >= TH + 2) return -1;  // (item beyond the halo tile)
       if (it.R < 0 || it.R >= a.c.NH) return -1;
       if (second || a.c.mode1 == CY_SRC_DIRECT) return it.R * a.c.W;
       if (a.c.mode1 == CY_SRC_POOL2) return (it.n * 2 * a.c.H + 2 * it.hh) * (2 * a.c.W);
@@ -271,20 +292,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
         RowIt rit = row_begin(rc.R0);
 #pragma unroll
         for (int i = 0; i < C::NA; ++i) {
-          const int rp = row_base(rit, in2);
+          const int rp = row_base(rit, i, in2);
           row_next(rit);
           const bool ok = wok && rp >= 0;
           rc.v[i] = ld16(base + (ok ? (size_t)(rp + (w >> wsh)) * ld : (size_t)0));
           rc.aok |= (ok ? 1u : 0u) << i;
         }
         issued = C::NA;
-        if (a.c.prologue && cvalid && !in2) {  // (scalar-cache loads: not counted by vmcnt)
-#pragma unroll
-          for (int j = 0; j < EPC; ++j) {
-            rc.sc[j] = a.c.scale[cabs + j];
-            rc.sh[j] = a.c.shift[cabs + j];
-          }
-        }
       }
       advance_chunk();
       return issued;
@@ -299,39 +313,40 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
         const size_t rowstep = (size_t)(2 * a.c.W) * a.c.ld1;
         RowIt rit = row_begin(rc.R0);
 #pragma unroll
-        for (int i0 = 0; i0 < C::NA; i0 += 3) {
-          u32x4 v[3][4];
-          bool ok[3];
+        for (int i = 0; i < C::NA; ++i) {  // (one item at a time: four loads in flight; the register budget)
+          const int rp = row_base(rit, i, false);
+          row_next(rit);
+          if (hr0 + RSTEP * i >= TH + 2) continue;
+          u32x4 o = {0u, 0u, 0u, 0u};
+          if (wok && rp >= 0) {
+            const T* p = s1p + (size_t)(rp + 2 * w) * a.c.ld1 + cabs;
+            const u32x4 v0 = ld16(p), v1 = ld16(p + a.c.ld1), v2 = ld16(p + rowstep), v3 = ld16(p + rowstep + a.c.ld1);
+            float f0[EPC], f1[EPC];
+            Chunk<T>::unpack(v0, f0);
+            Chunk<T>::unpack(v1, f1);
 #pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const int rp = row_base(rit, false);
-            row_next(rit);
-            ok[j] = wok && rp >= 0;
-            if (ok[j]) {
-              const T* p = s1p + (size_t)(rp + 2 * w) * a.c.ld1 + cabs;
-              v[j][0] = ld16(p), v[j][1] = ld16(p + a.c.ld1), v[j][2] = ld16(p + rowstep),
-              v[j][3] = ld16(p + rowstep + a.c.ld1);
-            }
+            for (int q = 0; q < EPC; ++q) f0[q] = fmaxf(f0[q], f1[q]);
+            Chunk<T>::unpack(v2, f1);
+#pragma unroll
+            for (int q = 0; q < EPC; ++q) f0[q] = fmaxf(f0[q], f1[q]);
+            Chunk<T>::unpack(v3, f1);
+#pragma unroll
+            for (int q = 0; q < EPC; ++q) f0[q] = fmaxf(f0[q], f1[q]);
+            o = Chunk<T>::pack(f0);
           }
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            u32x4 o = {0u, 0u, 0u, 0u};
-            if (ok[j]) {
-              float f0[EPC], f1[EPC], f2[EPC], f3[EPC];
-              Chunk<T>::unpack(v[j][0], f0);
-              Chunk<T>::unpack(v[j][1], f1);
-              Chunk<T>::unpack(v[j][2], f2);
-              Chunk<T>::unpack(v[j][3], f3);
-#pragma unroll
-              for (int q = 0; q < EPC; ++q) f0[q] = fmaxf(fmaxf(f0[q], f1[q]), fmaxf(f2[q], f3[q]));
-              o = Chunk<T>::pack(f0);
-            }
-            st16(dstp + (i0 + j) * 32 * 16, o);
-          }
+          st16(dstp + i * RSTEP * 16 * 16, o);
         }
         return;
       }
       const bool pro = a.c.prologue && cabs < a.c.C1;
+      float sc[EPC], sh[EPC];
+      if (pro) {
+        const f32x4* cs = reinterpret_cast<const f32x4*>(s_coef + cabs);
+        const f32x4* ch_ = reinterpret_cast<const f32x4*>(s_coef + C::COEF_MAX + cabs);
+        const f32x4 a0 = cs[0], a1 = cs[1], b0 = ch_[0], b1 = ch_[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sc[j] = a0[j], sc[4 + j] = a1[j], sh[j] = b0[j], sh[4 + j] = b1[j];
+      }
 #pragma unroll
       for (int i = 0; i < C::NA; ++i) {
         u32x4 v = ((rc.aok >> i) & 1u) ? rc.v[i] : u32x4{0u, 0u, 0u, 0u};
@@ -339,10 +354,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
           float f[EPC];
           Chunk<T>::unpack(v, f);
 #pragma unroll
-          for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(rc.sc[j], f[j], rc.sh[j]), 0.f);
+          for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(sc[j], f[j], sh[j]), 0.f);
           v = Chunk<T>::pack(f);
         }
-        st16(dstp + i * 32 * 16, v);  // rows hr0 + 2 i: 32 positions apart
+        if (hr0 + RSTEP * i < TH + 2) st16(dstp + i * RSTEP * 16 * 16, v);  // rows hr0 + RSTEP i
       }
     };
 
@@ -351,17 +366,21 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
     PcUnit bu;
     int b_unit = ul.at(0);
     if (b_unit >= 0) bu = pc_decode(a, b_unit);
-    // weights resident: one cout block, no K split, at most two stages -> the two slots never change
-    const bool resident = a.nblk == 1 && a.c.ksplit == 1 && a.nst <= 2;
-    auto b_issue = [&](int g) -> bool {  // weights of global stage g -> slot g & 1 (LDS-DMA), then advance
+    // weights resident: one cout block, no K split, and the unit's stages map onto the slots the same way in
+    // every unit (one stage: every slot holds it; NBS stages: slot = stage) -> loaded once
+    const bool resident = a.nblk == 1 && a.c.ksplit == 1 && (a.nst == 1 || a.nst == C::NBS);
+    int b_slot = 0;  // slot of the next stage to issue (= global stage % NBS)
+    auto b_issue = [&](int g) -> bool {  // weights of global stage g -> slot g % NBS (LDS-DMA), then advance
       if (b_unit < 0) return false;
-      const bool dma = !(resident && g >= 2) && !(a.debug & 8);
+      const bool dma = !(resident && g >= C::NBS) && !(a.debug & 8);
+      const int slot = b_slot;
+      b_slot = b_slot + 1 == C::NBS ? 0 : b_slot + 1;
       if (dma) {
         const unsigned char* src =
-            wbase + ((size_t)bu.blk * a.nst + (bu.s0 + b_stage)) * C::B_BYTES + (pw * 9) * 1024 + lane * 16;
-        unsigned char* dst = sB0 + (g & 1) * C::B_BYTES + (pw * 9) * 1024;
+            wbase + ((size_t)bu.blk * a.nst + (bu.s0 + b_stage)) * C::B_BYTES + (pw * C::NPW) * 1024 + lane * 16;
+        unsigned char* dst = sB0 + slot * C::B_BYTES + (pw * C::NPW) * 1024;
 #pragma unroll
-        for (int j = 0; j < 9; ++j)
+        for (int j = 0; j < C::NPW; ++j)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 1024),
                                            (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
       }
@@ -384,16 +403,25 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
     __syncthreads();  // zero rows written (all 512 threads)
 
     if (gtot == 0) return;  // (a workgroup without units: its consumers execute no barrier either)
-    // Barrier with the right vmcnt: the LDS-DMA of this interval must have landed; activation loads issued
-    // AFTER it (n_new = 0 or NA instructions) may stay in flight.  Without DMA in this interval nothing of
-    // the vector-memory queue has to be waited for.
+    // Barrier with the right vmcnt.  The weights of the NEXT stage must have landed; they were issued LEAD - 1
+    // intervals ago, so the LDS-DMA of this interval (NPW instructions, stage g + LEAD) and the activation
+    // loads issued after it (n_new = 0 or NA) may stay in flight.
+    constexpr int LEAD = C::NBS - 1;
     auto sync = [&](bool dma, int n_new) {
-      if (!dma) pc_barrier_lds();
-      else if (n_new) pc_barrier<C::NA>();
-      else pc_barrier<0>();
+      if (LEAD == 1) {
+        if (!dma) pc_barrier_lds();
+        else if (n_new) pc_barrier<C::NA>();
+        else pc_barrier<0>();
+      } else {
+        if (dma && n_new) pc_barrier<C::NPW + C::NA>();
+        else if (dma) pc_barrier<C::NPW>();
+        else if (n_new) pc_barrier<C::NA>();
+        else pc_barrier<0>();
+      }
     };
-    // prologue: weights of stage 0 in flight, chunk 0 committed, chunks 1 and 2 in registers
-    bool dma = b_issue(0);
+    // prologue: weights of the first LEAD stages in flight, chunk 0 committed, chunks 1 and 2 in registers
+    bool dma = false;
+    for (int l = 0; l < LEAD; ++l) dma = b_issue(l);
     asm volatile("" ::: "memory");  // (pins the issue order the vmcnt counts assume)
     a_request(rc0);
     a_request(rc1);
@@ -406,10 +434,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
     int pst = 0;
     PC_STAMP(pst++);
     for (int g = 0; g + 1 < gtot; ++g) {
-      // consumers compute stage g; slot (g+1)&1 and -- at a chunk boundary -- buffer ga&1 are free
+      // consumers compute stage g; slot (g+LEAD) % NBS and -- at a chunk boundary -- buffer ga&1 are free.
       // Order inside a chunk-boundary interval: commit FIRST (the compiler's wait for the set's registers is
-      // a vmcnt(0): it must not include the LDS-DMA of this interval, ~1 us from issue to landing), then
-      // the DMA, then the next request (its loads are the youngest and stay in flight over the barrier)
+      // a vmcnt(0): it must not include the LDS-DMA of this interval), then the DMA, then the next request
       int n_new = 0;
       const bool boundary = g + 1 == next_chunk_stage;
       if (boundary) {
@@ -417,7 +444,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
         asm volatile("" ::: "memory");
       }
       PC_STAMP(pst++);
-      dma = b_issue(g + 1);
+      dma = b_issue(g + LEAD);
       if (boundary) {
         asm volatile("" ::: "memory");  // the next request's loads are YOUNGER than this stage's LDS-DMA
         if (ga & 1) {
@@ -533,8 +560,42 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
 
   __syncthreads();  // zero rows written
 
+  // Deferred output stores (eight consumer waves): a unit's packed bf16 outputs stay in registers and are
+  // stored two per stage during the NEXT unit's first stages, between its MFMAs.  With every workgroup in
+  // step, immediate stores make the whole chip write its tiles at the same moment (in-kernel stamps: 19-25k
+  // cycles per epilogue, matrix pipes idle) and then compute with HBM idle.
+  constexpr bool DEFER = NCW == 8;
+  constexpr int NPEND = DEFER ? M_REP * N_REP * 2 : 1;
+  u32x4 pend[NPEND];
+  int pend_from = NPEND;  // first entry of `pend` not stored yet (NPEND: nothing pending)
+  int pend_R0 = 0, pend_w0 = 0, pend_n0 = 0;
+  auto store_pending = [&](auto K) {  // entry k = ((n * M_REP + m) * 2 + half)
+    constexpr int k = decltype(K)::value;
+    constexpr int n = k / (M_REP * 2), m = (k / 2) % M_REP, gq = (k % 2) * 2;
+    const int qq = (wm * M_REP + m) * 32 + r;
+    const int hx = qq & 15;
+    const int R = pend_R0 + (qq >> 4), w = pend_w0 + hx - 1;
+    const int co = pend_n0 + (wn * N_REP + n) * 32 + 8 * gq + 8 * h;
+    if (hx >= 1 && hx <= TW && R < a.c.NH && w < a.c.W && co < a.c.Cout) {
+      const size_t gp = (size_t)R * a.c.W + w;
+      T* o1 = reinterpret_cast<T*>(a.c.out);
+      T* o2 = reinterpret_cast<T*>(a.c.out2);
+      T* dst = (a.c.split_c > 0 && co >= a.c.split_c) ? o2 + gp * a.c.ldo2 + (co - a.c.split_c) : o1 + gp * a.c.ldo + co;
+      *reinterpret_cast<u32x4*>(dst) = pend[k];
+    }
+  };
+  auto drain_pending = [&](int count) {  // store the next `count` pending entries
+    if constexpr (DEFER) {
+      const int to = pend_from + count < NPEND ? pend_from + count : NPEND;
+      pc_static_for<0, NPEND>([&](auto K) {
+        if (decltype(K)::value >= pend_from && decltype(K)::value < to) store_pending(K);
+      });
+      pend_from = to;
+    }
+  };
   int cst = 0;
-  int g = 0;   // global stage counter (weight slot = g & 1)
+  int c_slot = 0;  // weight slot of the next stage (= global stage % NBS)
+  int g = 0;   // global stage counter
   int ga = 0;  // global activation chunk counter (buffer = ga & 1)
   for (int it = 0;; ++it) {
     const int unit = ul.at(it);
@@ -580,7 +641,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
       PC_STAMP(cst++);
       const int sub = s % SPA;  // stage inside the activation chunk
       const unsigned char* sA = sA0 + ((ga + s / SPA) & 1) * C::A_BYTES + sub * PPB * APLB;
-      const unsigned char* sB = sB0 + (g & 1) * C::B_BYTES;
+      const unsigned char* sB = sB0 + c_slot * C::B_BYTES;
+      c_slot = c_slot + 1 == C::NBS ? 0 : c_slot + 1;
       // the 9 x KS (tap, k-step) steps of the stage as ONE software pipeline, DEPTH register sets deep:
       // the fragments of step i + DEPTH - 1 are requested before the MFMAs of step i are issued (order
       // pinned by sched_barrier), across tap boundaries too.  The consumer wave is alone on its SIMD's
@@ -630,8 +692,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
       } else {
         run_stage(TapC<KSB>{});
       }
+      if (DEFER && pend_from < NPEND) drain_pending(2);
     }
     ga += (ns + SPA - 1) / SPA;
+    if (DEFER && pend_from < NPEND) drain_pending(NPEND);  // (a unit shorter than the drain)
 
     PC_STAMP(cst++);
     // ---------------- epilogue: accumulators -> NHWC, straight from registers ----------------
@@ -710,11 +774,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
             lo[j] = sw[0];
             hi[j] = sw[1];
           }
-          const int co = n0 + (wn * N_REP + n) * 32 + 8 * gq + 8 * h;
-          if (ok && co < a.c.Cout) {
-            T* dst = (a.c.split_c > 0 && co >= a.c.split_c) ? o2 + gp * a.c.ldo2 + (co - a.c.split_c)
-                                                            : o1 + gp * a.c.ldo + co;
-            *reinterpret_cast<u32x4*>(dst) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          if constexpr (DEFER) {
+            pend[(n * M_REP + m) * 2 + gq / 2] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          } else {
+            const int co = n0 + (wn * N_REP + n) * 32 + 8 * gq + 8 * h;
+            if (ok && co < a.c.Cout) {
+              T* dst = (a.c.split_c > 0 && co >= a.c.split_c) ? o2 + gp * a.c.ldo2 + (co - a.c.split_c)
+                                                              : o1 + gp * a.c.ldo + co;
+              *reinterpret_cast<u32x4*>(dst) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
           }
         }
       }
@@ -732,7 +800,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const PcArgs a) {
         }
       }
     }
+    if constexpr (DEFER) pend_from = 0, pend_R0 = R0, pend_w0 = w0, pend_n0 = n0;
   }
+  if (DEFER && pend_from < NPEND) drain_pending(NPEND);
   if (do_stats) {
     flush_stats();
     // cout blocks this workgroup never produced: their columns of its partial rows are zero
@@ -792,7 +862,7 @@ inline long pc_packed_elems(int Cout, int Cin) {  // elements of the image that 
 }
 
 struct PcPlan {
-  int bn, tiles, nblk, nst, ksplit, units, grid, partials;
+  int bn, ncw, tiles, nblk, nst, ksplit, units, grid, partials;
   size_t ws_bytes;
   int finish_blocks;
 };
@@ -800,6 +870,11 @@ struct PcPlan {
 inline PcPlan plan_pc(int N, int H, int W, int Cin, int Cout) {
   PcPlan p;
   p.bn = pc_bn_for(Cout);
+  static const int ncw128 = [] {
+    const char* e = getenv("CY_PC_NCW");
+    return (e && atoi(e) == 4) ? 4 : 8;
+  }();
+  p.ncw = p.bn == 128 ? ncw128 : 4;
   const int kcb = 2048 / p.bn;
   p.tiles = cy_cdiv((long)N * H, 16) * (W / 14);
   p.nblk = cy_cdiv(Cout, p.bn);
@@ -827,14 +902,14 @@ inline PcPlan plan_pc(int N, int H, int W, int Cin, int Cout) {
   long fb = (npix + 15) / 16;
   if (fb > 1024) fb = 1024;
   p.finish_blocks = (int)fb;
-  p.partials = Z > 1 ? p.finish_blocks : p.grid * (p.bn == 128 ? 2 : 4);
+  p.partials = Z > 1 ? p.finish_blocks : p.grid * (p.bn == 128 ? p.ncw / 2 : 4);
   p.ws_bytes = Z > 1 ? (size_t)Z * npix * Cout * sizeof(float) : 0;
   return p;
 }
 
-template <typename T, int BN> int launch_conv_pc(PcArgs a, const PcPlan& p, hipStream_t st) {
-  using C = PcCfg<BN>;
-  auto kern = conv3x3_pc_kernel<T, BN>;
+template <typename T, int BN, int NCW = 4> int launch_conv_pc(PcArgs a, const PcPlan& p, hipStream_t st) {
+  using C = PcCfg<BN, NCW>;
+  auto kern = conv3x3_pc_kernel<T, BN, NCW>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -851,7 +926,7 @@ template <typename T, int BN> int launch_conv_pc(PcArgs a, const PcPlan& p, hipS
   }();
   a.debug = dbg;
   a.stamps = g_pc_stamp_buf;
-  hipLaunchKernelGGL(kern, dim3(p.grid), dim3(512), C::SMEM, st, a);
+  hipLaunchKernelGGL(kern, dim3(p.grid), dim3(C::NT), C::SMEM, st, a);
   CY_CHECK_LAUNCH();
   return CY_OK;
 }

@@ -18,6 +18,8 @@
 //    and written to LDS after them: global latency hides behind the tap loop.
 // Weights are read in the same packed image as the other kernel ([tap][co_pad][ci_pad]).
 #pragma once
+#include <cstdlib>
+
 #include "cy_conv_tile.h"
 
 #ifndef CY_PLANE_INTERLEAVE
@@ -110,7 +112,15 @@ __global__ void __launch_bounds__(256, PREFA ? 1 : 2)
   const int wm = wave / WGN, wn = wave % WGN;
   const int r = lane & 31, h = lane >> 5;
 
-  const int tile = blockIdx.x;
+  // Workgroups are dealt round robin over the 8 XCDs (b and b + 8 share one, MI355X_MICROARCH.md "Workgroup
+  // dispatch"): with tile = b, vertically adjacent tiles -- which share two of their 18 halo rows -- sit on
+  // different XCDs and the rows are fetched from HBM into two L2s (measured traffic 1.33 x algorithmic).
+  // Remapped, every XCD owns a contiguous band of tiles (bijective for any tile count).
+  int tile = blockIdx.x;
+  if (a.xcd_remap) {
+    const int nt = gridDim.x, x = tile & 7, i = tile >> 3, q = nt >> 3, rr = nt & 7;
+    tile = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
+  }
   const int ct = tile % a.tiles_w;
   const int rt = tile / a.tiles_w;
   const int R0 = rt * TH, w0 = ct * TW;
@@ -555,6 +565,11 @@ int launch_conv_plane(ConvArgs a, hipStream_t st) {
   if (a.W % C::TW != 0) return CY_ERR_SHAPE;
   a.tiles_w = a.W / C::TW;
   a.full_tiles = 0;
+  static const int xcd = [] {
+    const char* e = getenv("CY_PLANE_XCD");
+    return e ? atoi(e) : 1;
+  }();
+  a.xcd_remap = xcd;
   dim3 grid(cy_cdiv(a.NH, TH) * a.tiles_w, cy_cdiv(a.Cout, BN), a.ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(256), C::SMEM, st, a);
   CY_CHECK_LAUNCH();

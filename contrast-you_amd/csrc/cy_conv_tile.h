@@ -33,6 +33,7 @@ struct ConvArgs {
   int full_tiles;  // 1: every tile is entirely inside the image grid
   float* ws;       // split-K: f32 partial outputs [ksplit][N*H*W][Cout]
   int ksplit;      // number of K splits over input-channel chunks (blockIdx.z)
+  int xcd_remap;   // plane kernel: workgroup b -> tile such that the 8 XCDs own contiguous bands of tiles
 };
 
 // ---- MFMA fragment abstraction: one "k-step" is 16 input channels ----------

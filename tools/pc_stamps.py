@@ -25,7 +25,7 @@ kw = dict(mode=mode, scale=None if scale is None else scale.cuda(), shift=None i
 g1, g2 = nhwc(x1, BF), None if x2 is None else nhwc(x2, BF)
 pf, pd = ops.pack_weights_pc(w.cuda(), BF)
 gdy = nhwc(dy, BF)
-stamps = torch.zeros(8 * 128, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(12 * 128, dtype=torch.int64, device="cuda")
 _lib.call("cy_debug_pc_stamps", stamps.data_ptr())
 for _ in range(3):
     if which == "fwd":
@@ -34,8 +34,9 @@ for _ in range(3):
         ops.conv3x3_pc_fwd(gdy, None, pd, C1 + C2, want_stats=False)
 torch.cuda.synchronize()
 buf = stamps.cpu().tolist()
-st = [[buf[w * 128 + k] for k in range(128)] for w in range(8)]
-t0 = min(s[0] for s in st if s[0])
+st = [[buf[w * 128 + k] for k in range(128)] for w in range(12)]
+PW = 8 if (st[8][0] or st[8][1]) else 4
+
 print("consumer wave 0: (wait-at-barrier, stage) cycles per stage; E = epilogue marker")
 c = st[0]
 row = []
@@ -46,8 +47,8 @@ while k + 2 < 128 and c[k + 1]:
     if len(row) >= 40:
         break
 print(row)
-print("producer wave 4: (b_issue, commit/request, barrier wait) cycles per interval")
-p = st[4]
+print(f"producer wave {PW}: (b_issue, commit/request, barrier wait) cycles per interval")
+p = st[PW]
 row = []
 k = 0
 while k + 3 < 128 and p[k + 3]:
