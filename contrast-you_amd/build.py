@@ -21,7 +21,7 @@ LIB = HERE / "lib" / "libcontrastyou_hip.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+         "-Wno-unused-variable", "-Wno-unused-but-set-variable"] + os.environ.get("CY_HIPCC_EXTRA", "").split()
 
 
 def _deps_mtime() -> float:

@@ -17,6 +17,7 @@
 // partial per tile, fixed-order reduction in cy_bn_finalize) and stores
 // 16-byte NHWC chunks after a wave-private LDS transpose.
 #include "cy_conv_plane.h"
+#include "cy_conv_plane8.h"
 #include "cy_conv_tile.h"
 
 #include <cstdlib>
@@ -516,6 +517,7 @@ constexpr int kPlaneTH = 16, kPlaneTW = 14;
 
 struct ConvPlan {
   bool plane;
+  bool plane8;      // plane, 128 couts, 16-bit storage: one eight-wave workgroup per 32 x 14 tile (cy_conv_plane8.h)
   bool one_per_cu;  // plane, 128 couts: at most one workgroup per CU, halo prefetch in registers
   TileChoice tile;
   int ksplit;         // >1: split-K over input-channel chunks + finish kernel
@@ -526,9 +528,41 @@ struct ConvPlan {
 
 // Deep layers (14x14 / 28x28 at small batch) have too few output tiles to fill 256 CUs: split
 // the reduction over input-channel chunks across blockIdx.z.
-ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes) {
+ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool plane8_ok = false) {
   ConvPlan p;
   p.plane = use_plane_kernel(W);
+  p.plane8 = false;
+  static const int plane8_mode = [] {
+    const char* e = getenv("CY_PLANE8");
+    return e ? atoi(e) : 0;
+  }();
+  if (p.plane && plane8_ok && plane8_mode && elem_bytes == 2 && Cout >= 128 && Cout % 8 == 0) {
+    p.plane8 = true;
+    p.one_per_cu = false;
+    p.tile.th = 32, p.tile.tw = kPlaneTW, p.tile.bn = 128;
+    const long npix8 = (long)N * H * W;
+    const int tiles8 = cy_cdiv((long)N * H, 32) * (W / kPlaneTW);
+    const int blocks8 = tiles8 * cy_cdiv(Cout, 128);
+    const int ncc8 = cy_cdiv(Cin, 32);
+    int Z = 1;
+    if (blocks8 < 192) {  // one workgroup per CU: aim at ~224-256 workgroups, >= 2 chunks each
+      Z = (240 + blocks8 / 2) / blocks8;
+      if (Z > ncc8 / 2) Z = ncc8 / 2;
+      if (Z > 8) Z = 8;
+      if (Z < 1) Z = 1;
+    }
+    if (const char* ov = getenv("CY_KSPLIT")) {
+      const int z = atoi(ov);
+      if (z >= 1) Z = z > ncc8 ? ncc8 : z;
+    }
+    p.ksplit = Z;
+    long fb = (npix8 + 15) / 16;
+    if (fb > 1024) fb = 1024;
+    p.finish_blocks = (int)fb;
+    p.partials = Z > 1 ? p.finish_blocks : tiles8;
+    p.ws_bytes = Z > 1 ? (size_t)Z * npix8 * Cout * sizeof(float) : 0;
+    return p;
+  }
   p.tile = choose_tile((long)N * H, W, Cout);
   const long npix = (long)N * H * W;
   if (p.plane) {
@@ -596,6 +630,10 @@ int launch_finish(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
 
 template <typename T>
 int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
+  if (p.plane8) {
+    if constexpr (sizeof(T) == 2) return launch_conv_plane8<T>(a, st);
+    return CY_ERR_DTYPE;
+  }
   if (p.plane) {
     if (p.tile.bn == 128)
       return p.one_per_cu ? launch_conv_plane<T, kPlaneTH, 128, 2, 2, 128, false, true>(a, st)
@@ -895,7 +933,9 @@ static int conv_check(const cy_conv_desc* d) {
 }
 
 static ConvPlan plan_of(const cy_conv_desc* d) {
-  return plan_conv(d->N, d->H, d->W, d->C1 + d->C2, d->Cout, d->in_dtype == CY_F32 ? 4 : 2);
+  const bool p8 = !(d->prologue && d->C1 > Plane8Cfg<bf16>::COEF_MAX) && d->mode1 != CY_SRC_POOL2 &&
+                  !(d->C2 != 0 && d->C1 % Plane8Cfg<bf16>::KC);
+  return plan_conv(d->N, d->H, d->W, d->C1 + d->C2, d->Cout, d->in_dtype == CY_F32 ? 4 : 2, p8);
 }
 
 int cy_conv3x3_num_partials(const cy_conv_desc* d) {
@@ -908,7 +948,7 @@ int cy_conv3x3_plan(const cy_conv_desc* d, cy_conv_plan* plan) {
   if (rc != CY_OK) return rc;
   if (!plan) return CY_ERR_ARG;
   const ConvPlan p = plan_of(d);
-  plan->kernel = p.plane ? 1 : 0;
+  plan->kernel = p.plane8 ? 3 : (p.plane ? 1 : 0);
   plan->th = p.tile.th, plan->tw = p.tile.tw, plan->bn = p.tile.bn;
   plan->ksplit = p.ksplit, plan->one_per_cu = p.one_per_cu ? 1 : 0, plan->partials = p.partials;
   plan->workgroups = cy_cdiv((long)d->N * d->H, p.tile.th) * cy_cdiv(d->W, p.tile.tw) *
@@ -938,6 +978,12 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
   a.mode1 = d->mode1, a.prologue = d->prologue;
   a.ld1 = d->ld1, a.ld2 = d->ld2, a.ldo = d->ldo, a.ldo2 = d->ldo2, a.split_c = d->split_c;
   a.tiles_w = 0, a.full_tiles = 0;
+  {  // extents of the sources (the last pixel's row ends at ld * (pixels - 1) + C)
+    const long eb = d->in_dtype == CY_F32 ? 4 : 2;
+    const long px1 = d->mode1 == CY_SRC_POOL2 ? 4L * d->N * d->H * d->W : (d->mode1 == CY_SRC_UP2 ? (long)d->N * (d->H / 2) * (d->W / 2) : (long)d->N * d->H * d->W);
+    a.bytes1 = ((px1 - 1) * d->ld1 + d->C1) * eb;
+    a.bytes2 = d->C2 ? (((long)d->N * d->H * d->W - 1) * d->ld2 + d->C2) * eb : 0;
+  }
   cy_conv3x3_packed_dims(d->Cout, d->C1 + d->C2, &a.w_co_pad, &a.w_ci_pad);
   const ConvPlan p = plan_of(d);
   a.ksplit = p.ksplit;
@@ -989,8 +1035,14 @@ int cy_conv3x3_pc_pack(const float* w, void* wpc_f, void* wpc_d, int Cout, int C
   return CY_OK;
 }
 
+int cy_debug_p8_weights(const void* pc_image) {
+  g_p8_w_dma = pc_image;
+  return CY_OK;
+}
+
 int cy_debug_pc_stamps(unsigned long long* dev_buf) {
   g_pc_stamp_buf = dev_buf;
+  g_p8_stamp_buf = dev_buf;
   return CY_OK;
 }
 

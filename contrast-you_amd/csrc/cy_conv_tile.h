@@ -34,6 +34,8 @@ struct ConvArgs {
   float* ws;       // split-K: f32 partial outputs [ksplit][N*H*W][Cout]
   int ksplit;      // number of K splits over input-channel chunks (blockIdx.z)
   int xcd_remap;   // plane kernel: workgroup b -> tile such that the 8 XCDs own contiguous bands of tiles
+  long long bytes1, bytes2;    // sizes of the source tensors in bytes (buffer descriptors of the LDS-DMA kernels), or 0
+  unsigned long long* stamps;  // development aid (cy_debug_pc_stamps): shader-clock stamps of workgroup 0, or null
 };
 
 // ---- MFMA fragment abstraction: one "k-step" is 16 input channels ----------

@@ -144,6 +144,9 @@ long long cy_conv3x3_pc_packed_elems(int Cout, int Cin);
 /* development aid: workgroup 0 of every following cy_conv3x3_pc_fwd launch records shader-clock stamps of
  * its 8 waves into dev_buf[8][128] (DEVICE memory; NULL switches it off again). */
 int cy_debug_pc_stamps(unsigned long long* dev_buf);
+/* development aid: route the eight-wave plane kernel's weights through LDS-DMA from this cy_conv3x3_pc_pack
+ * image (NULL: packed image of cy_conv3x3_pack_weights as usual). */
+int cy_debug_p8_weights(const void* pc_image);
 int cy_conv3x3_pc_pack(const float* w, void* wpc_f, void* wpc_d, int Cout, int Cin, int dtype, void* stream);
 int cy_conv3x3_pc_num_partials(const cy_conv_desc* d);
 size_t cy_conv3x3_pc_ws_bytes(const cy_conv_desc* d);

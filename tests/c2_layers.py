@@ -36,6 +36,8 @@ def conv_kernel_name(plan: dict, dtype_tag: str = "DF16b") -> str:
         wgm, wgn, pitch, allt = (2, 2, 128, 0) if plan["bn"] == 128 else (4, 1, 64, 1)
         return ("conv3x3_plane_kernelI" + dtype_tag + i(plan["th"]) + i(plan["bn"]) + i(wgm) + i(wgn) + i(pitch)
                 + b(allt) + b(plan["one_per_cu"]) + "E")
+    if plan["kernel"] == "conv3x3_plane8_kernel":
+        return "conv3x3_plane8_kernelI" + dtype_tag + "E"
     if plan["kernel"] == "conv3x3_pc_kernel":
         return "conv3x3_pc_kernelI" + dtype_tag + i(plan["bn"])
     wgm, wgn = ((1, 4) if (plan["th"], plan["tw"]) in ((8, 28), (16, 14)) else (2, 2)) if plan["bn"] == 128 else (4, 1)
@@ -55,7 +57,7 @@ def profiled_conv_kernels(path: Path):
     names = set()
     for line in path.read_text().splitlines():
         tok = line.split("  ")[0].strip()
-        m = re.search(r"(conv3x3_(?:plane|igemm|pc)_kernelI\w+?)Ev", tok)
+        m = re.search(r"(conv3x3_(?:plane8|plane|igemm|pc)_kernelI\w+?)Ev", tok)
         if m:
             names.add(m.group(1))
         m = re.match(r"(wgrad(?:12)?_kernel<)(?:[A-Za-z_]\w*, )?(\d+, \d+, \d+)", tok)

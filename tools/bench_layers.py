@@ -3,6 +3,7 @@
 max_channel 512, bf16): forward, data-gradient and weight-gradient kernels, in TFLOP/s.
 Run on the GPU box:  python tools/bench_layers.py [--n 32] [--hw 224] [--dtype bf16]"""
 import argparse
+import os
 import sys
 from pathlib import Path
 
@@ -65,8 +66,17 @@ def main():
         shift = torch.rand(C1, device=dev) - 0.5 if pro else None
         dy = ops.empty_nhwc(N, Cout, H, H, dt, dev).normal_()
         flops = 2.0 * N * H * H * 9 * (C1 + C2) * Cout
+        p8dma = os.environ.get("CY_P8_DMA", "0") != "0"  # development aid: eight-wave plane kernel, weights by LDS-DMA
+        if p8dma:
+            from cyhip import _lib
+            pf, pd = ops.pack_weights_pc(w, dt)
+            _lib.call("cy_debug_p8_weights", pf.data_ptr() if Cout >= 128 and (C1 + C2) % 32 == 0 else 0)
         t_f = timeit(lambda: ops.conv3x3_fwd(x1, x2, wf, Cout, mode=mode, scale=scale, shift=shift), a.iters, 1)
+        if p8dma:
+            _lib.call("cy_debug_p8_weights", pd.data_ptr() if C1 + C2 >= 128 and Cout % 32 == 0 else 0)
         t_d = timeit(lambda: ops.conv3x3_fwd(dy, None, wd, C1 + C2, want_stats=False), a.iters, 1)
+        if p8dma:
+            _lib.call("cy_debug_p8_weights", 0)
         t_w = timeit(lambda: ops.conv3x3_wgrad(x1, x2, dy, mode=mode, scale=scale, shift=shift), a.iters, 1)
         tot["fwd"] += t_f
         tot["dgrad"] += t_d
