@@ -18,6 +18,7 @@
 // 16-byte NHWC chunks after a wave-private LDS transpose.
 #include "cy_conv_plane.h"
 #include "cy_conv_plane8.h"
+#include "cy_conv_stream.h"
 #include "cy_conv_tile.h"
 
 #include <cstdlib>
@@ -517,6 +518,7 @@ constexpr int kPlaneTH = 16, kPlaneTW = 14;
 
 struct ConvPlan {
   bool plane;
+  bool stream;      // plane, 16-bit storage, Cin / Cout in {32, 64}, no load transform: persistent streaming kernel (cy_conv_stream.h)
   bool plane8;      // plane, 128 couts, 16-bit storage: one eight-wave workgroup per 32 x 14 tile (cy_conv_plane8.h)
   bool one_per_cu;  // plane, 128 couts: at most one workgroup per CU, halo prefetch in registers
   TileChoice tile;
@@ -528,10 +530,27 @@ struct ConvPlan {
 
 // Deep layers (14x14 / 28x28 at small batch) have too few output tiles to fill 256 CUs: split
 // the reduction over input-channel chunks across blockIdx.z.
-ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool plane8_ok = false) {
+ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool plane8_ok = false, bool stream_ok = false,
+                   bool prologue = false) {
   ConvPlan p;
   p.plane = use_plane_kernel(W);
   p.plane8 = false;
+  p.stream = false;
+  static const int stream_mode = [] {
+    const char* e = getenv("CY_STREAM");
+    return e ? atoi(e) : 1;
+  }();
+  // (persistent pipeline: worth it from ~4 tiles per workgroup on -- the 224x224 level at any batch size here)
+  if (p.plane && stream_ok && stream_mode && cy_cdiv((long)N * H, kPlaneTH) * (W / kPlaneTW) >= 2048) {
+    p.stream = true;
+    p.one_per_cu = false;
+    p.tile.th = kPlaneTH, p.tile.tw = kPlaneTW, p.tile.bn = Cout;
+    p.ksplit = 1;
+    p.finish_blocks = 0;
+    p.partials = stream_partials(Cin, Cout, cy_cdiv((long)N * H, kPlaneTH) * (W / kPlaneTW), prologue);
+    p.ws_bytes = 0;
+    return p;
+  }
   static const int plane8_mode = [] {
     const char* e = getenv("CY_PLANE8");
     return e ? atoi(e) : 0;
@@ -630,6 +649,10 @@ int launch_finish(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
 
 template <typename T>
 int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
+  if (p.stream) {
+    if constexpr (sizeof(T) == 2) return dispatch_conv_stream<T>(a, st);
+    return CY_ERR_DTYPE;
+  }
   if (p.plane8) {
     if constexpr (sizeof(T) == 2) return launch_conv_plane8<T>(a, st);
     return CY_ERR_DTYPE;
@@ -935,7 +958,7 @@ static int conv_check(const cy_conv_desc* d) {
 static ConvPlan plan_of(const cy_conv_desc* d) {
   const bool p8 = !(d->prologue && d->C1 > Plane8Cfg<bf16>::COEF_MAX) && d->mode1 != CY_SRC_POOL2 &&
                   !(d->C2 != 0 && d->C1 % Plane8Cfg<bf16>::KC);
-  return plan_conv(d->N, d->H, d->W, d->C1 + d->C2, d->Cout, d->in_dtype == CY_F32 ? 4 : 2, p8);
+  return plan_conv(d->N, d->H, d->W, d->C1 + d->C2, d->Cout, d->in_dtype == CY_F32 ? 4 : 2, p8, stream_applicable(d), d->prologue != 0);
 }
 
 int cy_conv3x3_num_partials(const cy_conv_desc* d) {
@@ -948,7 +971,7 @@ int cy_conv3x3_plan(const cy_conv_desc* d, cy_conv_plan* plan) {
   if (rc != CY_OK) return rc;
   if (!plan) return CY_ERR_ARG;
   const ConvPlan p = plan_of(d);
-  plan->kernel = p.plane8 ? 3 : (p.plane ? 1 : 0);
+  plan->kernel = p.stream ? 4 : (p.plane8 ? 3 : (p.plane ? 1 : 0));
   plan->th = p.tile.th, plan->tw = p.tile.tw, plan->bn = p.tile.bn;
   plan->ksplit = p.ksplit, plan->one_per_cu = p.one_per_cu ? 1 : 0, plan->partials = p.partials;
   plan->workgroups = cy_cdiv((long)d->N * d->H, p.tile.th) * cy_cdiv(d->W, p.tile.tw) *
@@ -983,9 +1006,14 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
     const long px1 = d->mode1 == CY_SRC_POOL2 ? 4L * d->N * d->H * d->W : (d->mode1 == CY_SRC_UP2 ? (long)d->N * (d->H / 2) * (d->W / 2) : (long)d->N * d->H * d->W);
     a.bytes1 = ((px1 - 1) * d->ld1 + d->C1) * eb;
     a.bytes2 = d->C2 ? (((long)d->N * d->H * d->W - 1) * d->ld2 + d->C2) * eb : 0;
+    const long opx = (long)d->N * d->H * d->W;
+    const long ob = d->out_dtype == CY_F32 ? 4 : 2;
+    a.bytes_o1 = ((opx - 1) * d->ldo + (d->split_c > 0 ? d->split_c : d->Cout)) * ob;
+    a.bytes_o2 = d->split_c > 0 ? ((opx - 1) * d->ldo2 + (d->Cout - d->split_c)) * ob : 0;
   }
   cy_conv3x3_packed_dims(d->Cout, d->C1 + d->C2, &a.w_co_pad, &a.w_ci_pad);
   const ConvPlan p = plan_of(d);
+  a.bytes_st = stats ? (long long)p.partials * 2 * d->Cout * 4 : 0;
   a.ksplit = p.ksplit;
   a.ws = (float*)ws;
   if (p.ksplit > 1 && (!ws || ws_bytes < p.ws_bytes)) return CY_ERR_WORKSPACE;

@@ -35,6 +35,7 @@ struct ConvArgs {
   int ksplit;      // number of K splits over input-channel chunks (blockIdx.z)
   int xcd_remap;   // plane kernel: workgroup b -> tile such that the 8 XCDs own contiguous bands of tiles
   long long bytes1, bytes2;    // sizes of the source tensors in bytes (buffer descriptors of the LDS-DMA kernels), or 0
+  long long bytes_o1, bytes_o2, bytes_st;  // ... of the outputs and the statistics partials
   unsigned long long* stamps;  // development aid (cy_debug_pc_stamps): shader-clock stamps of workgroup 0, or null
 };
 

@@ -217,7 +217,7 @@ def _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, ld1, ld2, ldo, split_c=0, l
     return p
 
 
-KERNEL_NAMES = {0: "conv3x3_igemm_kernel", 1: "conv3x3_plane_kernel", 2: "conv3x3_pc_kernel", 3: "conv3x3_plane8_kernel"}
+KERNEL_NAMES = {0: "conv3x3_igemm_kernel", 1: "conv3x3_plane_kernel", 2: "conv3x3_pc_kernel", 3: "conv3x3_plane8_kernel", 4: "conv3x3_stream_kernel"}
 
 
 def conv3x3_plan(N, H, W, C1, C2, Cout, dtype: torch.dtype, mode: int = 0, prologue: bool = False) -> dict:

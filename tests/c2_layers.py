@@ -28,8 +28,9 @@ def unet_layers(hw: int = 224, max_channel: int = 512):
 ENCODER = ("Conv1b", "Conv2a", "Conv2b", "Conv3a", "Conv3b", "Conv4a", "Conv4b", "Conv5a", "Conv5b")
 
 
-def conv_kernel_name(plan: dict, dtype_tag: str = "DF16b") -> str:
-    """mangled-name fragment of the instantiation a cy_conv_plan stands for"""
+def conv_kernel_name(plan: dict, dtype_tag: str = "DF16b", cin: int = 0, stats: bool = False, pro: bool = False) -> str:
+    """mangled-name fragment of the instantiation a cy_conv_plan stands for (cin / stats / pro: what the streaming
+    kernel is additionally instantiated on)"""
     b = lambda v: f"Lb{int(bool(v))}E"  # noqa: E731
     i = lambda v: f"Li{int(v)}E"  # noqa: E731
     if plan["kernel"] == "conv3x3_plane_kernel":
@@ -38,6 +39,8 @@ def conv_kernel_name(plan: dict, dtype_tag: str = "DF16b") -> str:
                 + b(allt) + b(plan["one_per_cu"]) + "E")
     if plan["kernel"] == "conv3x3_plane8_kernel":
         return "conv3x3_plane8_kernelI" + dtype_tag + "E"
+    if plan["kernel"] == "conv3x3_stream_kernel":
+        return ("conv3x3_stream_kernelI" + dtype_tag + i(cin // 32) + i(plan["bn"] // 32) + b(stats) + b(pro) + "E")
     if plan["kernel"] == "conv3x3_pc_kernel":
         return "conv3x3_pc_kernelI" + dtype_tag + i(plan["bn"])
     wgm, wgn = ((1, 4) if (plan["th"], plan["tw"]) in ((8, 28), (16, 14)) else (2, 2)) if plan["bn"] == 128 else (4, 1)
@@ -57,7 +60,7 @@ def profiled_conv_kernels(path: Path):
     names = set()
     for line in path.read_text().splitlines():
         tok = line.split("  ")[0].strip()
-        m = re.search(r"(conv3x3_(?:plane8|plane|igemm|pc)_kernelI\w+?)Ev", tok)
+        m = re.search(r"(conv3x3_(?:plane8|plane|igemm|pc|stream)_kernelI\w+?)Ev", tok)
         if m:
             names.add(m.group(1))
         m = re.match(r"(wgrad(?:12)?_kernel<)(?:[A-Za-z_]\w*, )?(\d+, \d+, \d+)", tok)

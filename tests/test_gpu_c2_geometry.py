@@ -83,7 +83,7 @@ def _run_layer(N, layer, dtype, seed, expect_kernel=None):
     if expect_kernel is not None:
         assert plan["kernel"] in expect_kernel, (name, plan)
     out, stats = ops.conv3x3_fwd(g1, g2, wf, Cout, **kw)
-    tol = 1.2e-2 if dtype == BF else 2e-5
+    tol = {BF: 1.2e-2, torch.float16: 2e-3}.get(dtype, 2e-5)
     assert_close(out, ref, tol, f"{name} N={N} fwd {plan}")
     assert stats.shape[0] == plan["partials"], (name, stats.shape, plan)
     o = cpu(out).double()
@@ -95,7 +95,7 @@ def _run_layer(N, layer, dtype, seed, expect_kernel=None):
     din, _ = ops.conv3x3_fwd(nhwc(dy, dtype), None, wd, C1 + C2, want_stats=False)
     assert_close(din, F.conv_transpose2d(dy, w, None, 1, 1), tol, f"{name} N={N} dgrad {dplan}")
     dw = ops.conv3x3_wgrad(g1, g2, nhwc(dy, dtype), **kw)
-    assert_close(dw, wv.grad, 2e-3 if dtype == BF else 2e-5, f"{name} N={N} wgrad")
+    assert_close(dw, wv.grad, 2e-3 if dtype in (BF, torch.float16) else 2e-5, f"{name} N={N} wgrad")
     return plan, dplan
 
 
@@ -105,12 +105,35 @@ C2_LAYERS = cl.unet_layers(224, 512)
 @pytest.mark.parametrize("N", [16, 32])
 @pytest.mark.parametrize("layer", C2_LAYERS, ids=[l[0] for l in C2_LAYERS])
 def test_c2_layer_bf16(layer, N):
-    plan, dplan = _run_layer(N, layer, BF, seed=1000 + N, expect_kernel=("conv3x3_plane_kernel", "conv3x3_plane8_kernel"))
+    plan, dplan = _run_layer(N, layer, BF, seed=1000 + N, expect_kernel=("conv3x3_plane_kernel", "conv3x3_plane8_kernel", "conv3x3_stream_kernel"))
     # the claims of VERDICT r01 / ADVICE r01: these geometries reach split-K above 1, 512-channel operands and
     # (where the plane kernel is planned) the one-workgroup-per-CU build
     name = layer[0]
     if name == "Conv5b" and N == 16:
         assert plan["ksplit"] > 1, plan
+
+
+STREAM_LAYERS = [l for l in C2_LAYERS if l[0] in ("Conv1b", "Up2", "Up_conv2a", "Up_conv2b")]
+
+
+@pytest.mark.parametrize("dtype", [BF, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("layer", STREAM_LAYERS, ids=lambda l: l[0])
+def test_c2_low_channel_layers_take_the_streaming_kernel(layer, dtype):
+    """the 224 x 224 level (Cin, Cout in {32, 64}) runs in the persistent LDS-DMA kernel (csrc/cy_conv_stream.h):
+    forward with BN statistics (upsample / concat / BN+ReLU-prologue loads) and data gradient (incl. the split
+    epilogue of the concat layer), both 16-bit storage types"""
+    plan, dplan = _run_layer(16, layer, dtype, seed=555, expect_kernel=("conv3x3_stream_kernel",))
+    assert dplan["kernel"] == "conv3x3_stream_kernel", dplan
+    name, H, C1, C2, Cout, mode, pro = layer
+    if C2:  # the data gradient of a concat layer leaves as two tensors (skip branch / upsampled branch)
+        from cyhip import ops
+        x1, x2, w, dy, scale, shift = _case(16, layer, dtype, 555)
+        _, wd = ops.pack_weights(w.to(DEV), dtype)
+        (d1, d2), _ = ops.conv3x3_fwd(nhwc(dy, dtype), None, wd, C1 + C2, want_stats=False, split=C1)
+        rd = F.conv_transpose2d(dy, w, None, 1, 1)
+        tol = {BF: 1.2e-2, torch.float16: 2e-3}[dtype]
+        assert_close(d1, rd[:, :C1], tol, f"{name} dgrad split 1")
+        assert_close(d2, rd[:, C1:], tol, f"{name} dgrad split 2")
 
 
 @pytest.mark.parametrize("layer", [l for l in C2_LAYERS if l[0] in ("Conv1b", "Conv3a", "Conv4b", "Conv5b", "Up_conv5a", "Up4", "Up2")],

@@ -12,8 +12,9 @@ def _tested_kernel_names():
     names = set()
     for N in (16, 32):
         for name, H, C1, C2, Cout, mode, pro in cl.unet_layers(224, 512):
-            names.add(cl.conv_kernel_name(ops.conv3x3_plan(N, H, H, C1, C2, Cout, torch.bfloat16, mode, pro)))
-            names.add(cl.conv_kernel_name(ops.conv3x3_plan(N, H, H, Cout, 0, C1 + C2, torch.bfloat16, 0, 0)))
+            names.add(cl.conv_kernel_name(ops.conv3x3_plan(N, H, H, C1, C2, Cout, torch.bfloat16, mode, pro),
+                                          cin=C1 + C2, stats=True, pro=bool(pro)))
+            names.add(cl.conv_kernel_name(ops.conv3x3_plan(N, H, H, Cout, 0, C1 + C2, torch.bfloat16, 0, 0), cin=Cout))
             names.add(cl.wgrad_kernel_name(ops.conv3x3_wgrad_plan(N, H, H, C1, C2, Cout, torch.bfloat16, mode, pro)))
     for name, H, C1, C2, Cout, mode, pro in cl.unet_layers(224, 512):
         if name in cl.ENCODER:  # the two passes of the two-stage step in one launch
@@ -33,7 +34,7 @@ def test_every_profiled_conv_instantiation_has_a_parity_case():
 def test_plan_query_matches_partials_and_split():
     from cyhip import ops
     p = ops.conv3x3_plan(16, 28, 28, 256, 0, 256, torch.bfloat16, 0, 1)  # Conv4b at N=16
-    assert p["kernel"] in ("conv3x3_plane_kernel", "conv3x3_pc_kernel") and p["bn"] == 128
+    assert p["kernel"] == "conv3x3_plane_kernel" and p["bn"] == 128
     assert p["workgroups"] >= 192
     w = ops.conv3x3_wgrad_plan(16, 14, 14, 512, 0, 512, torch.bfloat16, 0, 1)
     assert w["splits"] >= 1 and w["workgroups"] >= 64
