@@ -541,7 +541,8 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool 
     return e ? atoi(e) : 1;
   }();
   // (persistent pipeline: worth it from ~4 tiles per workgroup on -- the 224x224 level at any batch size here)
-  if (p.plane && stream_ok && stream_mode && cy_cdiv((long)N * H, kPlaneTH) * (W / kPlaneTW) >= 2048) {
+  // (CY_STREAM=2: no tile-count threshold, for experiments)
+  if (p.plane && stream_ok && stream_mode && (stream_mode == 2 || cy_cdiv((long)N * H, kPlaneTH) * (W / kPlaneTW) >= 2048)) {
     p.stream = true;
     p.one_per_cu = false;
     p.tile.th = kPlaneTH, p.tile.tw = kPlaneTW, p.tile.bn = Cout;

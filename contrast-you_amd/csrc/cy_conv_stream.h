@@ -25,7 +25,10 @@ namespace {
 // (NBW blocks per wave: 1); NBUF tile buffers (2 for Cin 64 -> Cout 32, so that two workgroups fit a CU's LDS).  Two
 // four-wave workgroups per CU run out of phase with each other -- DMA issue, MFMAs and epilogue of a tile are
 // serial within a workgroup.
-template <int KCH, int NB> constexpr int stream_nbw() { return 1; }  // (2 for Cin 32 -> Cout 64 was slower and spilled)
+// (Cout 64 as both blocks in one wave -- every activation fragment feeding two MFMAs, 144-288 weight registers,
+//  one wave per SIMD at up to 512 registers -- halves the LDS reads that bound the eight-wave form (stamps: 5500
+//  cycles per 72 MFMAs) but was 15-25 % slower: a wave alone on its SIMD exposes every wait)
+template <int KCH, int NB> constexpr int stream_nbw() { return 1; }
 template <int KCH, int NB> constexpr int stream_nbuf() { return (KCH * NB == 4) ? 3 : 2; }
 // workgroups per CU: three four-wave workgroups of the 32-channel shapes (<= 168 registers, 39 KB of LDS each),
 // two of Cin 64 -> Cout 32 (two waves per SIMD at 144 weight registers), one eight-wave workgroup for 64 -> 64

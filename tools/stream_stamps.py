@@ -6,7 +6,7 @@ import os
 import sys
 from pathlib import Path
 
-os.environ["CY_STREAM"] = "1"
+os.environ.setdefault("CY_STREAM", "1")
 import torch  # noqa: E402
 
 REPO = Path(__file__).resolve().parents[1]
