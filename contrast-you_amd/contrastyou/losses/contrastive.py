@@ -79,10 +79,10 @@ class SupConLoss1(nn.Module):
         else:
             labels = torch.arange(n, dtype=torch.int32, device=dev)  # SimCLR: only the other view
         P = torch.cat([proj_feat1, proj_feat2], dim=0)
-        loss, S, stats = SupConFn.apply(P, labels, pos, float(self._t))
-        self._last = (S, stats, labels, pos)
+        loss, diag, stats = SupConFn.apply(P, labels, pos, float(self._t))
+        self._last = (P.detach(), stats, labels, pos)
         # device-side evidence for the reference's two checks
-        norm_err = (S.diagonal() * self._t - 1).abs().max()
+        norm_err = (diag * self._t - 1).abs().max()
         self._pending.append((norm_err, loss.detach()))
         if not self.defer_checks:
             self.validate()
@@ -103,7 +103,8 @@ class SupConLoss1(nn.Module):
     def _matrices(self):
         if self._last is None:
             raise AttributeError("call the criterion first")
-        S, stats, labels, pos = self._last
+        P, stats, labels, pos = self._last  # (the matrices are inspection aids: the similarity is formed on demand)
+        S = ops.sgemm(P.float().contiguous(), P.float().contiguous(), 1.0 / float(self._t), b_trans=True)
         return ops.supcon_matrices(S, stats, labels, pos)
 
     @property

@@ -191,6 +191,303 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---------------------------------------------------------------- SupCon, fused: S never leaves the CU
+// The 2n x 2n similarity matrix S = P P^T / t (64 MB at the C5 size of 4096 embeddings) and the gradient
+// matrix G of the same size are formed tile by tile in the MFMA accumulators and consumed there:
+//   forward   row sums  l_i = sum_{k != i} exp(S_ik - M),  ps_i = sum_{pos} S_ik,  cnt_i   per 64-row block and
+//             column split, with the reference's global shift M = max S known beforehand: S_ij <= max(S_ii, S_jj)
+//             (Cauchy-Schwarz), so M = max_i |P_i|^2 / t from a row-norm pre-pass -- no online rescaling;
+//   backward  dP_i = (1/t) sum_j G_ij P_j with G_ij = -(g/R)[pos_ij (1/c_i + 1/c_j) - e_ij (1/D_i + 1/D_j)]:
+//             the S tile is recomputed, turned into the G tile in registers, passed through LDS into operand
+//             layout and multiplied with the P_j block that is already resident for the first product.
+// Exact f32 MFMA (v_mfma_f32_32x32x2_f32) as before; fixed summation orders (column splits are summed in order
+// by the finalize / reduce kernels) => bitwise reproducible.  D <= 256.
+constexpr int SC_TM = 64;  // rows / columns of a tile
+// LDS image of a 64-row block of P: the k index split by parity, [k & 1][row][k >> 1] with row pitch D/2 + 4 floats
+// and the two parity planes 16 floats out of step -- the f32 MFMA takes one k per half-wave (lane >> 5), so a lane's
+// operands for four successive k-steps are one ds_read_b128, and a column-wise read (second product of the
+// backward pass) alternates planes lane by lane without bank conflicts
+__device__ __host__ __forceinline__ int sc_ld2(int D) { return D / 2 + 4; }
+__device__ __host__ __forceinline__ int sc_plane(int D) { return SC_TM * sc_ld2(D) + 16; }
+__device__ __host__ __forceinline__ int sc_block_floats(int D) { return 2 * sc_plane(D); }
+
+__global__ void __launch_bounds__(256)
+    supcon_diag_kernel(const float* __restrict__ P, float* __restrict__ diag, int R, int D, float inv_t) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float* pr = P + (size_t)row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s = fmaf(pr[i], pr[i], s);
+  s = wave_sum(s);
+  if (lane == 0) diag[row] = s * inv_t;
+}
+
+__device__ __forceinline__ void sc_stage(const float* __restrict__ P, float* sdst, int r0, int R, int D, int tid) {
+  // rows r0 .. r0+63 of P -> the parity-split image (zeros beyond R)
+  const int dq = D / 4, ld2 = sc_ld2(D), pl = sc_plane(D);
+  for (int e = tid; e < SC_TM * dq; e += 256) {
+    const int rr = e / dq, c4 = (e % dq) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r0 + rr < R) v = *reinterpret_cast<const f32x4*>(P + (size_t)(r0 + rr) * D + c4);
+    float* d = sdst + rr * ld2 + (c4 >> 1);
+    d[0] = v[0], d[1] = v[2];
+    d[pl] = v[1], d[pl + 1] = v[3];
+  }
+}
+
+// S tile (64 x 64) of row block sPi x column block sPj into the four waves' 32x32 accumulators
+__device__ __forceinline__ f32x16 sc_tile(const float* sPi, const float* sPj, int D, int wm, int wn, int i, int kk) {
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  const int ld2 = sc_ld2(D), pl = sc_plane(D);
+  const float* pa = sPi + kk * pl + (wm * 32 + i) * ld2;
+  const float* pb = sPj + kk * pl + (wn * 32 + i) * ld2;
+  for (int k4 = 0; k4 < D / 2; k4 += 4) {  // four k-steps per pair of 16-byte reads
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(pa + k4);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(pb + k4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[q], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// positives with the row side hoisted out of the column loop: folded index (i mod n) and label per row
+struct ScRow {
+  int a;    // row mod n (R = 2n: one conditional subtraction, no division)
+  int lab;  // label of the row (labels mode)
+};
+__device__ __forceinline__ ScRow sc_row(const int32_t* labels, int n, int row) {
+  ScRow q;
+  q.a = row >= n ? row - n : row;
+  q.lab = (labels && row < 2 * n) ? labels[q.a] : 0;
+  return q;
+}
+__device__ __forceinline__ bool sc_pos(const ScRow& r, const ScRow& c, const int32_t* labels, const uint8_t* pm, int n) {
+  return labels ? r.lab == c.lab : pm[(size_t)r.a * n + c.a] != 0;
+}
+
+// grid (row blocks, column splits).  part[split][R][3] = (l, ps, cnt) of the split's columns
+__global__ void __launch_bounds__(256)
+    supcon_fused_fwd_kernel(const float* __restrict__ P, const int32_t* __restrict__ labels,
+                            const uint8_t* __restrict__ pm, const float* __restrict__ Mptr,
+                            float* __restrict__ part, int n, int D, float inv_t, int nsplit) {
+  extern __shared__ float sm[];
+  const int R = 2 * n;
+  float* sPi = sm;
+  float* sPj = sm + sc_block_floats(D);
+  float* sred = sPj;  // reused at the end: [2 wn][64 rows][3]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i = lane & 31, kk = lane >> 5;
+  const int m0 = blockIdx.x * SC_TM;
+  const int ncb = (R + SC_TM - 1) / SC_TM;
+  const int cb0 = (ncb * (int)blockIdx.y) / nsplit, cb1 = (ncb * ((int)blockIdx.y + 1)) / nsplit;
+  const float M = Mptr[0];
+  sc_stage(P, sPi, m0, R, D, tid);
+  float l[16], ps[16], cnt[16];
+  ScRow rws[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    l[q] = ps[q] = cnt[q] = 0.f;
+    rws[q] = sc_row(labels, n, m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kk);
+  }
+  for (int cb = cb0; cb < cb1; ++cb) {
+    const int n0 = cb * SC_TM;
+    __syncthreads();  // previous tile's reads of sPj are done
+    sc_stage(P, sPj, n0, R, D, tid);
+    __syncthreads();
+    const f32x16 acc = sc_tile(sPi, sPj, D, wm, wn, i, kk);
+    const int col = n0 + wn * 32 + i;
+    const ScRow cq = sc_row(labels, n, col);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+      if (row < R && col < R && row != col) {
+        const float s = acc[reg] * inv_t;
+        l[reg] += expf(s - M);
+        if (sc_pos(rws[reg], cq, labels, pm, n)) {
+          ps[reg] += s;
+          cnt[reg] += 1.f;
+        }
+      }
+    }
+  }
+  // row totals: over the 32 lanes that share kk (fixed xor tree), then over the two column halves (wn)
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      l[reg] += __shfl_xor(l[reg], o, 64);
+      ps[reg] += __shfl_xor(ps[reg], o, 64);
+      cnt[reg] += __shfl_xor(cnt[reg], o, 64);
+    }
+  __syncthreads();
+  if (i == 0) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int rr = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+      float* d = sred + (wn * SC_TM + rr) * 3;
+      d[0] = l[reg], d[1] = ps[reg], d[2] = cnt[reg];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < SC_TM * 3; e += 256) {
+    const int rr = e / 3;
+    if (m0 + rr < R) part[((size_t)blockIdx.y * R + m0 + rr) * 3 + e % 3] = sred[e] + sred[SC_TM * 3 + e];
+  }
+}
+
+// single block: M = max diag (grid-wide value for the other kernels), then (after the fused pass) the loss
+__global__ void __launch_bounds__(256)
+    supcon_max_kernel(const float* __restrict__ diag, float* __restrict__ Mout, int R) {
+  __shared__ float smax[256];
+  const int tid = threadIdx.x;
+  float m = -INFINITY;
+  for (int i = tid; i < R; i += 256) m = fmaxf(m, diag[i]);
+  smax[tid] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) smax[tid] = fmaxf(smax[tid], smax[tid + o]);
+    __syncthreads();
+  }
+  if (tid == 0) Mout[0] = smax[0];
+}
+
+__global__ void __launch_bounds__(256)
+    supcon_fused_finalize_kernel(const float* __restrict__ part, const float* __restrict__ Mptr,
+                                 float* __restrict__ row_stats, float* __restrict__ loss, int R, int nsplit) {
+  __shared__ double ssum[256];
+  const int tid = threadIdx.x;
+  const float M = Mptr[0];
+  double acc = 0.0;
+  for (int i = tid; i < R; i += 256) {
+    float li = 0.f, ps = 0.f, cnt = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+      const float* p = part + ((size_t)s * R + i) * 3;
+      li += p[0], ps += p[1], cnt += p[2];
+    }
+    const float Di = li + 1e-16f;
+    acc += (double)(ps / cnt - M - logf(Di));  // cnt == 0 -> NaN like the reference
+    row_stats[i * 4 + 0] = Di;
+    row_stats[i * 4 + 1] = cnt;
+    row_stats[i * 4 + 2] = ps;
+    row_stats[i * 4 + 3] = M;
+  }
+  ssum[tid] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) ssum[tid] += ssum[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) loss[0] = (float)(-ssum[0] / (double)R);
+}
+
+// grid (row blocks, column splits).  dpart[split][R][D] = sum over the split's columns of G_ij P_j
+__global__ void __launch_bounds__(256)
+    supcon_fused_bwd_kernel(const float* __restrict__ P, const int32_t* __restrict__ labels,
+                            const uint8_t* __restrict__ pm, const float* __restrict__ rs,
+                            const float* __restrict__ gscale, float* __restrict__ dpart, int n, int D,
+                            float inv_t, int nsplit) {
+  extern __shared__ float sm[];
+  const int R = 2 * n, ldg = SC_TM + 1;
+  const int ld2 = sc_ld2(D), pl = sc_plane(D);
+  float* sPi = sm;
+  float* sPj = sm + sc_block_floats(D);
+  float* sG = sPj + sc_block_floats(D);
+  float* sRow = sG + SC_TM * ldg;  // [64][2]: 1/D_i, 1/c_i of the row block
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i = lane & 31, kk = lane >> 5;
+  const int m0 = blockIdx.x * SC_TM;
+  const int ncb = (R + SC_TM - 1) / SC_TM;
+  const int cb0 = (ncb * (int)blockIdx.y) / nsplit, cb1 = (ncb * ((int)blockIdx.y + 1)) / nsplit;
+  const float M = rs[3];
+  const float gs = gscale[0] / (float)R;
+  sc_stage(P, sPi, m0, R, D, tid);
+  if (tid < SC_TM) {
+    const int row = m0 + tid;
+    sRow[tid * 2 + 0] = row < R ? 1.f / rs[row * 4 + 0] : 0.f;
+    sRow[tid * 2 + 1] = row < R ? 1.f / rs[row * 4 + 1] : 0.f;
+  }
+  const int nct = (D + 31) / 32;          // 32-wide column tiles of dP
+  f32x16 acc2[4];                          // this wave's column tiles: wn, wn + 2, wn + 4, wn + 6
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc2[c][q] = 0.f;
+  for (int cb = cb0; cb < cb1; ++cb) {
+    const int n0 = cb * SC_TM;
+    __syncthreads();  // previous tile: the second product has read sG and sPj
+    sc_stage(P, sPj, n0, R, D, tid);
+    __syncthreads();
+    const f32x16 acc = sc_tile(sPi, sPj, D, wm, wn, i, kk);
+    const int col = n0 + wn * 32 + i;
+    const ScRow cq = sc_row(labels, n, col);
+    const float iDj = col < R ? 1.f / rs[col * 4 + 0] : 0.f;
+    const float icj = col < R ? 1.f / rs[col * 4 + 1] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int rr = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+      const int row = m0 + rr;
+      float v = 0.f;
+      if (row < R && col < R && row != col) {
+        const float e = expf(acc[reg] * inv_t - M);
+        const float pos = sc_pos(sc_row(labels, n, row), cq, labels, pm, n) ? 1.f : 0.f;
+        v = -gs * (pos * (sRow[rr * 2 + 1] + icj) - e * (sRow[rr * 2 + 0] + iDj));
+      }
+      sG[rr * ldg + wn * 32 + i] = v;
+    }
+    __syncthreads();
+    // dP rows (wm block) += G[64 rows][64 j] * P_j[64 j][D]
+    const float* ga = sG + (wm * 32 + i) * ldg + kk;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ct = wn + 2 * c;
+      if (ct < nct) {
+        const int dcol = ct * 32 + i;  // P_j[j][dcol] sits at [dcol & 1][j][dcol >> 1]
+        const float* pb = sPj + (dcol & 1) * pl + kk * ld2 + (dcol >> 1);
+#pragma unroll 8
+        for (int js = 0; js < SC_TM; js += 2)
+          acc2[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[js], pb[js * ld2], acc2[c], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int ct = wn + 2 * c;
+    const int dcol = ct * 32 + i;
+    if (ct < nct && dcol < D) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+        if (row < R) dpart[((size_t)blockIdx.y * R + row) * D + dcol] = acc2[c][reg];
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    supcon_dpart_reduce_kernel(const float* __restrict__ dpart, float* __restrict__ dP, long total, int nsplit,
+                               float inv_t) {
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += dpart[(size_t)k * total + e];
+    dP[e] = s * inv_t;
+  }
+}
+
+inline int sc_nsplit(int R) {
+  const int rb = (R + SC_TM - 1) / SC_TM;
+  int ns = 256 / rb;
+  if (ns > rb) ns = rb;
+  if (ns < 1) ns = 1;
+  return ns;
+}
+
 // ---------------------------------------------------------------- avg pool
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -373,6 +670,76 @@ int cy_supcon_bwd(const float* P, const int32_t* labels, const uint8_t* pos_mask
                      row_stats, labels, pos_mask, gscale, G, n);
   CY_CHECK_LAUNCH();
   return launch_sgemm(G, P, dP, R, D, R, 1.f / t, 0, st);
+}
+
+size_t cy_supcon_fused_ws_bytes(int n, int D) {
+  if (n <= 0 || D <= 0) return 0;
+  const size_t R = 2 * (size_t)n;
+  const size_t ns = (size_t)sc_nsplit((int)R);
+  // diag[R] + M[4] + forward partials [ns][R][3] | backward partials [ns][R][D]
+  const size_t fwd = ns * R * 3, bwd = ns * R * (size_t)D;
+  return (R + 4 + (fwd > bwd ? fwd : bwd)) * sizeof(float);
+}
+
+int cy_supcon_fused_fwd(const float* P, const int32_t* labels, const uint8_t* pos_mask, float* loss,
+                        float* row_stats, float* diag_out, void* ws, size_t ws_bytes, int n, int D, float t,
+                        void* stream) {
+  if (!P || (!labels && !pos_mask) || !loss || !row_stats || !ws) return CY_ERR_ARG;
+  if (n <= 0 || D <= 0 || D > 256 || D % 8 || !(t > 0.f)) return CY_ERR_SHAPE;
+  if (ws_bytes < cy_supcon_fused_ws_bytes(n, D)) return CY_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int R = 2 * n, ns = sc_nsplit(R), rb = cy_cdiv(R, SC_TM);
+  float* diag = (float*)ws;
+  float* Mv = diag + R;
+  float* part = Mv + 4;
+  hipLaunchKernelGGL(supcon_diag_kernel, dim3(cy_cdiv(R, 4)), dim3(256), 0, st, P, diag, R, D, 1.f / t);
+  CY_CHECK_LAUNCH();
+  hipLaunchKernelGGL(supcon_max_kernel, dim3(1), dim3(256), 0, st, diag, Mv, R);
+  CY_CHECK_LAUNCH();
+  const size_t smem = (size_t)2 * sc_block_floats(D) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(supcon_fused_fwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sc_block_floats(256) * 4) != hipSuccess)
+      return CY_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(supcon_fused_fwd_kernel, dim3(rb, ns), dim3(256), smem, st, P, labels, pos_mask, Mv, part,
+                     n, D, 1.f / t, ns);
+  CY_CHECK_LAUNCH();
+  hipLaunchKernelGGL(supcon_fused_finalize_kernel, dim3(1), dim3(256), 0, st, part, Mv, row_stats, loss, R, ns);
+  CY_CHECK_LAUNCH();
+  if (diag_out && hipMemcpyAsync(diag_out, diag, (size_t)R * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return CY_ERR_LAUNCH;
+  return CY_OK;
+}
+
+int cy_supcon_fused_bwd(const float* P, const int32_t* labels, const uint8_t* pos_mask, const float* row_stats,
+                        const float* gscale, float* dP, void* ws, size_t ws_bytes, int n, int D, float t,
+                        void* stream) {
+  if (!P || (!labels && !pos_mask) || !row_stats || !gscale || !dP || !ws) return CY_ERR_ARG;
+  if (n <= 0 || D <= 0 || D > 256 || D % 8 || !(t > 0.f)) return CY_ERR_SHAPE;
+  if (ws_bytes < cy_supcon_fused_ws_bytes(n, D)) return CY_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int R = 2 * n, ns = sc_nsplit(R), rb = cy_cdiv(R, SC_TM);
+  float* dpart = (float*)ws + R + 4;
+  const size_t smem = ((size_t)2 * sc_block_floats(D) + SC_TM * (SC_TM + 1) + SC_TM * 2) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(supcon_fused_bwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (2 * sc_block_floats(256) + SC_TM * (SC_TM + 1) + SC_TM * 2) * 4) != hipSuccess)
+      return CY_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(supcon_fused_bwd_kernel, dim3(rb, ns), dim3(256), smem, st, P, labels, pos_mask, row_stats,
+                     gscale, dpart, n, D, 1.f / t, ns);
+  CY_CHECK_LAUNCH();
+  const long total = (long)R * D;
+  hipLaunchKernelGGL(supcon_dpart_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, st, dpart, dP, total, ns,
+                     1.f / t);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
 }
 
 int cy_supcon_matrices(const float* S, const float* row_stats, const int32_t* labels,

@@ -11,7 +11,7 @@ from pathlib import Path
 
 CY_F32, CY_BF16, CY_F16 = 0, 1, 2
 CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2 = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _ERRORS = {-1: "CY_ERR_ARG (bad/NULL argument)", -2: "CY_ERR_SHAPE (unsupported shape)",
            -3: "CY_ERR_DTYPE (unsupported dtype)", -4: "CY_ERR_LAUNCH (HIP launch failed)",
@@ -110,6 +110,9 @@ _SIGS = {
     "cy_l2norm_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "cy_supcon_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "cy_supcon_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "cy_supcon_fused_ws_bytes": (c_size_t, [c_int, c_int]),
+    "cy_supcon_fused_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_float, _P]),
+    "cy_supcon_fused_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_float, _P]),
     "cy_supcon_matrices": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "cy_sgemm": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
     "cy_affine_nearest_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

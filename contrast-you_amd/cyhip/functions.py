@@ -499,22 +499,33 @@ class L2NormFn(torch.autograd.Function):
 
 
 class SupConFn(torch.autograd.Function):
-    """SupConLoss1._forward (contrastyou/losses/contrastive.py:52-100) on P = cat(z1, z2)."""
+    """SupConLoss1._forward (contrastyou/losses/contrastive.py:52-100) on P = cat(z1, z2).  Returns the loss, the
+    diagonal of the similarity matrix (|P_i|^2 / t: what the reference's unit-norm assertion inspects) and the row
+    statistics; for D <= 256 the 2n x 2n matrix itself exists only tile-wise inside the kernels."""
 
     @staticmethod
     def forward(ctx, P: Tensor, labels: Optional[Tensor], pos_mask: Optional[Tensor], t: float):
         ops.require_gpu(P)
         P = P.float().contiguous()
-        loss, S, stats = ops.supcon_fwd(P, labels, pos_mask, t)
-        ctx.save_for_backward(P, S, stats)
+        ctx.fused = ops.supcon_fused_ok(P)
+        if ctx.fused:
+            loss, diag, stats = ops.supcon_fwd_fused(P, labels, pos_mask, t)
+            ctx.save_for_backward(P, stats)
+        else:
+            loss, S, stats = ops.supcon_fwd(P, labels, pos_mask, t)
+            diag = S.diagonal().clone()
+            ctx.save_for_backward(P, stats, S)
         ctx.labels, ctx.pos_mask, ctx.t = labels, pos_mask, t
-        ctx.mark_non_differentiable(S, stats)
-        return loss, S, stats
+        ctx.mark_non_differentiable(diag, stats)
+        return loss, diag, stats
 
     @staticmethod
-    def backward(ctx, g: Tensor, _gS, _gstats):
-        P, S, stats = ctx.saved_tensors
+    def backward(ctx, g: Tensor, _gd, _gstats):
         gs = g.reshape(1).float().contiguous()
+        if ctx.fused:
+            P, stats = ctx.saved_tensors
+            return ops.supcon_bwd_fused(P, ctx.labels, ctx.pos_mask, stats, gs, ctx.t), None, None, None
+        P, stats, S = ctx.saved_tensors
         return ops.supcon_bwd(P, ctx.labels, ctx.pos_mask, S, stats, gs, ctx.t), None, None, None
 
 

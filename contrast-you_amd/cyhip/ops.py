@@ -865,6 +865,37 @@ def supcon_bwd(P: Tensor, labels, pos_mask, S: Tensor, stats: Tensor, gscale: Te
     return dP
 
 
+SUPCON_FUSED = _os.environ.get("CY_SUPCON_FUSED", "1") != "0"
+
+
+def supcon_fused_ok(P: Tensor) -> bool:
+    return SUPCON_FUSED and P.shape[1] <= 256 and P.shape[1] % 8 == 0
+
+
+def supcon_fwd_fused(P: Tensor, labels: Optional[Tensor], pos_mask: Optional[Tensor], t: float):
+    """loss, diag(S), row statistics; the similarity matrix is never materialised (csrc/cy_contrast.hip)"""
+    R, D = P.shape
+    n = R // 2
+    nbytes = _lib.load().cy_supcon_fused_ws_bytes(n, D)
+    ws = _ws(nbytes, P.device)
+    stats = _f32(R * 4, P.device).view(R, 4)
+    diag = _f32(R, P.device)
+    loss = _f32(1, P.device)
+    _lib.call("cy_supcon_fused_fwd", P.data_ptr(), _ptr(labels), _ptr(pos_mask), loss.data_ptr(), stats.data_ptr(),
+              diag.data_ptr(), ws.data_ptr(), nbytes, n, D, float(t), _stream())
+    return loss.view(()), diag, stats
+
+
+def supcon_bwd_fused(P: Tensor, labels, pos_mask, stats: Tensor, gscale: Tensor, t: float) -> Tensor:
+    R, D = P.shape
+    nbytes = _lib.load().cy_supcon_fused_ws_bytes(R // 2, D)
+    ws = _ws(nbytes, P.device)
+    dP = torch.empty_like(P)
+    _lib.call("cy_supcon_fused_bwd", P.data_ptr(), _ptr(labels), _ptr(pos_mask), stats.data_ptr(), gscale.data_ptr(),
+              dP.data_ptr(), ws.data_ptr(), nbytes, R // 2, D, float(t), _stream())
+    return dP
+
+
 def supcon_matrices(S: Tensor, stats: Tensor, labels, pos_mask):
     R = S.shape[0]
     outs = [_f32(R * R, S.device).view(R, R) for _ in range(4)]

@@ -311,6 +311,18 @@ int cy_supcon_bwd(const float* P, const int32_t* labels, const uint8_t* pos_mask
                   float t, void* stream);
 /* materialise sim_logits (S-M), sim_exp, pos_mask, neg_mask, each f32 [R][R]
  * (contrastive.py:79-82; read only for the TensorBoard figures). any may be NULL */
+/* The same loss and gradient with S (and the gradient matrix) formed tile by tile in the MFMA accumulators and
+ * never written: forward = row sums with the global shift M = max_i |P_i|^2 / t (the maximum of S lies on its
+ * diagonal), backward = (1/t) G P with the S tile recomputed.  D <= 256, D % 8 == 0.  row_stats as above;
+ * diag_out (optional) receives S_ii = |P_i|^2 / t, what SupConLoss1's unit-norm assertion looks at.
+ * ws: cy_supcon_fused_ws_bytes(n, D) bytes, the same buffer for both calls. */
+size_t cy_supcon_fused_ws_bytes(int n, int D);
+int cy_supcon_fused_fwd(const float* P, const int32_t* labels, const uint8_t* pos_mask, float* loss,
+                        float* row_stats, float* diag_out, void* ws, size_t ws_bytes, int n, int D, float t,
+                        void* stream);
+int cy_supcon_fused_bwd(const float* P, const int32_t* labels, const uint8_t* pos_mask, const float* row_stats,
+                        const float* gscale, float* dP, void* ws, size_t ws_bytes, int n, int D, float t,
+                        void* stream);
 int cy_supcon_matrices(const float* S, const float* row_stats, const int32_t* labels,
                        const uint8_t* pos_mask, float* sim_logits, float* sim_exp,
                        float* pos_out, float* neg_out, int n, void* stream);

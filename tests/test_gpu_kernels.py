@@ -403,6 +403,60 @@ def test_supcon_c5_size_against_oracle():
     assert_close(dP, torch.cat([a.grad, b.grad]).float(), 1e-4, "C5 supcon dP")
 
 
+def test_supcon_fused_against_reference_goldens(golden_dir):
+    """the fused kernels (similarity / gradient matrices never materialised) against the reference's own vectors"""
+    ops = _ops()
+    gld = np.load(golden_dir / "heads_losses.npz")
+    z1, z2 = torch.from_numpy(gld["sc_z1"]), torch.from_numpy(gld["sc_z2"])
+    P = torch.cat([z1, z2]).to(DEV)
+    assert ops.supcon_fused_ok(P)
+    n = z1.shape[0]
+    gs = torch.ones(1, device=DEV)
+    for tag, target in (("simclr", list(range(n))), ("partition", [0, 1, 2, 0, 1, 2, 0, 1]),
+                        ("patient", [0, 1, 2, 3, 3, 4, 5, 6])):
+        lab = torch.tensor(target, dtype=torch.int32, device=DEV)
+        loss, diag, stats = ops.supcon_fwd_fused(P, lab, None, 0.07)
+        assert abs(loss.item() - float(gld[f"sc_{tag}_loss"])) < 1e-5 * abs(float(gld[f"sc_{tag}_loss"])), tag
+        assert_close(diag, (P * P).sum(1).cpu() / 0.07, 1e-6, "diag")
+        dP = ops.supcon_bwd_fused(P, lab, None, stats, gs, 0.07)
+        assert_close(dP[:n], torch.from_numpy(gld[f"sc_{tag}_dz1"]), 2e-4, f"{tag} dz1")
+        assert_close(dP[n:], torch.from_numpy(gld[f"sc_{tag}_dz2"]), 2e-4, f"{tag} dz2")
+    pm = torch.from_numpy(gld["sc_mask"]).to(torch.uint8).to(DEV)
+    loss, diag, stats = ops.supcon_fwd_fused(P, None, pm, 0.07)
+    assert abs(loss.item() - float(gld["sc_mask_loss"])) < 1e-5 * abs(float(gld["sc_mask_loss"]))
+    dP = ops.supcon_bwd_fused(P, None, pm, stats, gs, 0.07)
+    assert_close(dP[:n], torch.from_numpy(gld["sc_mask_dz1"]), 2e-4, "mask dz1")
+
+
+@pytest.mark.parametrize("n,D", [(256, 256), (2048, 256), (37, 64), (100, 128), (65, 24)])
+def test_supcon_fused_against_oracle_and_unfused(n, D):
+    """row counts that are not multiples of the 64-row tile, D below 256, the C5 size (4096 embeddings): loss and
+    gradient against the f64 oracle, and against the kernels that materialise S; twice for reproducibility"""
+    ops = _ops()
+    from oracle.losses import supcon_loss
+    g = torch.Generator().manual_seed(1000 + n)
+    z1 = F.normalize(torch.randn(n, D, generator=g), dim=1)
+    z2 = F.normalize(z1 + 0.4 * torch.randn(n, D, generator=g), dim=1)
+    target = [i % 3 for i in range(n)]
+    a, b = z1.double().requires_grad_(True), z2.double().requires_grad_(True)
+    ref = supcon_loss(a, b, target=target)
+    ref.backward()
+    P = torch.cat([z1, z2]).to(DEV)
+    lab = torch.tensor(target, dtype=torch.int32, device=DEV)
+    gsc = torch.full((1,), 0.7, device=DEV)
+    loss, diag, stats = ops.supcon_fwd_fused(P, lab, None, 0.07)
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item()), (loss.item(), ref.item())
+    dP = ops.supcon_bwd_fused(P, lab, None, stats, gsc, 0.07)
+    assert_close(dP, 0.7 * torch.cat([a.grad, b.grad]).float(), 1e-4, "fused dP vs oracle")
+    loss_u, S, stats_u = ops.supcon_fwd(P, lab, None, 0.07)
+    assert abs(loss.item() - loss_u.item()) < 1e-6 * abs(loss_u.item())
+    assert_close(stats[:, :3], cpu(stats_u[:, :3]), 1e-5, "row statistics")
+    assert_close(dP, cpu(ops.supcon_bwd(P, lab, None, S, stats_u, gsc, 0.07)), 1e-5, "fused dP vs unfused")
+    loss2, _, stats2 = ops.supcon_fwd_fused(P, lab, None, 0.07)
+    dP2 = ops.supcon_bwd_fused(P, lab, None, stats2, gsc, 0.07)
+    assert torch.equal(loss, loss2) and torch.equal(dP, dP2)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_affine_fwd_bwd(dtype):
     ops = _ops()
