@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from cyhip import ops
-from cyhip.functions import (AdaptiveAvgPoolFn, AvgPoolFn, DenseProjHiddenFn, GroupSoftmaxFn, HeadFn, L2NormFn,
+from cyhip.functions import (AdaptiveAvgPoolFn, ClusterHeadFn, AvgPoolFn, DenseProjHiddenFn, GroupSoftmaxFn, HeadFn, L2NormFn,
                              LinearFn)
 
 from .nn import Flatten, Identical, Normalize, SoftmaxWithT
@@ -202,6 +202,13 @@ class DenseClusterHead(_ClusterBase):
     def forward(self, features: Tensor) -> List[Tensor]:
         ops.require_gpu(features)
         n, _, h, w_ = features.shape
+        if (self._head_type == "linear" and not self._normalize
+                and ops.cluster_head_ok(features.shape[1], self._num_subheads, self._num_clusters)):
+            # conv1x1 + per-sub-head softmax in one pass on the matrix cores; the logits are never written
+            w, b = self._stacked(0)
+            rows = ops.to_nhwc(features).permute(0, 2, 3, 1).reshape(n * h * w_, -1)
+            probs = ClusterHeadFn.apply(rows, w, b, self._num_subheads, self._num_clusters, float(self._T))
+            return [p.view(n, h, w_, self._num_clusters).permute(0, 3, 1, 2) for p in probs.unbind(0)]
         if self._head_type == "linear":
             w, b = self._stacked(0)
             logits = HeadFn.apply(features, w.view(w.shape[0], w.shape[1], 1, 1), b)  # [n, S*k, h, w] NHWC f32

@@ -132,6 +132,10 @@ _SIGS = {
     "cy_adaptive_avgpool_bwd": (c_int, [_P, _P] + [c_int] * 8 + [_P]),
     "cy_gather_rows_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "cy_gather_rows_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "cy_cluster_head_fwd": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    "cy_cluster_head_bwd_ws_bytes": (c_size_t, [c_long, c_int]),
+    "cy_cluster_head_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_long, c_int, c_int, c_int, c_int, c_float, c_int, _P,
+                                    c_size_t, _P]),
     "cy_group_softmax_fwd": (c_int, [_P, _P, c_long, c_int, c_int, c_float, _P]),
     "cy_group_softmax_bwd": (c_int, [_P, _P, _P, c_long, c_int, c_int, c_float, _P]),
     "cy_joint_ws_bytes": (c_size_t, [c_int] * 5),

@@ -629,6 +629,33 @@ class GroupSoftmaxFn(torch.autograd.Function):
         return ops.group_softmax_bwd(probs, g.float().contiguous(), ctx.T), None, None, None
 
 
+class ClusterHeadFn(torch.autograd.Function):
+    """stacked 1x1 conv / linear (S*k <= 128 outputs) + per-sub-head softmax(./T) in one pass on the f32 MFMA:
+    rows x [M, C] -> probs [S, M, k]; the logits never reach memory (csrc/cy_cluster_head.hip;
+    contrastyou/projectors/heads.py:125-173, projectors/nn.py:35-44)"""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor], S: int, k: int, T: float):
+        ops.require_gpu(x, w)
+        x = x.contiguous()
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            x = x.float()
+        w2 = w.detach().reshape(S * k, -1).float().contiguous()
+        probs = ops.cluster_head_fwd(x, w2, None if b is None else b.detach().float().contiguous(), S, k, T)
+        ctx.save_for_backward(x, w2, probs)
+        ctx.T, ctx.w_shape, ctx.has_bias = T, w.shape, b is not None
+        return probs
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, w2, probs = ctx.saved_tensors
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dx, dw, db = ops.cluster_head_bwd(x, w2, probs, g.float().contiguous(), ctx.T, need_dx, need_dw)
+        return (dx, dw.view(ctx.w_shape) if (dw is not None and ctx.needs_input_grad[1]) else None,
+                db if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None, None, None)
+
+
 class IIDFn(torch.autograd.Function):
     """joint of two probability maps + information loss in one autograd node.
     x1, x2: f32 [N,H,W,k] contiguous (vectors: H=W=1).  mode 0/1: IIDSegmentationLoss with padding

@@ -1021,6 +1021,35 @@ def gather_rows_bwd(dout: Tensor, idx: Tensor, rows: int) -> Tensor:
 
 
 # --------------------------------------------------------------------------- cluster heads / discrete MI
+def cluster_head_ok(C: int, S: int, k: int) -> bool:
+    return C in (32, 64) and S * k <= 128 and k <= 32
+
+
+def cluster_head_fwd(x: Tensor, w: Tensor, b: Optional[Tensor], S: int, k: int, T: float = 1.0) -> Tensor:
+    """x: [M, C] rows (an NHWC map flattened over pixels) -> probs f32 [S, M, k] (csrc/cy_cluster_head.hip)"""
+    require_gpu(x, w)
+    M, Cc = x.shape
+    probs = _f32(S * M * k, x.device).view(S, M, k)
+    _lib.call("cy_cluster_head_fwd", x.data_ptr(), w.data_ptr(), _ptr(b), probs.data_ptr(), M, Cc, S * k, S, k,
+              1.0 / T, dtype_code(x.dtype), _stream())
+    return probs
+
+
+def cluster_head_bwd(x: Tensor, w: Tensor, probs: Tensor, dprobs: Tensor, T: float, need_dx: bool, need_dw: bool):
+    S, M, k = probs.shape
+    Cc = x.shape[1]
+    dx = torch.empty_like(x) if need_dx else None
+    dw = db = ws = None
+    nbytes = 0
+    if need_dw:
+        dw, db = _f32(S * k * Cc, x.device).view(S * k, Cc), _f32(S * k, x.device)
+        nbytes = _lib.load().cy_cluster_head_bwd_ws_bytes(M, Cc)
+        ws = _ws(nbytes, x.device)
+    _lib.call("cy_cluster_head_bwd", x.data_ptr(), w.data_ptr(), probs.data_ptr(), dprobs.data_ptr(), _ptr(dx),
+              _ptr(dw), _ptr(db), M, Cc, S * k, S, k, 1.0 / T, dtype_code(x.dtype), _ptr(ws), nbytes, _stream())
+    return dx, dw, db
+
+
 def group_softmax_fwd(logits: Tensor, S: int, k: int, T: float = 1.0) -> Tensor:
     """logits f32 [M, S*k] -> probs f32 [S, M, k]"""
     require_gpu(logits)

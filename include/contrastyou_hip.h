@@ -421,6 +421,20 @@ int cy_gather_rows_bwd(const float* dout, const int32_t* idx, float* dsrc, int M
  * (contrastyou/projectors/heads.py:44-78,125-173; contrastyou/losses/discreteMI.py:
  * 90-170,201-261).  Probability maps are NHWC f32 [N][H][W][k], k <= 64.
  * ------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------
+ * Stacked cluster heads in one pass (DenseClusterHead / ClusterHead, head_type="linear",
+ * projectors/heads.py:125-173): probs[S][M][k] = softmax over each sub-head's k of (W x + b) / T with
+ * K = S*k <= 128 outputs and C in {32, 64} inputs, rows x[M][C] (bf16 / f16 / f32, NHWC pixels); exact f32
+ * MFMA; the logits are never written.  Backward from (probs, dprobs): dx[M][C] (dtype of x; NULL: skipped),
+ * dw[K][C], db[K] (NULL: skipped; ws from cy_cluster_head_bwd_ws_bytes).
+ * ------------------------------------------------------------------------ */
+int cy_cluster_head_fwd(const void* x, const float* w, const float* b, float* probs, long M, int C, int K, int S,
+                        int k, float invT, int dtype, void* stream);
+size_t cy_cluster_head_bwd_ws_bytes(long M, int C);
+int cy_cluster_head_bwd(const void* x, const float* w, const float* probs, const float* dprobs, void* dx, float* dw,
+                        float* db, long M, int C, int K, int S, int k, float invT, int dtype, void* ws,
+                        size_t ws_bytes, void* stream);
+
 /* logits [M][S*k] -> probs [S][M][k] = softmax(logits*invT) within each of the
  * S sub-heads (SoftmaxWithT, projectors/nn.py:35-44); S=1 is a row softmax. */
 int cy_group_softmax_fwd(const float* logits, float* probs, long M, int S, int k, float invT,

@@ -176,6 +176,33 @@ def test_cluster_head_gradients_match_oracle():
         close(head._headers[i][0].bias.grad, sdo[i]["0.bias"].grad, 1e-4, f"db{i}")
 
 
+@pytest.mark.parametrize("C,S,k,M,dt", [(64, 10, 10, 1000, torch.float32), (32, 10, 10, 4133, torch.bfloat16),
+                                         (32, 3, 7, 77, torch.float16), (64, 4, 32, 260, torch.float32)])
+def test_cluster_head_one_pass_kernels(C, S, k, M, dt):
+    """cy_cluster_head_fwd / _bwd (conv1x1 + per-sub-head softmax on the f32 MFMA, logits never written) against
+    torch on the same rows: ragged pixel counts, 64 input channels, k up to 32, 16-bit inputs, temperature"""
+    from cyhip import ops
+    gen = torch.Generator().manual_seed(100 + M)
+    x = torch.randn(M, C, generator=gen).to(dt)
+    w = torch.randn(S * k, C, generator=gen) * 0.3
+    b = torch.randn(S * k, generator=gen) * 0.1
+    g_ = torch.randn(S, M, k, generator=gen)
+    Tt = 0.7
+    xr, wr, br = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.softmax((xr @ wr.t() + br).view(M, S, k) / Tt, dim=2).permute(1, 0, 2)
+    (ref * g_).sum().backward()
+    assert ops.cluster_head_ok(C, S, k)
+    xd = x.to(DEV)
+    probs = ops.cluster_head_fwd(xd, w.to(DEV), b.to(DEV), S, k, Tt)
+    close(probs, ref, 1e-5, "probs")
+    dx, dw, db = ops.cluster_head_bwd(xd, w.to(DEV), probs, g_.to(DEV), Tt, True, True)
+    close(dx, xr.grad, 1e-4 if dt == torch.float32 else 1e-2, "dx")
+    close(dw, wr.grad, 1e-4, "dw")
+    close(db, br.grad, 1e-4, "db")
+    dx2, dw2, db2 = ops.cluster_head_bwd(xd, w.to(DEV), probs, g_.to(DEV), Tt, True, True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dx, dx2)
+
+
 def test_iid_losses_match_reference_vectors(g):
     from contrastyou.losses.discreteMI import IIDLoss, IIDSegmentationLoss, compute_joint
     a = T(g["iid_a"]).to(DEV).requires_grad_(True)

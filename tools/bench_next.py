@@ -78,6 +78,12 @@ def main():
     line("  dx only", ms)
     ms = timed(lambda: ops.head_bwd(x, w, dl, False, True), iters=3)
     line("  dw only", ms)
+    rows = x.permute(0, 2, 3, 1).reshape(npix, c)
+    w2 = w.reshape(S * k, c).contiguous()
+    ms = timed(lambda: ops.cluster_head_fwd(rows, w2, b, S, k))
+    line("cluster_head_fwd (conv1x1 + softmax, one pass)", ms, xbytes + npix * S * k * 4, 2.0 * npix * c * S * k)
+    ms = timed(lambda: ops.cluster_head_bwd(rows, w2, probs, dp, 1.0, True, True))
+    line("cluster_head_bwd (softmax bwd + dx + dw, one pass)", ms, 2 * xbytes + 2 * npix * S * k * 4, 6.0 * npix * c * S * k)
     half = n // 2
     a1 = probs[0, : half * hw * hw].view(half, hw, hw, k)
     a2 = probs[0, half * hw * hw:].view(half, hw, hw, k)
