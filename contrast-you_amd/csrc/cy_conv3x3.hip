@@ -786,6 +786,7 @@ __global__ void __launch_bounds__(256)
   // block: fixed order => deterministic)
   __shared__ float sw[9 * 4 * 64];  // [tap][ci][co], Cout <= 64
   __shared__ float sred[4 * 2 * 64];  // [wave][sum | sumsq][cout]
+  extern __shared__ float sx[];        // [Cin][rows of this block's pixel range + 2][W + 2], zero left / right columns
   const int tid = threadIdx.x;
   for (int i = tid; i < 9 * Cin * Cout; i += 256) {
     const int co = i % Cout;
@@ -804,23 +805,48 @@ __global__ void __launch_bounds__(256)
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
-  for (long p = p0 + tid / CG; p < p1; p += ppb) {
+  // The nine taps of a pixel are nine 4-byte global loads in the first version -- 0.9 M wave-level load
+  // instructions per launch, four threads per pixel repeating them: the kernel ran at 1.4 TB/s of output.  The
+  // input rows of the block's pixel range (+ one row above and below) are staged in LDS once, coalesced.
+  const int W2 = W + 2;
+  const int g0 = p0 < npix ? (int)(p0 / W) : 0;
+  const int g1 = p1 > p0 ? (int)((p1 - 1) / W) : g0;
+  const int nrows = g1 - g0 + 3;
+  for (int ci = 0; ci < Cin; ++ci)
+    for (int r = tid / 64; r < nrows; r += 4) {  // a wave per row
+      const int g = g0 - 1 + r;
+      const bool rok = g >= 0 && g < N * H;
+      const int n_ = rok ? g / H : 0;
+      const float* xr = x + (((size_t)n_ * Cin + ci) * H + (g - n_ * H)) * W;
+      float* dst = sx + ((size_t)ci * nrows + r) * W2;
+      for (int c = tid & 63; c < W2; c += 64) dst[c] = (rok && c >= 1 && c <= W) ? xr[c - 1] : 0.f;
+    }
+  __syncthreads();
+  // pixel coordinates advance incrementally.  (Also tried on top of the LDS image, both slower or equal: this
+  // thread's 72 weights in registers for Cin = 1 -- 55.7 us; two pixels per thread sharing every weight read --
+  // 49.7 us; as below 46.9 us per launch on average over the two batch sizes, 56.1 before the LDS image.)
+  long p = p0 + tid / CG;
+  int wq, hq, n;
+  {
+    const unsigned pu = (unsigned)(p < npix ? p : 0);
+    const unsigned row = pu / (unsigned)W;
+    wq = (int)(pu - row * (unsigned)W);
+    n = (int)(row / (unsigned)H);
+    hq = (int)(row - (unsigned)n * (unsigned)H);
+  }
+  const int dq = ppb / W, dr = ppb - dq * W;  // ppb = dq rows + dr pixels
+  for (; p < p1; p += ppb) {
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    // (32-bit index arithmetic: 64-bit divisions cost more than the 72 FMAs of a pixel)
-    const unsigned pu = (unsigned)p;
-    const unsigned row = pu / (unsigned)W;
-    const int wq = (int)(pu - row * (unsigned)W);
-    const int n = (int)(row / (unsigned)H);
-    const int hq = (int)(row - (unsigned)n * (unsigned)H);
+    const int rc = n * H + hq - g0 + 1;  // LDS row of this pixel
     for (int ci = 0; ci < Cin; ++ci) {
-      const float* xp = x + ((size_t)n * Cin + ci) * H * W;
+      const float* xc = sx + ((size_t)ci * nrows + rc) * W2 + wq + 1;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const int hh = hq + tap / 3 - 1, ww = wq + tap % 3 - 1;
-        float xv = 0.f;
-        if (hh >= 0 && hh < H && ww >= 0 && ww < W) xv = xp[(size_t)hh * W + ww];
+        const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+        const int hh = hq + dh;
+        const float xv = (hh >= 0 && hh < H) ? xc[dh * W2 + dw] : 0.f;  // (left / right: the zero columns)
         const float* wr = sw + (tap * Cin + ci) * Cout + cg * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wr[j], acc[j]);
@@ -839,6 +865,10 @@ __global__ void __launch_bounds__(256)
       s1[j] += q;
       s2[j] += q * q;
     }
+    wq += dr;
+    hq += dq;
+    if (wq >= W) wq -= W, ++hq;
+    while (hq >= H) hq -= H, ++n;
   }
   if (stats) {
     // lanes of a wave that share a cout group (xor-shuffles over the pixel bits), then the four waves
@@ -1132,14 +1162,20 @@ int cy_conv3x3_first_fwd(const float* x, const float* w, void* out, float* stats
   const int np = cy_conv3x3_first_num_partials(N, H, W, Cout);
   if (np < 0) return np;
   hipStream_t st = (hipStream_t)stream;
+  // LDS image of the input rows a block touches (the kernel's own range arithmetic, upper bound)
+  const long npix = (long)N * H * W;
+  const int ppb = 256 / (Cout / 8);
+  const long per = ((npix + np - 1) / np + ppb - 1) / ppb * ppb;
+  const size_t smem = (size_t)Cin * (per / W + 4) * (W + 2) * sizeof(float);
+  if (smem > 48 * 1024) return CY_ERR_SHAPE;
   if (out_dtype == CY_BF16)
-    hipLaunchKernelGGL(conv3x3_first_kernel<bf16>, dim3(np), dim3(256), 0, st, x, w, (bf16*)out,
+    hipLaunchKernelGGL(conv3x3_first_kernel<bf16>, dim3(np), dim3(256), smem, st, x, w, (bf16*)out,
                        stats, N, Cin, H, W, Cout);
   else if (out_dtype == CY_F16)
-    hipLaunchKernelGGL(conv3x3_first_kernel<f16>, dim3(np), dim3(256), 0, st, x, w, (f16*)out,
+    hipLaunchKernelGGL(conv3x3_first_kernel<f16>, dim3(np), dim3(256), smem, st, x, w, (f16*)out,
                        stats, N, Cin, H, W, Cout);
   else if (out_dtype == CY_F32)
-    hipLaunchKernelGGL(conv3x3_first_kernel<float>, dim3(np), dim3(256), 0, st, x, w, (float*)out,
+    hipLaunchKernelGGL(conv3x3_first_kernel<float>, dim3(np), dim3(256), smem, st, x, w, (float*)out,
                        stats, N, Cin, H, W, Cout);
   else
     return CY_ERR_DTYPE;

@@ -717,6 +717,8 @@ __global__ void __launch_bounds__(256)
                        float* __restrict__ ws, int N, int Cin, int H, int W, int Cout) {
   // thread = (pixel lane, group of 8 couts); accumulates 9 taps x 8 couts for one ci at a time
   __shared__ float sred[4 * 9 * 64];  // [wave][tap][cout], Cout <= 64
+  extern __shared__ float sx[];        // [rows of this block's pixel range + 2][W + 2] of the current ci (see
+                                       // conv3x3_first_kernel: nine 4-byte global loads per pixel otherwise)
   const int CG = Cout / 8;
   const int rows = 256 / CG;
   const int tid = threadIdx.x;
@@ -731,12 +733,31 @@ __global__ void __launch_bounds__(256)
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-    for (long p = p0 + prow; p < p1; p += rows) {
-      const unsigned pu = (unsigned)p;  // 32-bit index arithmetic (npix < 2^31 checked by the host)
+    const int W2 = W + 2;
+    const int g0 = p0 < npix ? (int)(p0 / W) : 0;
+    const int g1 = p1 > p0 ? (int)((p1 - 1) / W) : g0;
+    const int nrows = g1 - g0 + 3;
+    __syncthreads();  // (the previous ci's image is no longer read)
+    for (int r = tid / 64; r < nrows; r += 4) {  // a wave per row
+      const int g = g0 - 1 + r;
+      const bool rok = g >= 0 && g < N * H;
+      const int n_ = rok ? g / H : 0;
+      const float* xr = x + (((size_t)n_ * Cin + ci) * H + (g - n_ * H)) * W;
+      float* dst = sx + (size_t)r * W2;
+      for (int c = tid & 63; c < W2; c += 64) dst[c] = (rok && c >= 1 && c <= W) ? xr[c - 1] : 0.f;
+    }
+    __syncthreads();
+    long p = p0 + prow;
+    int wq, hq, n;
+    {
+      const unsigned pu = (unsigned)(p < npix ? p : 0);  // (npix < 2^31 checked by the host)
       const unsigned row = pu / (unsigned)W;
-      const int wq = (int)(pu - row * (unsigned)W);
-      const int n = (int)(row / (unsigned)H);
-      const int hq = (int)(row - (unsigned)n * (unsigned)H);
+      wq = (int)(pu - row * (unsigned)W);
+      n = (int)(row / (unsigned)H);
+      hq = (int)(row - (unsigned)n * (unsigned)H);
+    }
+    const int dq = rows / W, dr = rows - dq * W;
+    for (; p < p1; p += rows) {
       float d[8];
       if constexpr (sizeof(T) == 2) {
         Chunk<T>::unpack(ld16(dy + p * Cout + cg * 8), d);
@@ -744,15 +765,19 @@ __global__ void __launch_bounds__(256)
         Chunk<float>::unpack(ld16(dy + p * Cout + cg * 8), d);
         Chunk<float>::unpack(ld16(dy + p * Cout + cg * 8 + 4), d + 4);
       }
-      const float* xp = x + ((size_t)n * Cin + ci) * H * W;
+      const float* xc = sx + (size_t)(n * H + hq - g0 + 1) * W2 + wq + 1;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        const int hh = hq + t / 3 - 1, ww = wq + t % 3 - 1;
-        float xv = 0.f;
-        if (hh >= 0 && hh < H && ww >= 0 && ww < W) xv = xp[(size_t)hh * W + ww];
+        const int dh = t / 3 - 1, dw = t % 3 - 1;
+        const int hh = hq + dh;
+        const float xv = (hh >= 0 && hh < H) ? xc[dh * W2 + dw] : 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[t][j] = fmaf(xv, d[j], acc[t][j]);
       }
+      wq += dr;
+      hq += dq;
+      if (wq >= W) wq -= W, ++hq;
+      while (hq >= H) hq -= H, ++n;
     }
     // block reduction over the pixel lanes: xor-shuffles across the lanes of a wave that share a
     // cout group (CG is a power of two), then the four waves through LDS
@@ -941,14 +966,17 @@ int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int accumu
   if (ws_bytes < cy_conv3x3_first_wgrad_ws_bytes(N, Cin, H, W, Cout)) return CY_ERR_WORKSPACE;
   const int nblk = first_wgrad_blocks((long)N * H * W);
   hipStream_t st = (hipStream_t)stream;
+  const long per = ((long)N * H * W + nblk - 1) / nblk;
+  const size_t smem = (size_t)(per / W + 4) * (W + 2) * sizeof(float);
+  if (smem > 48 * 1024) return CY_ERR_SHAPE;
   if (dy_dtype == CY_BF16)
-    hipLaunchKernelGGL(first_wgrad_kernel<bf16>, dim3(nblk), dim3(256), 0, st, x, (const bf16*)dy,
+    hipLaunchKernelGGL(first_wgrad_kernel<bf16>, dim3(nblk), dim3(256), smem, st, x, (const bf16*)dy,
                        (float*)ws, N, Cin, H, W, Cout);
   else if (dy_dtype == CY_F16)
-    hipLaunchKernelGGL(first_wgrad_kernel<f16>, dim3(nblk), dim3(256), 0, st, x, (const f16*)dy,
+    hipLaunchKernelGGL(first_wgrad_kernel<f16>, dim3(nblk), dim3(256), smem, st, x, (const f16*)dy,
                        (float*)ws, N, Cin, H, W, Cout);
   else if (dy_dtype == CY_F32)
-    hipLaunchKernelGGL(first_wgrad_kernel<float>, dim3(nblk), dim3(256), 0, st, x,
+    hipLaunchKernelGGL(first_wgrad_kernel<float>, dim3(nblk), dim3(256), smem, st, x,
                        (const float*)dy, (float*)ws, N, Cin, H, W, Cout);
   else
     return CY_ERR_DTYPE;
