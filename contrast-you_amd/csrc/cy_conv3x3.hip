@@ -896,10 +896,15 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-int first_conv_blocks(long npix, int Cout) {
+int first_conv_blocks(long npix, int Cout, int W) {
   const int ppb = 256 / (Cout / 8);
   long b = (npix + ppb - 1) / ppb;
   if (b > 2048) b = 2048;  // 8 blocks per CU: a few hundred pixels each at the U-Net's sizes
+  // ... but never more image rows per block than its LDS image holds (96 KB, up to four input channels)
+  const long rows_max = (96 * 1024 / 4) / (4 * (W + 2)) - 4;
+  const long need = (npix + rows_max * W - 1) / (rows_max > 0 ? rows_max * W : 1);
+  if (rows_max < 1) return -1;
+  if (b < need) b = need;
   return (int)b;
 }
 
@@ -1151,7 +1156,8 @@ int cy_conv3x3_pc_fwd(const cy_conv_desc* d, const void* src1, const void* src2,
 
 int cy_conv3x3_first_num_partials(int N, int H, int W, int Cout) {
   if (Cout % 8 || Cout > 64 || 256 % (Cout / 8)) return CY_ERR_SHAPE;
-  return first_conv_blocks((long)N * H * W, Cout);
+  const int b = first_conv_blocks((long)N * H * W, Cout, W);
+  return b < 0 ? CY_ERR_SHAPE : b;
 }
 
 int cy_conv3x3_first_fwd(const float* x, const float* w, void* out, float* stats, int N, int Cin,
@@ -1167,7 +1173,15 @@ int cy_conv3x3_first_fwd(const float* x, const float* w, void* out, float* stats
   const int ppb = 256 / (Cout / 8);
   const long per = ((npix + np - 1) / np + ppb - 1) / ppb * ppb;
   const size_t smem = (size_t)Cin * (per / W + 4) * (W + 2) * sizeof(float);
-  if (smem > 48 * 1024) return CY_ERR_SHAPE;
+  if (smem > 96 * 1024) return CY_ERR_SHAPE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_first_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_first_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_first_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+      return CY_ERR_LAUNCH;
+    attr_done = true;
+  }
   if (out_dtype == CY_BF16)
     hipLaunchKernelGGL(conv3x3_first_kernel<bf16>, dim3(np), dim3(256), smem, st, x, w, (bf16*)out,
                        stats, N, Cin, H, W, Cout);

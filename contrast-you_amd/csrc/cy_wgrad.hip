@@ -823,10 +823,15 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-int first_wgrad_blocks(long npix) {
+int first_wgrad_blocks(long npix, int W) {
   long b = (npix + 1023) / 1024;
   if (b > 1024) b = 1024;
   if (b < 1) b = 1;
+  // never more image rows per block than its LDS image holds (96 KB, one input channel at a time)
+  const long rows_max = (96 * 1024 / 4) / (W + 2) - 4;
+  if (rows_max < 1) return -1;
+  const long need = (npix + rows_max * W - 1) / (rows_max * W);
+  if (b < need) b = need;
   return (int)b;
 }
 
@@ -954,7 +959,7 @@ int cy_conv3x3_wgrad_pair(const cy_conv_desc* d, const void* src1, const void* s
 }
 
 size_t cy_conv3x3_first_wgrad_ws_bytes(int N, int Cin, int H, int W, int Cout) {
-  return (size_t)first_wgrad_blocks((long)N * H * W) * Cout * Cin * 9 * sizeof(float);
+  return (size_t)first_wgrad_blocks((long)N * H * W, W) * Cout * Cin * 9 * sizeof(float);
 }
 
 int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int accumulate, int N, int Cin,
@@ -964,11 +969,19 @@ int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int accumu
   if (Cin < 1 || Cin > 4 || Cout % 8 || Cout > 64 || 256 % (Cout / 8)) return CY_ERR_SHAPE;
   if ((long)N * H * W >= (1L << 31)) return CY_ERR_SHAPE;
   if (ws_bytes < cy_conv3x3_first_wgrad_ws_bytes(N, Cin, H, W, Cout)) return CY_ERR_WORKSPACE;
-  const int nblk = first_wgrad_blocks((long)N * H * W);
+  const int nblk = first_wgrad_blocks((long)N * H * W, W);
   hipStream_t st = (hipStream_t)stream;
   const long per = ((long)N * H * W + nblk - 1) / nblk;
   const size_t smem = (size_t)(per / W + 4) * (W + 2) * sizeof(float);
-  if (smem > 48 * 1024) return CY_ERR_SHAPE;
+  if (nblk < 0 || smem > 96 * 1024) return CY_ERR_SHAPE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(first_wgrad_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(first_wgrad_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(first_wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+      return CY_ERR_LAUNCH;
+    attr_done = true;
+  }
   if (dy_dtype == CY_BF16)
     hipLaunchKernelGGL(first_wgrad_kernel<bf16>, dim3(nblk), dim3(256), smem, st, x, (const bf16*)dy,
                        (float*)ws, N, Cin, H, W, Cout);

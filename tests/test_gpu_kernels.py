@@ -198,6 +198,32 @@ def test_first_conv_fwd_wgrad(cin, cout, dtype):
     assert_close(dw, w.grad, WTOL[dtype], "first conv wgrad")
 
 
+def test_first_conv_at_pretraining_batch_size():
+    """BASELINE config 5 runs the first layer on 512 slices per launch: more image rows per workgroup than the
+    LDS image of the input holds unless the grid grows with the batch (it did not at first: CY_ERR_SHAPE in
+    `bench.py --workload c5`).  Forward + statistics and weight gradient on 480 slices against the same kernels
+    on chunks of 60"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    N, H, W, Cout = 480, 224, 224, 8
+    x = torch.rand(N, 1, H, W, generator=g).to(DEV)
+    w = (rnd(Cout, 1, 3, 3, gen=g) * 0.3).to(DEV)
+    BF = torch.bfloat16
+    out, stats = ops.conv_first_fwd(x, w, BF)
+    dy = out  # any tensor of the right shape
+    dw = ops.conv_first_wgrad(x, dy)
+    s = stats.double().sum(0)
+    s_ref = torch.zeros_like(s)
+    dw_ref = torch.zeros_like(dw, dtype=torch.float64)
+    for i in range(0, N, 60):
+        o, st = ops.conv_first_fwd(x[i:i + 60].contiguous(), w, BF)
+        assert torch.equal(o, out[i:i + 60])
+        s_ref += st.double().sum(0)
+        dw_ref += ops.conv_first_wgrad(x[i:i + 60].contiguous(), o.contiguous(memory_format=torch.channels_last)).double()
+    assert_close(s, s_ref.cpu(), 1e-6, "statistics")
+    assert_close(dw, dw_ref.cpu(), 1e-5, "first-layer wgrad")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C,hw", [(32, 24), (8, 12), (512, 6), (40, 10)])
 def test_bn_relu_fwd_bwd(C, hw, dtype):
