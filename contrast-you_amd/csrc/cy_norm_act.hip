@@ -21,6 +21,14 @@ __global__ void __launch_bounds__(1024)
   __shared__ double sred[2][256][4];
   const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
   const int c = blockIdx.x * 4 + cl;
+  // (the per-channel parameters are requested BEFORE the partial sums are reduced: one memory round trip
+  //  instead of two in a kernel that is nothing but latency)
+  float rm_old = 0.f, rv_old = 1.f, gm = 1.f, bt = 0.f;
+  if (sl == 0 && c < C) {
+    if (running_mean) rm_old = running_mean[c], rv_old = running_var[c];
+    if (gamma) gm = gamma[c];
+    if (beta) bt = beta[c];
+  }
   double s1 = 0.0, s2 = 0.0;
   if (c < C && use_batch_stats) {
     for (int p = sl; p < P; p += 256) {
@@ -47,16 +55,16 @@ __global__ void __launch_bounds__(1024)
       if (var < 0.0) var = 0.0;
       if (update_running) {
         const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
-        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+        running_mean[c] = (float)((1.0 - momentum) * (double)rm_old + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * (double)rv_old + momentum * unb);
       }
     } else {
-      mean = running_mean[c];
-      var = running_var[c];
+      mean = rm_old;
+      var = rv_old;
     }
     const double istd = 1.0 / sqrt(var + (double)eps);
-    const double g = gamma ? (double)gamma[c] : 1.0;
-    const double b = beta ? (double)beta[c] : 0.0;
+    const double g = (double)gm;
+    const double b = (double)bt;
     scale[c] = (float)(g * istd);
     shift[c] = (float)(b - mean * g * istd);
     mean_out[c] = (float)mean;
@@ -199,6 +207,14 @@ __global__ void __launch_bounds__(256)
   __shared__ double sred[2][64][4];
   const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
   const int c = blockIdx.x * 4 + cl;
+  float sc_ = 0.f, mu_ = 0.f, is_ = 0.f, dg_old = 0.f, db_old = 0.f;  // requested before the reduction (see bn_finalize_kernel)
+  if (sl == 0 && c < C) {
+    if (batch_stats) sc_ = scale[c], mu_ = mean[c], is_ = invstd[c];
+    if (accumulate) {
+      if (dbeta) db_old = dbeta[c];
+      if (dgamma) dg_old = dgamma[c];
+    }
+  }
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     for (int p = sl; p < P; p += 64) {
@@ -218,12 +234,12 @@ __global__ void __launch_bounds__(256)
   }
   if (sl == 0 && c < C) {
     const double t1 = sred[0][0][cl], t2 = sred[1][0][cl];
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)t1 : (float)t1;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)t2 : (float)t2;
+    if (dbeta) dbeta[c] = accumulate ? db_old + (float)t1 : (float)t1;
+    if (dgamma) dgamma[c] = accumulate ? dg_old + (float)t2 : (float)t2;
     // dy = scale*dz + k1*y + k0   (k1 = k0 = 0 when BN used running statistics)
     double k1 = 0.0, k0 = 0.0;
     if (batch_stats) {
-      const double sc = scale[c], mu = mean[c], is = invstd[c];
+      const double sc = sc_, mu = mu_, is = is_;
       k1 = -sc * is * t2 / count;
       k0 = -sc * t1 / count - k1 * mu;
     }
