@@ -504,6 +504,12 @@ inline bool stream_applicable(const cy_conv_desc* d) {
   if (d->C2 != 0 && (d->C1 != 32 || d->C2 != 32)) return false;  // concat: one chunk per source
   if (d->split_c > 0 && d->split_c % 32) return false;
   if (d->W % 14) return false;
+  // buffer descriptors and 32-bit byte offsets: every tensor below 2 GiB
+  const long eb = 2, opx = (long)d->N * d->H * d->W;
+  const long px1 = d->mode1 == CY_SRC_UP2 ? (long)d->N * (d->H / 2) * (d->W / 2) : opx;
+  const long lim = (1L << 31) - 1;
+  if (px1 * d->ld1 * eb > lim || (d->C2 && opx * d->ld2 * eb > lim)) return false;
+  if (opx * d->ldo * eb > lim || (d->split_c > 0 && opx * d->ldo2 * eb > lim)) return false;
   return true;
 }
 
