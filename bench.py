@@ -72,7 +72,8 @@ class SyntheticLoader:
             yield self.batch
 
 
-def build_step(device, rank: int, n_l: int, n_unl: int, hw: int, max_channel: int, bf16: bool = True):
+def build_step(device, rank: int, n_l: int, n_unl: int, hw: int, max_channel: int, bf16: bool = True,
+               num_classes: int = 4, fp16: bool = False):
     from contrastyou.amp import BF16Scaler
     from contrastyou.arch import UNet
     from contrastyou.hooks.base import TrainerHook
@@ -81,15 +82,18 @@ def build_step(device, rank: int, n_l: int, n_unl: int, hw: int, max_channel: in
     from semi_seg.hooks import create_infonce_hooks
 
     torch.manual_seed(10)
-    model = UNet(input_dim=1, num_classes=4, max_channel=max_channel, momentum=0.01).to(device)
+    model = UNet(input_dim=1, num_classes=num_classes, max_channel=max_channel, momentum=0.01).to(device)
     type(TrainerHook).names.clear()  # allow re-building hooks inside one process
     hook = create_infonce_hooks(model=model, feature_names="Conv5", weights=1.0, contrast_ons="partition",
                                 spatial_size=1, data_name="acdc").to(device)
     optimizer = RAdam([{"params": list(model.parameters())}, {"params": list(hook.parameters())}],
                       lr=3e-5, weight_decay=1e-5)
-    labeled = SyntheticLoader(n_l, hw, 4, device, 1234 + rank, "lab")
-    unlabeled = SyntheticLoader(n_unl, hw, 4, device, 4321 + rank, "unl")
-    scaler = BF16Scaler() if bf16 else torch.amp.GradScaler("cuda", enabled=False)
+    labeled = SyntheticLoader(n_l, hw, num_classes, device, 1234 + rank, "lab")
+    unlabeled = SyntheticLoader(n_unl, hw, num_classes, device, 4321 + rank, "unl")
+    if fp16:  # the reference's own AMP mode: fp16 autocast + torch GradScaler (contrastyou/amp/amp.py:13-45)
+        scaler = torch.amp.GradScaler("cuda", enabled=True)
+    else:
+        scaler = BF16Scaler() if bf16 else torch.amp.GradScaler("cuda", enabled=False)
     return dict(model=model, hook=hook, optimizer=optimizer, labeled=labeled, unlabeled=unlabeled,
                 criterion=KL_div(), scaler=scaler)
 
@@ -252,9 +256,10 @@ def main():
     ap.add_argument("--n-unlabeled", type=int, default=16)
     ap.add_argument("--hw", type=int, default=224)
     ap.add_argument("--max-channel", type=int, default=512)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c5"],
-                    help="c2 (default, the BASELINE metric's config): semi-supervised step; c5: encoder "
-                         "pre-training, 256 slices x 2 views per GPU, until=Conv5, global negatives")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
+                    help="c2 (default, the BASELINE metric's config): semi-supervised step; c4: the same step at 8 "
+                         "classes, 256 x 256, fp16 autocast + GradScaler; c5: encoder pre-training, 256 slices x 2 "
+                         "views per GPU, until=Conv5, global negatives")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -279,6 +284,10 @@ def main():
         n_c5 = a.n_unlabeled if a.n_unlabeled != 16 else 256
         ctx = build_step_c5(device, rank, n_c5, a.hw, a.max_channel)
         a.n_labeled, a.n_unlabeled = 0, n_c5
+        a.no_cpu_baseline = True
+    elif a.workload == "c4":
+        a.hw = 256 if a.hw == 224 else a.hw
+        ctx = build_step(device, rank, a.n_labeled, a.n_unlabeled, a.hw, a.max_channel, num_classes=8, fp16=True)
         a.no_cpu_baseline = True
     else:
         ctx = build_step(device, rank, a.n_labeled, a.n_unlabeled, a.hw, a.max_channel)
@@ -327,14 +336,17 @@ def main():
             "metric": "2D slices/sec on ACDC U-Net+InfoNCE step", "value": round(slices / per_step, 2),
             "unit": "slices/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(per_step * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16" if a.workload == "c4" else "bf16", "data": "synthetic",
             "config": {"workload": (f"C5: encoder pre-training (PretrainDecoderEpocher, until=Conv5), {a.n_unlabeled} "
                                     f"slices x 2 views 1x{a.hw}x{a.hw} per GPU, InfoNCE over {2 * a.n_unlabeled * world} "
                                     f"embeddings (all-gather), UNet max_channel={a.max_channel}, decoder frozen, RAdam")
                        if a.workload == "c5" else
-                       ("C2: ACDC SemiSupervisedEpocher + InfoNCE@Conv5 (partition), two-stage, "
-                        f"{a.n_labeled} labeled + {a.n_unlabeled} unlabeled 1x{a.hw}x{a.hw} per GPU, "
-                        f"4 classes, UNet max_channel={a.max_channel}, RAdam"),
+                       ((f"C4: SemiSupervisedEpocher + InfoNCE@Conv5 (partition), two-stage, fp16 autocast + GradScaler, "
+                         f"{a.n_labeled} labeled + {a.n_unlabeled} unlabeled 1x{a.hw}x{a.hw} per GPU, 8 classes, "
+                         f"UNet max_channel={a.max_channel}, RAdam") if a.workload == "c4" else
+                        ("C2: ACDC SemiSupervisedEpocher + InfoNCE@Conv5 (partition), two-stage, "
+                         f"{a.n_labeled} labeled + {a.n_unlabeled} unlabeled 1x{a.hw}x{a.hw} per GPU, "
+                         f"4 classes, UNet max_channel={a.max_channel}, RAdam")),
                        "global_batch": slices, "network_passes_per_step_per_gpu": passes,
                        "parallelism": f"dp{world}",
                        "step_tflops_per_gpu": None if flops_step is None else round(flops_step / 1e12, 3),
