@@ -301,6 +301,22 @@ struct Wg12Cfg {
   static_assert(SMEM <= 160 * 1024, "LDS");
 };
 
+static unsigned long long* g_w12_stamp_buf = nullptr;  // cy_debug_wgrad_stamps
+#ifdef CY_WGRAD_STAMPS  // development aid (-DCY_WGRAD_STAMPS): per-wave shader-clock totals of the loop phases of
+                        // workgroup (0, 0), kept in scalar registers (no memory traffic inside the loop), written once:
+                        // [wave][8] = {request, mfma loop, commit, barrier, tiles}
+#define W12_STAMP(PH)                                                      \
+  do {                                                                     \
+    if (stamping) {                                                        \
+      const unsigned long long t__ = __builtin_amdgcn_s_memtime();         \
+      ph_sum[PH] += t__ - t_last;                                          \
+      t_last = t__;                                                        \
+    }                                                                      \
+  } while (0)
+#else
+#define W12_STAMP(PH) do {} while (0)
+#endif
+
 template <int WCO, int WCI, int WK, typename T = bf16>
 __global__ void __launch_bounds__(768, 1)
     wgrad12_kernel(const WgradArgs g) {
@@ -323,6 +339,11 @@ __global__ void __launch_bounds__(768, 1)
   const int wci = (rest / WK) % WCI;
   const int wco = rest / (WK * WCI);
   const int r = lane & 31, h = lane >> 5;
+#ifdef CY_WGRAD_STAMPS
+  const bool stamping = g.c.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+  unsigned long long ph_sum[4] = {0ull, 0ull, 0ull, 0ull}, t_last = 0ull;
+  int ntile_done = 0;
+#endif
 
   const int TH = g.TH, TW = g.TW;
   const int npix = TH * TW;
@@ -348,6 +369,7 @@ __global__ void __launch_bounds__(768, 1)
 
   // ---- staging: request (global -> registers) / commit (registers -> LDS buffer) ----------------
   // tiles never span images (TH | H): the image of a tile and its first row in it are uniform
+  const int ld1v = a.ld1, ld2v = a.ld2;
   const int cha = tid % CPA, chb = tid % CPB;  // constant per thread (768 % CP* == 0)
   const int HWt = TW + 2;
   const int nhalo = (TH + 2) * HWt;
@@ -416,7 +438,10 @@ __global__ void __launch_bounds__(768, 1)
     hok = 0;
     if (pooled) return;
     const T* base = in2 ? s2 + (cabs - a.C1) : s1 + cabs;
-    const int ld = in2 ? a.ld2 : a.ld1;
+    // (a per-lane choice between two kernel-argument FIELDS compiles to a per-lane pointer and a vector load of the
+    //  argument followed by s_waitcnt vmcnt(0) -- a full memory round trip in the middle of every request, waiting
+    //  for the dy loads just issued.  Scalars first.)
+    const int ld = in2 ? ld2v : ld1v;
     const int wsh = (!in2 && a.mode1 == CY_SRC_UP2) ? 1 : 0;
 #pragma unroll
     for (int i = 0; i < C::NHL; ++i) {
@@ -503,7 +528,11 @@ __global__ void __launch_bounds__(768, 1)
   int cur = 0;
   for (int tile = split; tile < ntiles; tile += g.S, cur ^= 1) {
     const int next = tile + g.S;
+#ifdef CY_WGRAD_STAMPS
+    if (stamping && t_last == 0ull) t_last = __builtin_amdgcn_s_memtime();
+#endif
     if (next < ntiles) request(next);
+    W12_STAMP(0);
     const unsigned char* sDy = smem + cur * C::BUF;
     const unsigned char* sIn = sDy + C::A_BYTES;
     for (int step = wk; step < nsteps; step += WK) {
@@ -526,10 +555,22 @@ __global__ void __launch_bounds__(768, 1)
       for (int d = 0; d < 3; ++d) Mma<T>::mma(af, bfr[d], acc[d]);
       __builtin_amdgcn_s_setprio(0);
     }
+    W12_STAMP(1);
     if (next < ntiles) commit(next, smem + (cur ^ 1) * C::BUF, smem + (cur ^ 1) * C::BUF + C::A_BYTES);
+    W12_STAMP(2);
     __syncthreads();  // this tile consumed by every wave, the next one staged
+    W12_STAMP(3);
+#ifdef CY_WGRAD_STAMPS
+    ++ntile_done;
+#endif
   }
 
+#ifdef CY_WGRAD_STAMPS
+  if (stamping && lane == 0) {
+    for (int q = 0; q < 4; ++q) g.c.stamps[wave * 8 + q] = ph_sum[q];
+    g.c.stamps[wave * 8 + 4] = (unsigned long long)ntile_done;
+  }
+#endif
   // ---- write the split's slab: taps (dh, dw = -1..1) of this wave ----
   float* slab = g.ws + (size_t)split * 9 * g.co_pad * g.ci_pad;
   if constexpr (WK == 1) {
@@ -704,7 +745,9 @@ int launch_wgrad12(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
     attr_done = true;
   }
   dim3 grid((p.co_pad / C::BCO) * (p.ci_pad / C::BCI), p.S);
-  hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::SMEM, st, g);
+  WgradArgs ga = g;
+  ga.c.stamps = g_w12_stamp_buf;
+  hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::SMEM, st, ga);
   CY_CHECK_LAUNCH();
   return CY_OK;
 }
@@ -838,6 +881,12 @@ int first_wgrad_blocks(long npix, int W) {
 }  // namespace
 
 extern "C" {
+
+int cy_debug_wgrad_stamps(unsigned long long* dev_buf) {  // development aid, see W12_STAMP
+  g_w12_stamp_buf = dev_buf;
+  return CY_OK;
+}
+
 
 int cy_conv3x3_wgrad_plan(const cy_conv_desc* d, int n_b, cy_wgrad_plan* plan) {
   if (!d || !plan || d->Cout <= 0 || d->C1 <= 0 || d->H <= 0 || d->W <= 0 || d->N <= 0 || n_b < 0) return CY_ERR_ARG;

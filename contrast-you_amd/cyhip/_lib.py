@@ -71,6 +71,7 @@ _SIGS = {
     "cy_conv3x3_fwd": (c_int, [_PCD, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "cy_conv3x3_pc_packed_elems": (C.c_longlong, [c_int, c_int]),
     "cy_debug_p8_weights": (c_int, [_P]),
+    "cy_debug_wgrad_stamps": (c_int, [_P]),
     "cy_debug_pc_stamps": (c_int, [_P]),
     "cy_conv3x3_pc_pack": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "cy_conv3x3_pc_num_partials": (c_int, [_PCD]),

@@ -147,6 +147,9 @@ int cy_debug_pc_stamps(unsigned long long* dev_buf);
 /* development aid: route the eight-wave plane kernel's weights through LDS-DMA from this cy_conv3x3_pc_pack
  * image (NULL: packed image of cy_conv3x3_pack_weights as usual). */
 int cy_debug_p8_weights(const void* pc_image);
+/* development aid: per-wave phase totals (shader clocks) of the twelve-wave weight-gradient kernel's tile loop
+ * (library built with -DCY_WGRAD_STAMPS), [12 waves][8] = {request, mfma loop, commit, barrier, tiles}. */
+int cy_debug_wgrad_stamps(unsigned long long* dev_buf);
 int cy_conv3x3_pc_pack(const float* w, void* wpc_f, void* wpc_d, int Cout, int Cin, int dtype, void* stream);
 int cy_conv3x3_pc_num_partials(const cy_conv_desc* d);
 size_t cy_conv3x3_pc_ws_bytes(const cy_conv_desc* d);
