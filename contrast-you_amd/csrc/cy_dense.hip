@@ -15,7 +15,9 @@
 //
 // Adaptive pooling bins (torch semantics): rows [floor(i*H/s), ceil((i+1)*H/s)), same for
 // columns; neighbouring bins overlap by at most one pixel when s <= H.
-#include "cy_common.h"
+#include <cstdlib>
+
+#include "cy_conv_tile.h"
 
 namespace {
 
@@ -341,6 +343,8 @@ inline int dp_bwd_blocks(int nb) { return nb < 256 ? nb : 256; }
 
 }  // namespace
 
+#include "cy_dense_mfma.h"
+
 extern "C" {
 
 int cy_dense_proj_fwd(const void* x, const float* w1, const float* b1, const int32_t* bins, int nb,
@@ -351,6 +355,11 @@ int cy_dense_proj_fwd(const void* x, const float* w1, const float* b1, const int
     return CY_ERR_SHAPE;
   if (!bins && nb != N * sh * sw) return CY_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  if (dpm_applicable(dtype, C, hid, slope)) {
+    if (dtype == CY_BF16)
+      return dpm_launch_fwd<bf16>((const bf16*)x, w1, b1, bins, nb, hpool, H, W, ldx, hid, sh, sw, slope, st);
+    return dpm_launch_fwd<f16>((const f16*)x, w1, b1, bins, nb, hpool, H, W, ldx, hid, sh, sw, slope, st);
+  }
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(dense_proj_fwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)x, w1,
                        b1, bins, hpool, H, W, C, ldx, hid, sh, sw, slope);
@@ -367,7 +376,9 @@ int cy_dense_proj_fwd(const void* x, const float* w1, const float* b1, const int
 }
 
 size_t cy_dense_proj_bwd_ws_bytes(int nb, int C, int hid) {
-  return (size_t)dp_bwd_blocks(nb) * ((size_t)hid * C + hid) * sizeof(float);
+  const size_t valu = (size_t)dp_bwd_blocks(nb) * ((size_t)hid * C + hid) * sizeof(float);
+  const size_t mfma = (size_t)DPM_WGS * DPM_PART * sizeof(float);
+  return valu > mfma ? valu : mfma;
 }
 
 int cy_dense_proj_bwd(const void* x, const float* w1, const float* b1, const int32_t* bins, int nb,
@@ -382,6 +393,13 @@ int cy_dense_proj_bwd(const void* x, const float* w1, const float* b1, const int
   if (dtype != CY_BF16 && dtype != CY_F32 && dtype != CY_F16) return CY_ERR_DTYPE;
   if (!ws || ws_bytes < cy_dense_proj_bwd_ws_bytes(nb, C, hid)) return CY_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  if (dpm_applicable(dtype, C, hid, slope)) {
+    if (dtype == CY_BF16)
+      return dpm_launch_bwd<bf16>((const bf16*)x, w1, b1, bins, nb, dhpool, (bf16*)dx, dw1, db1, accumulate, N, H, W,
+                                  ldx, hid, sh, sw, slope, (float*)ws, st);
+    return dpm_launch_bwd<f16>((const f16*)x, w1, b1, bins, nb, dhpool, (f16*)dx, dw1, db1, accumulate, N, H, W, ldx,
+                               hid, sh, sw, slope, (float*)ws, st);
+  }
   const int G = dp_bwd_blocks(nb);
   const size_t slot = (size_t)hid * C + hid;
   // dW1/db1: one launch over all bins (no pixel is written); dx: one launch per colour class

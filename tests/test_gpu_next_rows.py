@@ -73,6 +73,11 @@ def test_dense_projector_points_equal_full_map_and_oracle(dtype, tol):
     x = torch.randn(n, c, hw, hw, generator=gen)
     if dtype == torch.bfloat16:
         x = x.bfloat16().float()
+        # the 16-bit kernels run the first 1x1 convolution with W1 in the storage type (what autocast does to a
+        # Conv2d); give the oracle the same weights -- a 2^-9 change of W1 flips the leaky-ReLU branch of ~0.3 %
+        # of the pre-activations, each flip moving dx of its pixel by several per cent
+        with torch.no_grad():
+            head._projector[0].weight.copy_(head._projector[0].weight.bfloat16().float())
     seed = 77
     pts = region_points(n, s, s, point_nums=5, seed=seed)
     assert pts == onr.region_points(n, s, s, seed)
@@ -89,8 +94,10 @@ def test_dense_projector_points_equal_full_map_and_oracle(dtype, tol):
     (rows_full * coef.to(DEV)).sum().backward()
     close(rows, cpu(rows_full), 1e-5, "points vs full")
     close(xa.grad, cpu(xb.grad), 1e-2 if dtype == torch.bfloat16 else 1e-5, "dx points vs full")
+    # (16-bit: the matrix-core kernels round the pooled gradient to the storage type before the dW1 product --
+    # per bin on the list path, per cell of the bin partition on the all-bins path: 2^-9 per term, random)
     for k, p in head.named_parameters():
-        close(ga[k], cpu(p.grad), 1e-4, k)
+        close(ga[k], cpu(p.grad), 1e-4 if dtype == torch.float32 else 1e-3, k)
 
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in head.state_dict().items()}
     xo = x.clone().requires_grad_(True)
@@ -100,6 +107,67 @@ def test_dense_projector_points_equal_full_map_and_oracle(dtype, tol):
     close(xa.grad, xo.grad, tol * 2, "dx vs oracle")
     for k in sd:
         close(ga[k], sd[k].grad, tol * 2, k)
+
+
+@pytest.mark.parametrize("n,hw,s,hid,dtype", [
+    (2, 224, 20, 256, torch.bfloat16),   # the dense InfoNCE hook's geometry: 12/13-pixel bins, one shared row/column
+    (2, 56, 7, 128, torch.float16),      # H % s == 0: no shared pixels, every odd cell segment is empty
+    (3, 45, 8, 256, torch.float16),      # ragged bins
+    (1, 33, 32, 128, torch.bfloat16),    # bins of two pixels: most single-bin segments are empty
+])
+def test_dense_projector_matrix_core_kernels(n, hw, s, hid, dtype):
+    """16-bit maps with 32 channels and 128 / 256 hidden units run the matrix-core kernels of cy_dense_mfma.h
+    (forward by bins, backward by the cells of the bin partition; W1 is rounded to the storage type inside them --
+    here it is representable already, so the oracle sees the same weights).  All bins and a bin list with
+    neighbouring (overlapping) bins, against the oracle's conv -> lrelu -> conv -> pool -> normalise.
+    Products are exact and accumulated in f32: z to 1e-4; the pooled gradient is rounded to 16 bits before the
+    dW1 / dx products and dx is stored in 16 bits: 3e-3 / 1e-2."""
+    from oracle import losses as ol
+    from contrastyou.projectors.heads import DenseProjectionHead
+    gen = torch.Generator().manual_seed(hw + s)
+    out = 64
+    sd = ol.init_dense_projector_sd(32, hid, out, seed=11)
+    sd["_projector.0.weight"] = sd["_projector.0.weight"].to(dtype).float()
+    head = DenseProjectionHead(input_dim=32, hidden_dim=hid, output_dim=out, head_type="mlp", normalize=True,
+                               spatial_size=(s, s))
+    head.load_state_dict(sd, strict=True)
+    head = head.to(DEV)
+    x = torch.randn(n, 32, hw, hw, generator=gen).to(dtype).float()
+    coef = torch.randn(n, out, s, s, generator=gen)
+
+    xa = nhwc(x, dtype).requires_grad_(True)
+    z = head(xa)
+    (z * coef.to(DEV)).sum().backward()
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    zo = ol.dense_projection_head(osd, xo, (s, s))
+    (zo * coef).sum().backward()
+    close(z, zo, 1e-4, "z")
+    close(xa.grad, xo.grad, 1e-2, "dx")
+    for k, p in head.named_parameters():
+        close(p.grad, osd[k].grad, 3e-3, k)
+
+    # a bin list: a 2 x 3 patch of neighbouring bins of image 0 (shared rows / columns -> all four colour classes)
+    # plus one bin of the last image
+    per_image = [[] for _ in range(n)]
+    per_image[0] = [(i, j) for i in (1, 2) for j in (0, 1, 2)]
+    per_image[n - 1] = per_image[n - 1] + [(s - 1, s - 1)]
+    pts = [(b, i, j) for b, lst in enumerate(per_image) for i, j in lst]
+    head.zero_grad()
+    xb = nhwc(x, dtype).requires_grad_(True)
+    rows = head.project_points(xb, per_image)
+    cr = torch.randn(len(pts), out, generator=gen)
+    (rows * cr.to(DEV)).sum().backward()
+    for v in osd.values():
+        v.grad = None
+    xo2 = x.clone().requires_grad_(True)
+    zo2 = ol.dense_projection_head(osd, xo2, (s, s))
+    ro = torch.stack([zo2[b, :, i, j] for b, i, j in pts])
+    (ro * cr).sum().backward()
+    close(rows, ro, 1e-4, "rows")
+    close(xb.grad, xo2.grad, 1e-2, "dx (bin list)")
+    for k, p in head.named_parameters():
+        close(p.grad, osd[k].grad, 3e-3, k + " (bin list)")
 
 
 def test_dense_projector_multichunk_channels_and_linear_head():
