@@ -377,7 +377,8 @@ int cy_dense_proj_fwd(const void* x, const float* w1, const float* b1, const int
 
 size_t cy_dense_proj_bwd_ws_bytes(int nb, int C, int hid) {
   const size_t valu = (size_t)dp_bwd_blocks(nb) * ((size_t)hid * C + hid) * sizeof(float);
-  const size_t mfma = (size_t)DPM_WGS * DPM_PART * sizeof(float);
+  // workgroup partials + the job table (cells: N (2 sh - 1)(2 sw - 1) < 4 nb records)
+  const size_t mfma = (size_t)DPM_WGS * DPM_PART * sizeof(float) + (size_t)4 * (nb > 0 ? nb : 1) * sizeof(DpRec);
   return valu > mfma ? valu : mfma;
 }
 

@@ -140,6 +140,112 @@ __device__ __forceinline__ void dpm_load_w(const float* __restrict__ w1, int o, 
   }
 }
 
+// a job as the block loops see it; jobs past the end (or of another colour class) are empty.  The kernels set the
+// NEXT job up -- descriptor, coefficient loads, first pixel block -- before they work through the current one: a
+// job's chain of dependent global round trips (bins -> dhpool -> x) would otherwise cost 3-5 us each, as much as its
+// arithmetic
+struct DpRun {
+  DpJob J;
+  int nblk;
+  float inv_bw;
+  long pix0;
+};
+
+template <bool CELLS>
+__device__ __forceinline__ DpRun dpm_run(const int32_t* bins, int job, int njobs, int sh, int sw, int H, int W,
+                                         int colour) {
+  const int jc = job < njobs ? job : njobs - 1;
+  DpRun R;
+  R.J = CELLS ? dpm_cell_job(jc, sh, sw, H, W) : dpm_bin_job(bins, jc, sh, sw, H, W);
+  if (job >= njobs || (!CELLS && colour >= 0 && R.J.colour != colour)) R.J.npx = 0;
+  R.nblk = (R.J.npx + 31) >> 5;
+  R.inv_bw = 1.f / (float)(R.J.bw > 0 ? R.J.bw : 1);
+  R.pix0 = ((long)R.J.n * H + R.J.r0) * W + R.J.c0;
+  return R;
+}
+
+// Backward jobs come from a table written by dpm_jobs_kernel (one thread per job): the ~25 integer divisions of a
+// cell descriptor cost more than the arithmetic of a one-block cell when every wave redoes them on the vector unit.
+struct __attribute__((aligned(64))) DpRec {
+  long pix0;      // first pixel of the rectangle
+  int bw, npx, nblk, colour;
+  float inv_bw;
+  int pad;
+  int bin[4];     // rows of dhpool
+  float inv[4];   // 1 / |bin| (0: unused slot)
+};
+static_assert(sizeof(DpRec) == 64, "one 64-byte scalar load per job");
+
+__global__ void __launch_bounds__(256)
+    dpm_jobs_kernel(const int32_t* __restrict__ bins, int njobs, DpRec* __restrict__ recs, int cells, int sh, int sw,
+                    int H, int W) {
+  const int job = blockIdx.x * 256 + threadIdx.x;
+  if (job >= njobs) return;
+  const DpJob J = cells ? dpm_cell_job(job, sh, sw, H, W) : dpm_bin_job(bins, job, sh, sw, H, W);
+  DpRec R;
+  R.pix0 = ((long)J.n * H + J.r0) * W + J.c0;
+  R.bw = J.bw, R.npx = J.npx, R.nblk = (J.npx + 31) >> 5, R.colour = J.colour;
+  R.inv_bw = 1.f / (float)(J.bw > 0 ? J.bw : 1);
+  R.pad = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) R.bin[k] = J.bin[k], R.inv[k] = J.inv[k];
+  recs[job] = R;
+}
+
+// the record of `job`, empty (nblk = npx = 0) past the end or for another colour class; wave-uniform
+__device__ __forceinline__ DpRec dpm_rec(const DpRec* __restrict__ recs, int job, int njobs, int colour) {
+  // one vector load (lane k reads dword k) + 16 readlanes instead of a scalar load through the constant cache
+  const int* p = reinterpret_cast<const int*>(recs + (job < njobs ? job : njobs - 1));
+  const int v = p[threadIdx.x & 15];
+  int w[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) w[k] = __builtin_amdgcn_readlane(v, k);
+  DpRec R;
+  R.pix0 = (long)(((unsigned long long)(unsigned)w[1] << 32) | (unsigned)w[0]);
+  R.bw = w[2], R.npx = w[3], R.nblk = w[4], R.colour = w[5];
+  R.inv_bw = __int_as_float(w[6]);
+  R.pad = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) R.bin[k] = w[8 + k], R.inv[k] = __int_as_float(w[12 + k]);
+  if (job >= njobs || (colour >= 0 && R.colour != colour)) R.npx = 0, R.nblk = 0;
+  return R;
+}
+
+__device__ __forceinline__ float dpm_rec_coef(const float* __restrict__ dhpool, const DpRec& R, int hid, int o) {
+  const float d0 = dhpool[(size_t)R.bin[0] * hid + o], d1 = dhpool[(size_t)R.bin[1] * hid + o];
+  const float d2 = dhpool[(size_t)R.bin[2] * hid + o], d3 = dhpool[(size_t)R.bin[3] * hid + o];
+  return (d0 * R.inv[0] + d1 * R.inv[1]) + (d2 * R.inv[2] + d3 * R.inv[3]);
+}
+
+template <typename T>
+__device__ __forceinline__ void dpm_rec_rows(const T* __restrict__ x, const DpRec& R, int W, int ldx, int blk, int r,
+                                             int h, u32x4 (&f)[2]) {
+  const int q = blk * 32 + r;
+  const bool ok = q < R.npx;
+  const int qc = ok ? q : 0;
+  const int qr = (int)(((float)qc + 0.5f) * R.inv_bw), qcol = qc - qr * R.bw;
+  const T* p = x + (R.pix0 + (long)qr * W + qcol) * ldx + 8 * h;
+  f[0] = ld16(p);
+  f[1] = ld16(p + 16);
+  if (!ok) f[0] = f[1] = u32x4{0u, 0u, 0u, 0u};
+}
+
+// W1 rounded to T as an LDS image [hid][32] (64-byte rows, dpm_xoff swizzle): the backward kernels read their B
+// fragments from it instead of pinning 4 registers per (32 units, k-step)
+__device__ __forceinline__ int dpm_xoff(int row, int slot);
+template <typename T>
+__device__ __forceinline__ void dpm_stage_w(const float* __restrict__ w1, int hid, unsigned char* sw1) {
+  for (int idx = threadIdx.x; idx < hid * 4; idx += 256) {
+    const int row = idx >> 2, slot = idx & 3;
+    float f[8];
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w1 + (size_t)row * 32 + slot * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(w1 + (size_t)row * 32 + slot * 8 + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = a[i], f[4 + i] = b[i];
+    st16(sw1 + dpm_xoff(row, slot), Chunk<T>::pack(f));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // hpool[bin][o] = mean over the bin's pixels of lrelu(W1 x + b1).  NHB 32-unit blocks of hidden units per wave.
 template <typename T, int NHB>
@@ -165,11 +271,16 @@ __global__ void __launch_bounds__(256, 2)
     lbias[hb] = fmaxf(bias[hb], sbias[hb]);
   }
 
-  for (int b = gw / npass; b < nb; b += nw / npass) {
-    const DpJob J = dpm_bin_job(bins, b, sh, sw, H, W);
-    const int nblk = (J.npx + 31) >> 5;
-    const float inv_bw = 1.f / (float)J.bw;
-    const long pix0 = ((long)J.n * H + J.r0) * W + J.c0;
+  const int stride = nw / npass;
+  DpRun cur = dpm_run<false>(bins, gw / npass, nb, sh, sw, H, W, -1);
+  u32x4 f0[2], f1[2];
+  dpm_load_rows<T>(x, cur.J, cur.pix0, cur.inv_bw, W, ldx, 0, r, h, f0);
+  for (int b = gw / npass; b < nb; b += stride) {
+    const DpRun nxt = dpm_run<false>(bins, b + stride, nb, sh, sw, H, W, -1);
+    u32x4 n0[2];
+    dpm_load_rows<T>(x, nxt.J, nxt.pix0, nxt.inv_bw, W, ldx, 0, r, h, n0);
+    const DpJob& J = cur.J;
+    const int nblk = cur.nblk;
     float sum[NHB];
 #pragma unroll
     for (int hb = 0; hb < NHB; ++hb) sum[hb] = 0.f;
@@ -199,12 +310,10 @@ __global__ void __launch_bounds__(256, 2)
     };
 
     // two register sets; every load is unconditional (a conditional one would turn the waits into vmcnt(0))
-    u32x4 f0[2], f1[2];
-    dpm_load_rows<T>(x, J, pix0, inv_bw, W, ldx, 0, r, h, f0);
     for (int blk = 0; blk + 1 < nblk; blk += 2) {
-      dpm_load_rows<T>(x, J, pix0, inv_bw, W, ldx, blk + 1, r, h, f1);
+      dpm_load_rows<T>(x, J, cur.pix0, cur.inv_bw, W, ldx, blk + 1, r, h, f1);
       block(f0);
-      dpm_load_rows<T>(x, J, pix0, inv_bw, W, ldx, min(blk + 2, nblk - 1), r, h, f0);
+      dpm_load_rows<T>(x, J, cur.pix0, cur.inv_bw, W, ldx, min(blk + 2, nblk - 1), r, h, f0);
       block(f1);
     }
     if (nblk & 1) block(f0);
@@ -216,19 +325,12 @@ __global__ void __launch_bounds__(256, 2)
       s -= npad * lbias[hb];
       if (h == 0) hpool[(size_t)b * hid + o0 + hb * 32 + r] = s * J.inv[0];
     }
+    cur = nxt;
+    f0[0] = n0[0], f0[1] = n0[1];
   }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// per-lane gradient coefficient of the job for hidden unit o: D = sum over its bins of dhpool[bin][o] / |bin|
-__device__ __forceinline__ float dpm_coef(const float* __restrict__ dhpool, const DpJob& J, int hid, int o) {
-  float d = dhpool[(size_t)J.bin[0] * hid + o] * J.inv[0];
-#pragma unroll
-  for (int k = 1; k < 4; ++k)
-    if (J.inv[k] != 0.f) d += dhpool[(size_t)J.bin[k] * hid + o] * J.inv[k];  // (wave-uniform)
-  return d;
-}
-
 // swizzled byte offset of (row, 16-byte slot) in a per-wave tile of 64-byte rows (4 slots): rows 4 apart share banks
 __device__ __forceinline__ int dpm_xoff(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 // ... of (row, 8-byte slot) in a tile of 64-byte rows (8 slots)
@@ -239,12 +341,13 @@ __device__ __forceinline__ int dpm_goff(int row, int slot) { return row * 64 + (
 template <typename T, bool CELLS>
 __global__ void __launch_bounds__(256, 2)
     dense_proj_mfma_dw_kernel(const T* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
-                              const int32_t* __restrict__ bins, int njobs, const float* __restrict__ dhpool,
+                              const DpRec* __restrict__ recs, int njobs, const float* __restrict__ dhpool,
                               float* __restrict__ part, int H, int W, int ldx, int hid, int sh, int sw,
                               float slope) {
   using M = Mma<T>;
   constexpr int HB = 4;
   __shared__ __attribute__((aligned(16))) float red[2 * DPM_PART];  // (the x tiles alias its head)
+  __shared__ __attribute__((aligned(16))) unsigned char sw1[256 * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -254,13 +357,14 @@ __global__ void __launch_bounds__(256, 2)
   const int slot = (blockIdx.x / npass) * 4 + wave, nslot = (gridDim.x / npass) * 4;
   unsigned char* sx = reinterpret_cast<unsigned char*>(red) + wave * 2048;
 
-  DpFrag<T> wf[HB][2];
+  dpm_stage_w<T>(w1, hid, sw1);
+  __syncthreads();
   float nbias[HB];
+  int woff[2];  // fragment of (hidden unit o0 + r, k-step ks); + hb * 2048 bytes (the swizzle repeats every 16 rows)
 #pragma unroll
-  for (int hb = 0; hb < HB; ++hb) {
-    dpm_load_w<T>(w1, o0 + hb * 32 + r, h, wf[hb]);
-    nbias[hb] = -b1[o0 + hb * 32 + r];
-  }
+  for (int ks = 0; ks < 2; ++ks) woff[ks] = dpm_xoff(o0 + r, 2 * ks + h);
+#pragma unroll
+  for (int hb = 0; hb < HB; ++hb) nbias[hb] = -b1[o0 + hb * 32 + r];
   f32x16 dw[HB];
   float db[HB];
 #pragma unroll
@@ -278,18 +382,27 @@ __global__ void __launch_bounds__(256, 2)
     xhi[s] = dpm_xoff(rh, 2 * gsel + (p4 >> 1)) + 8 * (p4 & 1);
   }
 
+  // (Only the first pixel block of the next job is requested ahead here.  With the next job's 16 coefficient loads in
+  //  flight as well -- the form the dx kernel below runs -- THIS kernel's dW1 / db1 came out different from run to run
+  //  (relative 3e-3) on geometries where a wave gets three or more jobs; full s_waitcnt's
+  //  (-mllvm -amdgpu-waitcnt-forcezero) made it exact again, a full vmcnt wait before the hand-over, an lgkmcnt wait
+  //  around the x tile or s_nops behind the MFMAs did not.  Cause not identified; the coefficient loads cost one
+  //  dependent round trip per job here instead.)
+  DpRec cur = dpm_rec(recs, slot, njobs, -1);
+  float dpos[HB];
+  u32x4 f0[2], f1[2];
+  dpm_rec_rows<T>(x, cur, W, ldx, 0, r, h, f0);
   for (int job = slot; job < njobs; job += nslot) {
-    const DpJob J = CELLS ? dpm_cell_job(job, sh, sw, H, W) : dpm_bin_job(bins, job, sh, sw, H, W);
-    if (J.npx == 0) continue;
-    const int nblk = (J.npx + 31) >> 5;
-    const float inv_bw = 1.f / (float)J.bw;
-    const long pix0 = ((long)J.n * H + J.r0) * W + J.c0;
-    float dpos[HB], dneg[HB];
 #pragma unroll
-    for (int hb = 0; hb < HB; ++hb) {
-      dpos[hb] = dpm_coef(dhpool, J, hid, o0 + hb * 32 + r);
-      dneg[hb] = slope * dpos[hb];
-    }
+    for (int hb = 0; hb < HB; ++hb) dpos[hb] = dpm_rec_coef(dhpool, cur, hid, o0 + hb * 32 + r);
+    const DpRec nxt = dpm_rec(recs, job + nslot, njobs, -1);
+    u32x4 n0[2];
+    dpm_rec_rows<T>(x, nxt, W, ldx, 0, r, h, n0);
+    const DpRec& J = cur;
+    const int nblk = cur.nblk;
+    float dneg[HB];
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) dneg[hb] = slope * dpos[hb];
 
     auto block = [&](const u32x4 (&f)[2]) {
       st16(sx + dpm_xoff(r, h), f[0]);
@@ -308,7 +421,8 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int k = 0; k < 2; ++k) M::mma(dpm_frag<T>(f[ks]), wf[2 * hq + k][ks], acc[k]);
+          for (int k = 0; k < 2; ++k)
+            M::mma(dpm_frag<T>(f[ks]), dpm_frag<T>(ld16(sw1 + woff[ks] + (2 * hq + k) * 2048)), acc[k]);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int hb = 2 * hq + k;
@@ -327,19 +441,20 @@ __global__ void __launch_bounds__(256, 2)
       __builtin_amdgcn_wave_barrier();  // (the tile is rewritten by the next block)
     };
 
-    u32x4 f0[2], f1[2];
-    dpm_load_rows<T>(x, J, pix0, inv_bw, W, ldx, 0, r, h, f0);
     for (int blk = 0; blk + 1 < nblk; blk += 2) {
-      dpm_load_rows<T>(x, J, pix0, inv_bw, W, ldx, blk + 1, r, h, f1);
+      dpm_rec_rows<T>(x, J, W, ldx, blk + 1, r, h, f1);
       block(f0);
-      dpm_load_rows<T>(x, J, pix0, inv_bw, W, ldx, min(blk + 2, nblk - 1), r, h, f0);
+      dpm_rec_rows<T>(x, J, W, ldx, min(blk + 2, nblk - 1), r, h, f0);
       block(f1);
     }
     if (nblk & 1) block(f0);
     const float npad = (float)(nblk * 32 - J.npx);
 #pragma unroll
-    for (int hb = 0; hb < HB; ++hb)  // (per lane: the two halves hold the padded rows between them)
+    for (int hb = 0; hb < HB; ++hb) {  // (per lane: the two halves hold the padded rows between them)
       db[hb] -= 0.5f * npad * (0.f > nbias[hb] ? dpos[hb] : dneg[hb]);
+    }
+    cur = nxt;
+    f0[0] = n0[0], f0[1] = n0[1];
   }
 
   // the workgroup's partial, in register order [e = hb*16 + reg | 64 + hb][lane]: (w0 + w2) + (w1 + w3)
@@ -405,11 +520,12 @@ __global__ void __launch_bounds__(256)
 template <typename T, int NHB, bool CELLS>
 __global__ void __launch_bounds__(256, 2)
     dense_proj_mfma_dx_kernel(const T* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
-                              const int32_t* __restrict__ bins, int njobs, const float* __restrict__ dhpool,
+                              const DpRec* __restrict__ recs, int njobs, const float* __restrict__ dhpool,
                               T* __restrict__ dx, int H, int W, int ldx, int hid, int sh, int sw, float slope,
                               int colour) {
   using M = Mma<T>;
   __shared__ __attribute__((aligned(16))) unsigned char sgall[4 * 128 * 64];  // per wave: g^T [128 units][32 pixels]
+  __shared__ __attribute__((aligned(16))) unsigned char sw1[256 * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -417,14 +533,15 @@ __global__ void __launch_bounds__(256, 2)
   const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
   unsigned char* sg = sgall + wave * (128 * 64);
 
-  DpFrag<T> wf[NHB][2];  // pre-activations: B operand
+  dpm_stage_w<T>(w1, hid, sw1);  // pre-activations: B operand from LDS
+  __syncthreads();
+  int woff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) woff[ks] = dpm_xoff(r, 2 * ks + h);
   DpFrag<T> wt[NHB * 2];  // dx: A operand, row = channel r, k = hidden unit 16t + 8h + i
   float nbias[NHB];
 #pragma unroll
-  for (int hb = 0; hb < NHB; ++hb) {
-    dpm_load_w<T>(w1, hb * 32 + r, h, wf[hb]);
-    nbias[hb] = -b1[hb * 32 + r];
-  }
+  for (int hb = 0; hb < NHB; ++hb) nbias[hb] = -b1[hb * 32 + r];
 #pragma unroll
   for (int t = 0; t < NHB * 2; ++t) {
     float f[8];
@@ -442,15 +559,21 @@ __global__ void __launch_bounds__(256, 2)
     ghi[t] = dpm_goff(rh, 4 * gsel + p4) - t * 1024;
   }
 
-  for (int job = gw; job < njobs; job += nw) {
-    const DpJob J = CELLS ? dpm_cell_job(job, sh, sw, H, W) : dpm_bin_job(bins, job, sh, sw, H, W);
-    if (J.npx == 0 || (!CELLS && colour >= 0 && J.colour != colour)) continue;
-    const int nblk = (J.npx + 31) >> 5;
-    const float inv_bw = 1.f / (float)J.bw;
-    const long pix0 = ((long)J.n * H + J.r0) * W + J.c0;
-    float dpos[NHB];
+  DpRec cur = dpm_rec(recs, gw, njobs, colour);
+  float dpos[NHB];
+  u32x4 f0[2], f1[2];
 #pragma unroll
-    for (int hb = 0; hb < NHB; ++hb) dpos[hb] = dpm_coef(dhpool, J, hid, hb * 32 + r);
+  for (int hb = 0; hb < NHB; ++hb) dpos[hb] = dpm_rec_coef(dhpool, cur, hid, hb * 32 + r);
+  dpm_rec_rows<T>(x, cur, W, ldx, 0, r, h, f0);
+  for (int job = gw; job < njobs; job += nw) {
+    const DpRec nxt = dpm_rec(recs, job + nw, njobs, colour);
+    float dnxt[NHB];
+    u32x4 n0[2];
+#pragma unroll
+    for (int hb = 0; hb < NHB; ++hb) dnxt[hb] = dpm_rec_coef(dhpool, nxt, hid, hb * 32 + r);
+    dpm_rec_rows<T>(x, nxt, W, ldx, 0, r, h, n0);
+    const DpRec& J = cur;
+    const int nblk = cur.nblk;
 
     auto block = [&](const u32x4 (&f)[2], int blk) {
       f32x16 dxa;
@@ -468,7 +591,8 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int k = 0; k < 2; ++k) M::mma(dpm_frag<T>(f[ks]), wf[hq * 4 + hp * 2 + k][ks], acc[k]);
+            for (int k = 0; k < 2; ++k)
+              M::mma(dpm_frag<T>(f[ks]), dpm_frag<T>(ld16(sw1 + woff[ks] + (hq * 4 + hp * 2 + k) * 2048)), acc[k]);
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const float dp = dpos[hq * 4 + hp * 2 + k], dn = slope * dp, bs = nbias[hq * 4 + hp * 2 + k];
@@ -496,8 +620,8 @@ __global__ void __launch_bounds__(256, 2)
       // lane (pixel r of the block, half h): channels 8j + 4h + 0..3 in registers 4j .. 4j+3
       const int q = blk * 32 + r;
       if (q < J.npx) {
-        const int qr = (int)(((float)q + 0.5f) * inv_bw), qcol = q - qr * J.bw;
-        T* p = dx + (pix0 + (long)qr * W + qcol) * ldx + 4 * h;
+        const int qr = (int)(((float)q + 0.5f) * J.inv_bw), qcol = q - qr * J.bw;
+        T* p = dx + (J.pix0 + (long)qr * W + qcol) * ldx + 4 * h;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           T pk[4];
@@ -516,15 +640,17 @@ __global__ void __launch_bounds__(256, 2)
       }
     };
 
-    u32x4 f0[2], f1[2];
-    dpm_load_rows<T>(x, J, pix0, inv_bw, W, ldx, 0, r, h, f0);
     for (int blk = 0; blk + 1 < nblk; blk += 2) {
-      dpm_load_rows<T>(x, J, pix0, inv_bw, W, ldx, blk + 1, r, h, f1);
+      dpm_rec_rows<T>(x, J, W, ldx, blk + 1, r, h, f1);
       block(f0, blk);
-      dpm_load_rows<T>(x, J, pix0, inv_bw, W, ldx, min(blk + 2, nblk - 1), r, h, f0);
+      dpm_rec_rows<T>(x, J, W, ldx, min(blk + 2, nblk - 1), r, h, f0);
       block(f1, blk + 1);
     }
     if (nblk & 1) block(f0, nblk - 1);
+#pragma unroll
+    for (int hb = 0; hb < NHB; ++hb) dpos[hb] = dnxt[hb];
+    cur = nxt;
+    f0[0] = n0[0], f0[1] = n0[1];
   }
 }
 
@@ -568,13 +694,17 @@ int dpm_launch_bwd(const T* x, const float* w1, const float* b1, const int32_t* 
   const bool cells = bins == nullptr;
   const int njobs = cells ? N * (2 * sh - 1) * (2 * sw - 1) : nb;
   const int npass = hid / 128;
+  DpRec* recs = reinterpret_cast<DpRec*>(ws + (size_t)DPM_WGS * DPM_PART);
+  hipLaunchKernelGGL(dpm_jobs_kernel, dim3(cy_cdiv(njobs, 256)), dim3(256), 0, st, bins, njobs, recs, cells ? 1 : 0, sh,
+                     sw, H, W);
+  CY_CHECK_LAUNCH();
   if (dw1 || db1) {
     const int grid = dpm_dw_grid(njobs, npass);
     if (cells)
-      hipLaunchKernelGGL((dense_proj_mfma_dw_kernel<T, true>), dim3(grid), dim3(256), 0, st, x, w1, b1, bins, njobs,
+      hipLaunchKernelGGL((dense_proj_mfma_dw_kernel<T, true>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs, njobs,
                          dhpool, ws, H, W, ldx, hid, sh, sw, slope);
     else
-      hipLaunchKernelGGL((dense_proj_mfma_dw_kernel<T, false>), dim3(grid), dim3(256), 0, st, x, w1, b1, bins, njobs,
+      hipLaunchKernelGGL((dense_proj_mfma_dw_kernel<T, false>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs, njobs,
                          dhpool, ws, H, W, ldx, hid, sh, sw, slope);
     CY_CHECK_LAUNCH();
     hipLaunchKernelGGL(dense_proj_mfma_reduce_kernel, dim3(cy_cdiv((long)npass * DPM_PART, 32)), dim3(256), 0, st,
@@ -585,19 +715,19 @@ int dpm_launch_bwd(const T* x, const float* w1, const float* b1, const int32_t* 
     const int grid = njobs < DPM_WGS * 4 ? cy_cdiv(njobs, 4) : DPM_WGS;
     if (cells) {
       if (hid == 256)
-        hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 8, true>), dim3(grid), dim3(256), 0, st, x, w1, b1, bins,
+        hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 8, true>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs,
                            njobs, dhpool, dx, H, W, ldx, hid, sh, sw, slope, -1);
       else
-        hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 4, true>), dim3(grid), dim3(256), 0, st, x, w1, b1, bins,
+        hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 4, true>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs,
                            njobs, dhpool, dx, H, W, ldx, hid, sh, sw, slope, -1);
       CY_CHECK_LAUNCH();
     } else {
       for (int colour = 0; colour < 4; ++colour) {
         if (hid == 256)
-          hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 8, false>), dim3(grid), dim3(256), 0, st, x, w1, b1, bins,
+          hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 8, false>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs,
                              njobs, dhpool, dx, H, W, ldx, hid, sh, sw, slope, colour);
         else
-          hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 4, false>), dim3(grid), dim3(256), 0, st, x, w1, b1, bins,
+          hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 4, false>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs,
                              njobs, dhpool, dx, H, W, ldx, hid, sh, sw, slope, colour);
         CY_CHECK_LAUNCH();
       }

@@ -146,6 +146,16 @@ def test_dense_projector_matrix_core_kernels(n, hw, s, hid, dtype):
     close(xa.grad, xo.grad, 1e-2, "dx")
     for k, p in head.named_parameters():
         close(p.grad, osd[k].grad, 3e-3, k)
+    # run to run: bit-identical (fixed job -> wave assignment, fixed reduction order)
+    first = {k: p.grad.clone() for k, p in head.named_parameters()}
+    dx_first = xa.grad.clone()
+    for _ in range(3):
+        head.zero_grad()
+        xr = nhwc(x, dtype).requires_grad_(True)
+        (head(xr) * coef.to(DEV)).sum().backward()
+        assert torch.equal(xr.grad, dx_first), "dx differs between runs"
+        for k, p in head.named_parameters():
+            assert torch.equal(p.grad, first[k]), f"{k} differs between runs"
 
     # a bin list: a 2 x 3 patch of neighbouring bins of image 0 (shared rows / columns -> all four colour classes)
     # plus one bin of the last image
