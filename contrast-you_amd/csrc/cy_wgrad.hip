@@ -664,6 +664,7 @@ __global__ void __launch_bounds__(256)
 
 struct WgPlan {
   bool twelve;  // bf16: the twelve-wave kernel (CY_WGRAD12=0 keeps wgrad_kernel, for A/B runs)
+  bool spec;    // ... in its wave-specialised form (64 x 64 blocks; CY_WGRAD_SPEC=0 keeps wgrad12_kernel)
   int wco, wci, wk;
   int TH, TW, tiles_h, tiles_w, S, co_pad, ci_pad;
 };
@@ -687,6 +688,13 @@ WgPlan plan_wgrad(const cy_conv_desc* d) {
   } else {
     p.wco = 1, p.wci = 1, p.wk = 4;
   }
+  static const bool spec_enabled = [] {
+    const char* e = getenv("CY_WGRAD_SPEC");
+    return !(e && e[0] == '0');
+  }();
+  // (measured per layer at N = 32: the pooled-on-load layers -- four synchronous loads per halo item in the loaders --
+  //  and the 14 x 14 layers -- 98-pixel tiles -- are faster in the unspecialised kernel)
+  p.spec = p.twelve && spec_enabled && p.wco == 2 && p.wci == 2 && d->mode1 != CY_SRC_POOL2 && d->W >= 28;
   p.co_pad = cy_roundup(d->Cout, 32 * p.wco);
   p.ci_pad = cy_roundup(Cin, 32 * p.wci);
   // spatial tile: TW <= 32 columns (halo row pitch is fixed at 36 pixels), TH <= 8 rows with
@@ -751,6 +759,8 @@ int launch_wgrad12(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
   CY_CHECK_LAUNCH();
   return CY_OK;
 }
+
+#include "cy_wgrad_spec.h"  // (inside the anonymous namespace)
 
 // ---------------------------------------------------------------------------
 // first layer weight gradient (Cin 1..4, f32 NCHW image): plain VALU reduction
@@ -893,7 +903,7 @@ int cy_conv3x3_wgrad_plan(const cy_conv_desc* d, int n_b, cy_wgrad_plan* plan) {
   cy_conv_desc dt = *d;
   dt.N += n_b;
   const WgPlan p = plan_wgrad(&dt);
-  plan->twelve = p.twelve ? 1 : 0;
+  plan->twelve = p.spec ? 2 : (p.twelve ? 1 : 0);
   plan->wco = p.wco, plan->wci = p.wci, plan->wk = p.wk, plan->th = p.TH, plan->tw = p.TW, plan->splits = p.S;
   plan->workgroups = (p.co_pad / (32 * p.wco)) * (p.ci_pad / (32 * p.wci)) * p.S;
   return CY_OK;
@@ -948,6 +958,8 @@ static int wgrad_impl(const cy_conv_desc* d, const void* src1, const void* src2,
   int rc;
   if (d->in_dtype == CY_F32) {
     rc = launch_wgrad<float, 1, 1, 4>(g, p, st);
+  } else if (p.spec) {
+    rc = d->in_dtype == CY_F16 ? launch_wgrad12s<f16>(g, p, st) : launch_wgrad12s<bf16>(g, p, st);
   } else if (p.twelve && d->in_dtype == CY_F16) {
     if (p.wco == 2 && p.wci == 2) rc = launch_wgrad12<2, 2, 1, f16>(g, p, st);
     else if (p.wco == 2) rc = launch_wgrad12<2, 1, 2, f16>(g, p, st);

@@ -1,0 +1,375 @@
+// Wave-specialised form of the twelve-wave weight-gradient kernel for the 64 x 64 (co, ci) block (16 of the
+// U-Net's 21 layers).  Included by cy_wgrad.hip (WgradArgs, Wg12Cfg, WFrag, halo_chunk come from there).
+//
+// wgrad12_kernel gives every wave both jobs -- request / commit a slice of the next tile, then the MFMAs of one
+// kernel row -- and its stamps say where a tile's 15 500 cycles go: 3 900 in the request
+// burst (the CU's address unit takes ~40 cycles per 64-lane 16-byte gather, and all twelve waves queue there at the
+// same time), 5 700 in an MFMA loop that the LDS side bounds (1.33 fragment reads per MFMA), 1 700 commit, 4 200
+// barrier skew -- strictly one after the other, because every wave is in the same phase.
+// Here the phases belong to different waves and overlap:
+//  * waves 8-11 (256 threads, one per SIMD) are the LOADERS: commit tile j+1 (requested one tile period earlier, so
+//    the global latency is covered by a whole tile), request tile j+2, barrier.  65 gathers per tile instead of 84,
+//    no MFMA wave ever waits in the address unit's queue;
+//  * waves 0-7 own one 32 x 32 block (wave & 3) and taps 0-4 (waves 0-3) or 5-8 (waves 4-7): one dy fragment +
+//    4-5 input fragments for 4-5 MFMAs (1.2 fragment reads per MFMA), 80 accumulator registers; SIMD s runs waves
+//    s and s + 4 = nine taps of one block each: the MFMA work is balanced over the four SIMDs.
+// One barrier per tile as before: at the barrier tile j+1 is complete in the other LDS buffer and tile j has been
+// consumed.  The slabs and their reduction are unchanged (bitwise the same summation order per slab).
+#pragma once
+
+template <bool V> struct Wg12sFlag {
+  static constexpr bool value = V;
+};
+
+constexpr int WG12S_SMEM = Wg12Cfg<2, 2, 1>::MAIN + 256 * 4 + 344 * 4 + 16;  // + the halo item table
+static_assert(WG12S_SMEM <= 160 * 1024, "LDS");
+
+// MFMA role of wgrad12s_kernel: block `blk` (co half = blk >> 1, ci half = blk & 1), taps TAP0 .. TAP0 + NTAP - 1
+template <typename T, int TAP0, int NTAP>
+__device__ __forceinline__ void wg12s_mfma_role(const WgradArgs& g, unsigned char* smem, const int* s_ktab, int blk,
+                                                int lane, int nsteps, int nmine, int co0, int ci0, int split) {
+  using C = Wg12Cfg<2, 2, 1>;
+  constexpr int PA = C::PA, PB = C::PB, HW2 = C::HP;
+  const int r = lane & 31, h = lane >> 5;
+  const int cb = blk >> 1, ib = blk & 1;
+  f32x16 acc[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  // per-lane constants of the transposed fragment reads (see wgrad_kernel)
+  const int q = (lane & 15) >> 2, p4 = lane & 3, gsel = (lane >> 4) & 1;
+  const int cola = (cb * 32 + 16 * gsel + 4 * p4) * 2;
+  const int colb = (ib * 32 + 16 * gsel + 4 * p4) * 2;
+
+  __syncthreads();  // tables published
+  __syncthreads();  // first tile staged
+#ifdef CY_WGRAD_STAMPS
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool stamping = g.c.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+  unsigned long long ph_sum[4] = {0ull, 0ull, 0ull, 0ull}, t_last = stamping ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
+  for (int j = 0; j < nmine; ++j) {
+    const unsigned char* sDy = smem + (j & 1) * C::BUF;
+    const unsigned char* sIn = sDy + C::A_BYTES;
+    for (int step = 0; step < nsteps; ++step) {
+      const int k1 = step * 16 + 8 * h + q;
+      // (k1 >> 1) & 1 == ((k1 + 4) >> 1) & 1: both dy rows share the swizzle term
+      const unsigned char* arow = sDy + k1 * PA + (cola ^ (((k1 >> 1) & 1) << 6));
+      const typename Mma<T>::Frag af = WFrag<T>::load(arow, arow + 4 * PA);
+      const int p1 = s_ktab[k1], p2 = s_ktab[k1 + 4];  // (pad pixels map to pixel 0; their dy rows are zero)
+      // the swizzle term of pixel p + dh*HW2 + dw depends on dw only (HW2 % 4 == 0)
+      int c1[3], c2[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        c1[d] = colb ^ ((((p1 + d - 1) >> 1) & 1) << 6);
+        c2[d] = colb ^ ((((p2 + d - 1) >> 1) & 1) << 6);
+      }
+      const unsigned char* b1 = sIn + p1 * PB;
+      const unsigned char* b2 = sIn + p2 * PB;
+      typename Mma<T>::Frag bf[NTAP];
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        const int tap = TAP0 + t;
+        const int off = ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) * PB;
+        bf[t] = WFrag<T>::load(b1 + off + c1[tap % 3], b2 + off + c2[tap % 3]);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) Mma<T>::mma(af, bf[t], acc[t]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    W12_STAMP(1);
+    __syncthreads();  // this tile consumed by every wave, the next one staged
+    W12_STAMP(3);
+  }
+#ifdef CY_WGRAD_STAMPS
+  if (stamping && lane == 0) {
+    for (int q = 0; q < 4; ++q) g.c.stamps[wave * 8 + q] = ph_sum[q];
+    g.c.stamps[wave * 8 + 4] = (unsigned long long)nmine;
+  }
+#endif
+
+  // ---- write the split's slab: this wave's taps of its block ----
+  float* slab = g.ws + (size_t)split * 9 * g.co_pad * g.ci_pad;
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      slab[((size_t)(TAP0 + t) * g.co_pad + co0 + cb * 32 + row) * g.ci_pad + ci0 + ib * 32 + r] = acc[t][reg];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(768, 1)
+    wgrad12s_kernel(const WgradArgs g) {
+  using C = Wg12Cfg<2, 2, 1>;
+  constexpr int PA = C::PA, PB = C::PB, CPA = C::CPA, CPB = C::CPB;
+  constexpr int EPC = 8;
+  constexpr int SWA = 2, SWB = 2;  // pair swizzle of 128-byte pixels
+  constexpr int HW2 = C::HP;
+  constexpr int NL = 256;  // loader threads
+  constexpr int NDY = (C::MAXPIX * CPA + NL - 1) / NL;
+  constexpr int NHL = (C::MAXITEMS * CPB + NL - 1) / NL;
+  static_assert(PA == 128 && PB == 128 && NL % CPA == 0 && NL % CPB == 0, "64 x 64 block, 16-bit");
+  static_assert(NHL <= 32, "hok mask");
+  const ConvArgs& a = g.c;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* s_ktab = reinterpret_cast<int*>(smem + C::MAIN);  // tile pixel k -> halo pixel (ty+1)*HP + tx+1
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 8;
+  const int lt = tid - 512;  // loader thread index
+
+  const int TH = g.TH, TW = g.TW;
+  const int npix = TH * TW;
+  const int nsteps = (npix + 15) / 16;
+  const int npix_pad = nsteps * 16;
+  const int ci_tiles = g.ci_pad / C::BCI;
+  const int co_t = blockIdx.x / ci_tiles, ci_t = blockIdx.x % ci_tiles;
+  const int co0 = co_t * C::BCO, ci0 = ci_t * C::BCI;
+  const int split = blockIdx.y;
+  const int ntiles = g.tiles_h * g.tiles_w;
+  const int nmine = (ntiles - split + g.S - 1) / g.S;  // tiles split, split + S, ...
+
+  if (tid < 256) {
+    const int kk = tid < npix ? tid : 0;
+    const int ty = kk / TW, tx = kk - ty * TW;
+    s_ktab[tid] = (ty + 1) * HW2 + tx + 1;
+  }
+  // halo item -> LDS halo pixel (row * HP + column): with the two tables the loaders' per-item index arithmetic has
+  // no division by a run-time tile width left (19 items x two such divisions per tile made the four loader waves
+  // the slowest part of the first version of this kernel)
+  int* s_htab = s_ktab + 256;
+  {
+    const int HWt_ = TW + 2, nh_ = (TH + 2) * HWt_;
+    if (tid >= 256 && tid - 256 < nh_) {
+      const int lin = tid - 256;
+      const int hr = lin / HWt_, hc = lin - hr * HWt_;
+      s_htab[lin] = hr * HW2 + hc;
+    }
+  }
+
+  if (loader) {
+    // (the loaders' few hundred instructions per tile go in front of the MFMA waves' on the shared SIMD)
+    __builtin_amdgcn_s_setprio(3);
+    // ---- staging: request (global -> registers) / commit (registers -> LDS buffer), 256 threads ----------
+    const int ld1v = a.ld1, ld2v = a.ld2;
+    const int cha = lt % CPA, chb = lt % CPB;
+    const int HWt = TW + 2;
+    const int nhalo = (TH + 2) * HWt;
+    const int cabs = ci0 + chb * EPC;
+    const bool in2 = cabs >= a.C1;
+    const bool cvalid = cabs < a.C1 + a.C2;
+    const bool pooled = a.mode1 == CY_SRC_POOL2 && !in2;  // 2x2 max on load: staged in the commit phase
+    const bool pro = a.prologue && !in2 && cvalid;
+    float psc[EPC], psh[EPC];
+    int coef_seg = -1;
+    struct Seg {
+      const T* dy;
+      const T* s1;
+      const T* s2;
+      int rt, id;
+    };
+    auto segment = [&](int rt) {
+      Seg sg;
+      const bool second = rt >= g.tiles_h_a;
+      sg.id = second ? 1 : 0;
+      sg.rt = second ? rt - g.tiles_h_a : rt;
+      sg.dy = reinterpret_cast<const T*>(second ? g.dy_b : g.dy);
+      sg.s1 = reinterpret_cast<const T*>(second ? g.src1_b : a.src1);
+      sg.s2 = reinterpret_cast<const T*>(second ? g.src2_b : a.src2);
+      return sg;
+    };
+    auto src_row = [&](int n, int hh) -> int {  // pixel index of (row hh of image n, column 0), or -1
+      if (hh < 0 || hh >= a.H) return -1;
+      if (in2 || a.mode1 == CY_SRC_DIRECT) return (n * a.H + hh) * a.W;
+      if (a.mode1 == CY_SRC_POOL2) return (n * 2 * a.H + 2 * hh) * (2 * a.W);
+      return (n * (a.H >> 1) + (hh >> 1)) * (a.W >> 1);
+    };
+    u32x4 dreg[NDY], hreg[NHL];
+    unsigned dok = 0, hok = 0;  // bit i: item i holds loaded data (else it stands for zeros)
+    // k / TW and lin / (TW + 2) by multiplication (exact for operands < 512, divisors <= 64): the loaders must not
+    // depend on LDS table reads -- the LDS queue is full of the MFMA waves' fragment reads, and a dependent table
+    // read per item put ~600 cycles of latency in front of every global load
+    const int mtw = (65536 + TW - 1) / TW, mhw = (65536 + HWt - 1) / HWt;
+    // One pass over the items: item i of the tile IN the registers goes to LDS (`tc`, if >= 0), then the same
+    // register receives item i of tile `tr` (if >= 0).  Commit and request therefore overlap -- the LDS pipe (busy
+    // with the MFMA waves' fragment reads) and the address unit work at the same time -- instead of costing their
+    // sum (stamps of the first version: commit 5 200 + request 6 000 cycles per tile against an MFMA loop of 6 600).
+    // Every load is unconditional (clamped address + validity bit): a conditional one makes the compiler wait for
+    // ALL outstanding loads before each store.
+    // (the item -> pixel index arithmetic of 19 items is loop invariant; hoisted out of the tile loop it costs more
+    //  registers than there are -- an opaque copy of the thread index keeps it inside)
+    auto swap = [&](auto DC, auto DR, int tc, unsigned char* sDy, unsigned char* sIn, int tr) {
+      int lv = lt;
+      asm volatile("" : "+v"(lv));
+      constexpr bool do_c = decltype(DC)::value, do_r = decltype(DR)::value;  // (compile time: no branch in the item loops)
+      const int trc = do_r ? tr : 0;
+      const int ct = trc % g.tiles_w;
+      const Seg sg = segment(trc / g.tiles_w);
+      const int R0 = sg.rt * TH, w0 = ct * TW;
+      const int n = R0 / a.H, hh0 = R0 - n * a.H;
+      const int co = co0 + cha * EPC;
+      unsigned ndok = 0, nhok = 0;
+#pragma unroll
+      for (int i = 0; i < NDY; ++i) {
+        const int k = (lv + i * NL) / CPA;
+        if (do_c && k < npix_pad) {
+          const u32x4 v = ((dok >> i) & 1u) ? dreg[i] : u32x4{0u, 0u, 0u, 0u};
+          st16(sDy + k * PA + (halo_chunk<PA, SWA>(k, cha) << 4), v);
+        }
+        if (do_r) {
+          const int ty = (k * mtw) >> 16, tx = k - ty * TW;
+          const int w = w0 + tx;
+          const bool ok = k < npix && co < a.Cout && w < a.W;
+          const size_t off = ok ? ((size_t)(R0 + ty) * a.W + w) * g.ldy + co : 0;
+          dreg[i] = ld16(sg.dy + off);
+          ndok |= (ok ? 1u : 0u) << i;
+        }
+      }
+      if (pooled) {
+        if (do_c) {  // 2x2 max on load: synchronous
+          const int ctc = tc % g.tiles_w;
+          const Seg sc = segment(tc / g.tiles_w);
+          const int R0c = sc.rt * TH, w0c = ctc * TW;
+          const int nc = R0c / a.H, hh0c = R0c - nc * a.H;
+          for (int lin = lt / CPB; lin < nhalo; lin += NL / CPB) {
+            const int pix = s_htab[lin];
+            const int hr = pix / HW2, hc = pix - hr * HW2;
+            const int w = w0c - 1 + hc;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            const int rp = src_row(nc, hh0c - 1 + hr);
+            if (cvalid && w >= 0 && w < a.W && rp >= 0) {
+              const T* p = sc.s1 + (size_t)(rp + 2 * w) * a.ld1 + cabs;
+              const size_t rowstep = (size_t)(2 * a.W) * a.ld1;
+              const u32x4 v00 = ld16(p), v01 = ld16(p + a.ld1), v10 = ld16(p + rowstep),
+                          v11 = ld16(p + rowstep + a.ld1);
+              float f0[EPC], f1[EPC], f2[EPC], f3[EPC];
+              Chunk<T>::unpack(v00, f0);
+              Chunk<T>::unpack(v01, f1);
+              Chunk<T>::unpack(v10, f2);
+              Chunk<T>::unpack(v11, f3);
+#pragma unroll
+              for (int j = 0; j < EPC; ++j) f0[j] = fmaxf(fmaxf(f0[j], f1[j]), fmaxf(f2[j], f3[j]));
+              v = Chunk<T>::pack(f0);
+            }
+            st16(sIn + pix * PB + (halo_chunk<PB, SWB>(pix, chb) << 4), v);
+          }
+        }
+      } else {
+        const T* base = in2 ? sg.s2 + (cabs - a.C1) : sg.s1 + cabs;
+        const int ld = in2 ? ld2v : ld1v;
+        const int wsh = (!in2 && a.mode1 == CY_SRC_UP2) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < NHL; ++i) {
+          const int lin = (lv + i * NL) / CPB;
+          const int hr = (lin * mhw) >> 16, hc = lin - hr * HWt;
+          const int pix = hr * HW2 + hc;
+          if (do_c && lin < nhalo) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if ((hok >> i) & 1u) {
+              v = hreg[i];
+              if (pro) {
+                float f[EPC];
+                Chunk<T>::unpack(v, f);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(psc[j], f[j], psh[j]), 0.f);
+                v = Chunk<T>::pack(f);
+              }
+            }
+            st16(sIn + pix * PB + (halo_chunk<PB, SWB>(pix, chb) << 4), v);
+          }
+          if (do_r) {
+            const int w = w0 - 1 + hc;
+            const int rp = src_row(n, hh0 - 1 + hr);
+            const bool ok = lin < nhalo && cvalid && w >= 0 && w < a.W && rp >= 0;
+            const size_t off = ok ? (size_t)(rp + (w >> wsh)) * ld : 0;
+            hreg[i] = ld16((ok ? base : sg.s1) + off);
+            nhok |= (ok ? 1u : 0u) << i;
+          }
+        }
+      }
+      if (do_r) {
+        dok = ndok, hok = nhok;
+        if (pro && sg.id != coef_seg) {  // coefficients of the segment whose data the registers now hold
+          const float* sc = sg.id ? g.scale_b : a.scale;
+          const float* sh = sg.id ? g.shift_b : a.shift;
+#pragma unroll
+          for (int j = 0; j < EPC; ++j) {
+            psc[j] = sc[cabs + j];
+            psh[j] = sh[cabs + j];
+          }
+          coef_seg = sg.id;
+        }
+      }
+    };
+
+    using Yes = Wg12sFlag<true>;
+    using No = Wg12sFlag<false>;
+    __syncthreads();  // tables published
+    swap(No{}, Yes{}, -1, smem, smem + C::A_BYTES, split);
+    if (nmine > 1)
+      swap(Yes{}, Yes{}, split, smem, smem + C::A_BYTES, split + g.S);
+    else
+      swap(Yes{}, No{}, split, smem, smem + C::A_BYTES, -1);
+    __syncthreads();  // first tile staged
+#ifdef CY_WGRAD_STAMPS
+    const bool stamping = g.c.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+    unsigned long long ph_sum[4] = {0ull, 0ull, 0ull, 0ull}, t_last = stamping ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
+    int j = 0;
+    for (; j + 2 < nmine; ++j) {  // steady state: straight-line item loops
+      unsigned char* nb = smem + ((j + 1) & 1) * C::BUF;
+      swap(Yes{}, Yes{}, split + (j + 1) * g.S, nb, nb + C::A_BYTES, split + (j + 2) * g.S);
+      W12_STAMP(0);
+      __syncthreads();  // tile j consumed by the MFMA waves, tile j+1 staged
+      W12_STAMP(3);
+    }
+    for (; j < nmine; ++j) {
+      if (j + 1 < nmine) {
+        unsigned char* nb = smem + ((j + 1) & 1) * C::BUF;
+        swap(Yes{}, No{}, split + (j + 1) * g.S, nb, nb + C::A_BYTES, -1);
+      }
+      W12_STAMP(0);
+      __syncthreads();
+      W12_STAMP(3);
+    }
+#ifdef CY_WGRAD_STAMPS
+    if (stamping && lane == 0) {
+      for (int q = 0; q < 4; ++q) g.c.stamps[wave * 8 + q] = ph_sum[q];
+      g.c.stamps[wave * 8 + 4] = (unsigned long long)nmine;
+    }
+#endif
+    return;
+  }
+
+  // ---- MFMA waves ----
+  if (wave < 4)
+    wg12s_mfma_role<T, 0, 5>(g, smem, s_ktab, wave & 3, lane, nsteps, nmine, co0, ci0, split);
+  else
+    wg12s_mfma_role<T, 5, 4>(g, smem, s_ktab, wave & 3, lane, nsteps, nmine, co0, ci0, split);
+}
+
+template <typename T>
+int launch_wgrad12s(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
+  using C = Wg12Cfg<2, 2, 1>;
+  auto kern = wgrad12s_kernel<T>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            WG12S_SMEM) != hipSuccess)
+      return CY_ERR_LAUNCH;
+    attr_done = true;
+  }
+  dim3 grid((p.co_pad / C::BCO) * (p.ci_pad / C::BCI), p.S);
+  WgradArgs ga = g;
+  ga.c.stamps = g_w12_stamp_buf;
+  hipLaunchKernelGGL(kern, grid, dim3(768), WG12S_SMEM, st, ga);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}

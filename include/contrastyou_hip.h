@@ -169,7 +169,7 @@ int cy_conv3x3_wgrad(const cy_conv_desc* d, const void* src1, const void* src2, 
 
 /* Launch plan of the weight gradient for `d` (+ n_b images of a second segment, 0 for none). */
 typedef struct cy_wgrad_plan {
-  int32_t twelve;        /* 1: wgrad12_kernel (bf16), 0: wgrad_kernel */
+  int32_t twelve;        /* 2: wgrad12s_kernel (wave-specialised, 64x64 blocks), 1: wgrad12_kernel, 0: wgrad_kernel */
   int32_t wco, wci, wk;  /* wave layout: 32x32 (co,ci) blocks per workgroup and pixel splits inside it */
   int32_t th, tw;        /* spatial tile */
   int32_t splits;        /* pixel splits = f32 slabs summed by wgrad_reduce_kernel */

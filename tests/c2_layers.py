@@ -50,6 +50,8 @@ def conv_kernel_name(plan: dict, dtype_tag: str = "DF16b", cin: int = 0, stats: 
 
 
 def wgrad_kernel_name(plan: dict) -> str:
+    if plan["twelve"] == 2:
+        return "wgrad12s_kernel"
     base = "wgrad12_kernel" if plan["twelve"] else "wgrad_kernel"
     return f"{base}<{plan['wco']}, {plan['wci']}, {plan['wk']}"  # (prefix: a trailing type argument may follow)
 
@@ -63,6 +65,8 @@ def profiled_conv_kernels(path: Path):
         m = re.search(r"(conv3x3_(?:plane8|plane|igemm|pc|stream)_kernelI\w+?)Ev", tok)
         if m:
             names.add(m.group(1))
+        if "wgrad12s_kernel" in tok:
+            names.add("wgrad12s_kernel")
         m = re.match(r"(wgrad(?:12)?_kernel<)(?:[A-Za-z_]\w*, )?(\d+, \d+, \d+)", tok)
         if m:
             names.add(m.group(1) + m.group(2))
