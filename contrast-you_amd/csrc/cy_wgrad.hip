@@ -700,6 +700,8 @@ WgPlan plan_wgrad(const cy_conv_desc* d) {
   }();
   // (measured per layer at N = 32: the pooled-on-load layers -- four synchronous loads per halo item in the loaders --
   //  and the 14 x 14 layers -- 98-pixel tiles -- are faster in the unspecialised kernel)
+  // (the kernel is written for any block shape; on the 32- / 64-channel layers of the 224^2 and 112^2 levels, where a
+  //  tile's loads outweigh its MFMAs 4 : 1, four loader waves are too few: Conv1b 89 -> 109 us, Up_conv2b 80 -> 95 us)
   p.spec = p.twelve && spec_enabled && p.wco == 2 && p.wci == 2 && d->mode1 != CY_SRC_POOL2 && d->W >= 28;
   p.co_pad = cy_roundup(d->Cout, 32 * p.wco);
   p.ci_pad = cy_roundup(Cin, 32 * p.wci);
@@ -965,7 +967,7 @@ static int wgrad_impl(const cy_conv_desc* d, const void* src1, const void* src2,
   if (d->in_dtype == CY_F32) {
     rc = launch_wgrad<float, 1, 1, 4>(g, p, st);
   } else if (p.spec) {
-    rc = d->in_dtype == CY_F16 ? launch_wgrad12s<f16>(g, p, st) : launch_wgrad12s<bf16>(g, p, st);
+    rc = d->in_dtype == CY_F16 ? dispatch_wgrad12s<f16>(g, p, st) : dispatch_wgrad12s<bf16>(g, p, st);
   } else if (p.twelve && d->in_dtype == CY_F16) {
     if (p.wco == 2 && p.wci == 2) rc = launch_wgrad12<2, 2, 1, f16>(g, p, st);
     else if (p.wco == 2) rc = launch_wgrad12<2, 1, 2, f16>(g, p, st);

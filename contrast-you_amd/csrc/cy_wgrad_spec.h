@@ -21,17 +21,26 @@ template <bool V> struct Wg12sFlag {
   static constexpr bool value = V;
 };
 
-constexpr int WG12S_SMEM = Wg12Cfg<2, 2, 1>::MAIN + 256 * 4 + 344 * 4 + 16;  // + the halo item table
-static_assert(WG12S_SMEM <= 160 * 1024, "LDS");
+template <int WCO, int WCI> struct Wg12sCfg : Wg12Cfg<WCO, WCI, 4 / (WCO * WCI)> {
+  using B = Wg12Cfg<WCO, WCI, 4 / (WCO * WCI)>;
+  static constexpr int NBLK = WCO * WCI, WK = 4 / NBLK;  // 32 x 32 blocks, pixel splits inside a tap group
+  static constexpr int SMEM = B::MAIN + 256 * 4 + 344 * 4 + 16;  // + the halo item table
+  static_assert(SMEM <= 160 * 1024, "LDS");
+  static_assert(WK == 1 || 8 * 16 * 64 * 4 <= B::MAIN, "pixel-split reduction buffer");
+};
 
-// MFMA role of wgrad12s_kernel: block `blk` (co half = blk >> 1, ci half = blk & 1), taps TAP0 .. TAP0 + NTAP - 1
-template <typename T, int TAP0, int NTAP>
+// MFMA role of wgrad12s_kernel: block `blk` (co block = blk / WCI, ci block = blk % WCI), taps TAP0 .. TAP0 + NTAP - 1,
+// steps wk, wk + WK, ... of every tile (WK = 4 / blocks pixel splits; their accumulators are added through LDS
+// at the end, in split order)
+template <typename T, int WCO, int WCI, int TAP0, int NTAP>
 __device__ __forceinline__ void wg12s_mfma_role(const WgradArgs& g, unsigned char* smem, const int* s_ktab, int blk,
-                                                int lane, int nsteps, int nmine, int co0, int ci0, int split) {
-  using C = Wg12Cfg<2, 2, 1>;
-  constexpr int PA = C::PA, PB = C::PB, HW2 = C::HP;
+                                                int wk, int lane, int nsteps, int nmine, int co0, int ci0,
+                                                int split) {
+  using C = Wg12sCfg<WCO, WCI>;
+  constexpr int PA = C::PA, PB = C::PB, HW2 = C::HP, WK = C::WK, NBLK = C::NBLK;
+  constexpr bool SWA = PA == 128, SWB = PB == 128;  // pair swizzle of 128-byte pixels
   const int r = lane & 31, h = lane >> 5;
-  const int cb = blk >> 1, ib = blk & 1;
+  const int cb = blk / WCI, ib = blk % WCI;
   f32x16 acc[NTAP];
 #pragma unroll
   for (int t = 0; t < NTAP; ++t)
@@ -52,18 +61,18 @@ __device__ __forceinline__ void wg12s_mfma_role(const WgradArgs& g, unsigned cha
   for (int j = 0; j < nmine; ++j) {
     const unsigned char* sDy = smem + (j & 1) * C::BUF;
     const unsigned char* sIn = sDy + C::A_BYTES;
-    for (int step = 0; step < nsteps; ++step) {
+    for (int step = wk; step < nsteps; step += WK) {
       const int k1 = step * 16 + 8 * h + q;
       // (k1 >> 1) & 1 == ((k1 + 4) >> 1) & 1: both dy rows share the swizzle term
-      const unsigned char* arow = sDy + k1 * PA + (cola ^ (((k1 >> 1) & 1) << 6));
+      const unsigned char* arow = sDy + k1 * PA + (cola ^ (SWA ? (((k1 >> 1) & 1) << 6) : 0));
       const typename Mma<T>::Frag af = WFrag<T>::load(arow, arow + 4 * PA);
       const int p1 = s_ktab[k1], p2 = s_ktab[k1 + 4];  // (pad pixels map to pixel 0; their dy rows are zero)
       // the swizzle term of pixel p + dh*HW2 + dw depends on dw only (HW2 % 4 == 0)
       int c1[3], c2[3];
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        c1[d] = colb ^ ((((p1 + d - 1) >> 1) & 1) << 6);
-        c2[d] = colb ^ ((((p2 + d - 1) >> 1) & 1) << 6);
+        c1[d] = colb ^ (SWB ? ((((p1 + d - 1) >> 1) & 1) << 6) : 0);
+        c2[d] = colb ^ (SWB ? ((((p2 + d - 1) >> 1) & 1) << 6) : 0);
       }
       const unsigned char* b1 = sIn + p1 * PB;
       const unsigned char* b2 = sIn + p2 * PB;
@@ -92,27 +101,53 @@ __device__ __forceinline__ void wg12s_mfma_role(const WgradArgs& g, unsigned cha
 
   // ---- write the split's slab: this wave's taps of its block ----
   float* slab = g.ws + (size_t)split * 9 * g.co_pad * g.ci_pad;
+  if constexpr (WK > 1) {
+    // the WK waves of a (tap group, block) add their accumulators in split order; five rounds for both tap groups
+    // (the loader waves have ended: the barrier counts the eight MFMA waves)
+    float* red = reinterpret_cast<float*>(smem);  // [wave 0..7][16][64]
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
-  for (int t = 0; t < NTAP; ++t)
+    for (int t = 0; t < 5; ++t) {
+      __syncthreads();
+      if (t < NTAP) {
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      slab[((size_t)(TAP0 + t) * g.co_pad + co0 + cb * 32 + row) * g.ci_pad + ci0 + ib * 32 + r] = acc[t][reg];
+        for (int reg = 0; reg < 16; ++reg) red[(wv * 16 + reg) * 64 + lane] = acc[t < NTAP ? t : 0][reg];
+      }
+      __syncthreads();
+      if (t < NTAP && wk == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          float sum = 0.f;
+#pragma unroll
+          for (int qq = 0; qq < WK; ++qq) sum += red[((wv + qq * NBLK) * 16 + reg) * 64 + lane];
+          const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          slab[((size_t)(TAP0 + t) * g.co_pad + co0 + cb * 32 + row) * g.ci_pad + ci0 + ib * 32 + r] = sum;
+        }
+      }
     }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        slab[((size_t)(TAP0 + t) * g.co_pad + co0 + cb * 32 + row) * g.ci_pad + ci0 + ib * 32 + r] = acc[t][reg];
+      }
+  }
 }
 
-template <typename T>
+template <typename T, int WCO, int WCI>
 __global__ void __launch_bounds__(768, 1)
     wgrad12s_kernel(const WgradArgs g) {
-  using C = Wg12Cfg<2, 2, 1>;
+  using C = Wg12sCfg<WCO, WCI>;
   constexpr int PA = C::PA, PB = C::PB, CPA = C::CPA, CPB = C::CPB;
   constexpr int EPC = 8;
-  constexpr int SWA = 2, SWB = 2;  // pair swizzle of 128-byte pixels
+  constexpr int SWA = PA == 128 ? 2 : 0, SWB = PB == 128 ? 2 : 0;  // pair swizzle of 128-byte pixels
   constexpr int HW2 = C::HP;
   constexpr int NL = 256;  // loader threads
   constexpr int NDY = (C::MAXPIX * CPA + NL - 1) / NL;
   constexpr int NHL = (C::MAXITEMS * CPB + NL - 1) / NL;
-  static_assert(PA == 128 && PB == 128 && NL % CPA == 0 && NL % CPB == 0, "64 x 64 block, 16-bit");
+  static_assert(NL % CPA == 0 && NL % CPB == 0, "a loader thread keeps its channel chunk");
   static_assert(NHL <= 32, "hok mask");
   const ConvArgs& a = g.c;
 
@@ -348,28 +383,37 @@ __global__ void __launch_bounds__(768, 1)
     return;
   }
 
-  // ---- MFMA waves ----
+  // ---- MFMA waves: tap group = wave >> 2 (one of each per SIMD), block and pixel split from wave & 3 ----
+  const int sub = wave & 3;
   if (wave < 4)
-    wg12s_mfma_role<T, 0, 5>(g, smem, s_ktab, wave & 3, lane, nsteps, nmine, co0, ci0, split);
+    wg12s_mfma_role<T, WCO, WCI, 0, 5>(g, smem, s_ktab, sub % C::NBLK, sub / C::NBLK, lane, nsteps, nmine, co0, ci0,
+                                       split);
   else
-    wg12s_mfma_role<T, 5, 4>(g, smem, s_ktab, wave & 3, lane, nsteps, nmine, co0, ci0, split);
+    wg12s_mfma_role<T, WCO, WCI, 5, 4>(g, smem, s_ktab, sub % C::NBLK, sub / C::NBLK, lane, nsteps, nmine, co0, ci0,
+                                       split);
 }
 
-template <typename T>
+template <typename T, int WCO, int WCI>
 int launch_wgrad12s(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
-  using C = Wg12Cfg<2, 2, 1>;
-  auto kern = wgrad12s_kernel<T>;
+  using C = Wg12sCfg<WCO, WCI>;
+  auto kern = wgrad12s_kernel<T, WCO, WCI>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            WG12S_SMEM) != hipSuccess)
+                            C::SMEM) != hipSuccess)
       return CY_ERR_LAUNCH;
     attr_done = true;
   }
   dim3 grid((p.co_pad / C::BCO) * (p.ci_pad / C::BCI), p.S);
   WgradArgs ga = g;
   ga.c.stamps = g_w12_stamp_buf;
-  hipLaunchKernelGGL(kern, grid, dim3(768), WG12S_SMEM, st, ga);
+  hipLaunchKernelGGL(kern, grid, dim3(768), C::SMEM, st, ga);
   CY_CHECK_LAUNCH();
   return CY_OK;
+}
+
+template <typename T>
+int dispatch_wgrad12s(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
+  if (p.wco == 2 && p.wci == 2) return launch_wgrad12s<T, 2, 2>(g, p, st);
+  return CY_ERR_SHAPE;  // (<2,1>, <1,2>, <1,1> compile and pass the parity tests but are slower than wgrad12_kernel: not built)
 }
