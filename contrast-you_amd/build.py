@@ -24,6 +24,14 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"] + os.environ.get("CY_HIPCC_EXTRA", "").split()
 
 
+# per-file flags (kept empty unless a file needs one; CY_HIPCC_EXTRA_<STEM> adds to a single file for experiments)
+PER_FILE = {}
+
+
+def _file_flags(src: Path):
+    return PER_FILE.get(src.stem, []) + os.environ.get("CY_HIPCC_EXTRA_" + src.stem.upper(), "").split()
+
+
 def _deps_mtime() -> float:
     hdrs = list(CSRC.glob("*.h")) + [HERE.parent / "include" / "contrastyou_hip.h"]
     return max(p.stat().st_mtime for p in hdrs)
@@ -33,7 +41,7 @@ def _compile(src: Path, force: bool) -> Path:
     obj = OBJ / (src.stem + ".o")
     if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, _deps_mtime()):
         return obj
-    cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+    cmd = [HIPCC, *FLAGS, *_file_flags(src), "-c", str(src), "-o", str(obj)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")

@@ -559,18 +559,17 @@ __global__ void __launch_bounds__(256, 2)
     ghi[t] = dpm_goff(rh, 4 * gsel + p4) - t * 1024;
   }
 
+  // (as in the dW1 kernel: only the next job's first pixel block is requested ahead -- this kernel never showed that
+  //  kernel's run-to-run differences with the coefficient loads in flight too, but the cause there is not understood)
   DpRec cur = dpm_rec(recs, gw, njobs, colour);
   float dpos[NHB];
   u32x4 f0[2], f1[2];
-#pragma unroll
-  for (int hb = 0; hb < NHB; ++hb) dpos[hb] = dpm_rec_coef(dhpool, cur, hid, hb * 32 + r);
   dpm_rec_rows<T>(x, cur, W, ldx, 0, r, h, f0);
   for (int job = gw; job < njobs; job += nw) {
-    const DpRec nxt = dpm_rec(recs, job + nw, njobs, colour);
-    float dnxt[NHB];
-    u32x4 n0[2];
 #pragma unroll
-    for (int hb = 0; hb < NHB; ++hb) dnxt[hb] = dpm_rec_coef(dhpool, nxt, hid, hb * 32 + r);
+    for (int hb = 0; hb < NHB; ++hb) dpos[hb] = dpm_rec_coef(dhpool, cur, hid, hb * 32 + r);
+    const DpRec nxt = dpm_rec(recs, job + nw, njobs, colour);
+    u32x4 n0[2];
     dpm_rec_rows<T>(x, nxt, W, ldx, 0, r, h, n0);
     const DpRec& J = cur;
     const int nblk = cur.nblk;
@@ -647,8 +646,6 @@ __global__ void __launch_bounds__(256, 2)
       block(f1, blk + 1);
     }
     if (nblk & 1) block(f0, nblk - 1);
-#pragma unroll
-    for (int hb = 0; hb < NHB; ++hb) dpos[hb] = dnxt[hb];
     cur = nxt;
     f0[0] = n0[0], f0[1] = n0[1];
   }
