@@ -5,7 +5,8 @@
 // No workgroup-level cooperation: a WAVE owns a job (a bin, or a cell of the bin partition) and walks its
 // pixels 32 at a time.  The 1x1 convolution of a block of 32 pixels is 2 x (hid/32) MFMAs whose operands need no
 // LDS at all: the A fragment of pixel-row r is 16 contiguous bytes of the NHWC map (one global load per lane), the
-// B fragments (W1 rounded to the storage type) live in registers for the life of the wave.  D[pixel][hidden]
+// B fragments (W1 rounded to the storage type) live in registers for the life of the wave (forward) or in an LDS image
+// (backward kernels, which need the registers for their second product).  D[pixel][hidden]
 // leaves lane (o, half) with 16 pixels of hidden unit o, so the leaky-ReLU + pixel sum (forward) and the
 // multiplication with the pooled gradient (backward) are per-lane VALU work -- which is what bounds these
 // kernels (3-4 VALU operations per (pixel, hidden) pair against 1/16 MFMA).
