@@ -25,7 +25,9 @@ class AMPScaler:
         self._autocast_dtype = autocast_dtype
 
     def scale_loss(self, loss):
-        return self.scaler.scale(loss / self._accumulate_iter)
+        if self._accumulate_iter != 1:  # (x / 1 is a launch forward and one backward)
+            loss = loss / self._accumulate_iter
+        return self.scaler.scale(loss)
 
     def optimizer_step(self, optimizer, *, cur_iter: int):
         """step optimizer and scaler on the last micro-batch of an accumulation window"""

@@ -81,9 +81,9 @@ class SupConLoss1(nn.Module):
         P = torch.cat([proj_feat1, proj_feat2], dim=0)
         loss, diag, stats = SupConFn.apply(P, labels, pos, float(self._t))
         self._last = (P.detach(), stats, labels, pos)
-        # device-side evidence for the reference's two checks
-        norm_err = (diag * self._t - 1).abs().max()
-        self._pending.append((norm_err, loss.detach()))
+        # device-side evidence for the reference's two checks: one aminmax launch now, the arithmetic in validate()
+        mn, mx = torch.aminmax(diag)
+        self._pending.append((mn, mx, loss.detach()))
         if not self.defer_checks:
             self.validate()
         return loss
@@ -93,8 +93,9 @@ class SupConLoss1(nn.Module):
         pending, self._pending = self._pending, []
         if not pending:
             return
-        errs = torch.stack([p[0] for p in pending]).max()
-        losses = torch.stack([p[1] for p in pending])
+        ends = torch.stack([p[0] for p in pending] + [p[1] for p in pending])  # extreme S_ii = |P_i|^2 / t
+        errs = (ends * self._t - 1).abs().max()
+        losses = torch.stack([p[2] for p in pending])
         bad_norm, has_nan = (errs > 1e-4).item(), torch.isnan(losses).any().item()
         assert not bad_norm, "features need to be normalized first"
         if has_nan:

@@ -25,22 +25,51 @@ def _as_accumulable(v):
 
 
 class AverageValueMeter(Metric):
-    """weighted running mean of scalars"""
+    """weighted running mean of scalars.  Device scalars are queued (no launch per add: `v.double() * n` and the
+    running `sum + ...` were three tiny kernels per meter and step) and summed in f64 when the summary is asked
+    for, or every 1024 values."""
+
+    _FLUSH = 1024
 
     def __init__(self):
         super().__init__()
         self.sum, self.n = 0, 0
+        self._queue = []
 
     def reset(self):
         self.sum, self.n = 0, 0
+        self._queue = []
 
     def _add(self, value, n=1):
-        self.sum = self.sum + _as_accumulable(value) * n
+        if isinstance(value, torch.Tensor) and value.is_floating_point():
+            v = value.detach()
+            self._queue.append((v.reshape(-1)[0] if v.dim() > 0 else v, n))
+            if len(self._queue) >= self._FLUSH:
+                self._flush()
+        else:
+            self.sum = self.sum + _as_accumulable(value) * n
         self.n += n
+
+    def _flush(self):
+        q, self._queue = self._queue, []
+        if not q:
+            return
+        by_dev = {}
+        for v, n in q:
+            by_dev.setdefault((v.device, v.dtype), []).append((v, n))
+        for (dev, _), items in by_dev.items():
+            vals = torch.stack([v for v, _ in items]).double()
+            if any(n != 1 for _, n in items):
+                vals = vals * torch.tensor([float(n) for _, n in items], dtype=torch.float64).to(dev)
+            total = vals.sum()
+            if isinstance(self.sum, torch.Tensor) and self.sum.device != total.device:
+                total = total.to(self.sum.device)
+            self.sum = self.sum + total
 
     def _summary(self) -> float:
         if self.n == 0:
             return math.nan
+        self._flush()
         total = self.sum.item() if isinstance(self.sum, torch.Tensor) else self.sum
         return float(total / self.n)
 

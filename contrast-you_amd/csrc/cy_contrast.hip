@@ -572,7 +572,7 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ y,
                          const float* __restrict__ dy, float* __restrict__ dw,
-                         float* __restrict__ db, int M, int I, int O, int act, float slope) {
+                         float* __restrict__ db, int M, int I, int O, int act, float slope, int accumulate) {
   const long e = blockIdx.x * 256L + threadIdx.x;
   if (e >= (long)O * I) return;
   const int o = (int)(e / I), i = (int)(e % I);
@@ -582,8 +582,8 @@ __global__ void __launch_bounds__(256)
     s = fmaf(dz, x[(size_t)m * I + i], s);
     sb += dz;
   }
-  if (dw) dw[e] = s;
-  if (db && i == 0) db[o] = sb;
+  if (dw) dw[e] = accumulate ? dw[e] + s : s;
+  if (db && i == 0) db[o] = accumulate ? db[o] + sb : sb;
 }
 
 // ---------------------------------------------------------------- L2 normalise (wave per row)
@@ -689,8 +689,8 @@ int cy_supcon_fused_fwd(const float* P, const int32_t* labels, const uint8_t* po
   if (ws_bytes < cy_supcon_fused_ws_bytes(n, D)) return CY_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int R = 2 * n, ns = sc_nsplit(R), rb = cy_cdiv(R, SC_TM);
-  float* diag = (float*)ws;
-  float* Mv = diag + R;
+  float* diag = diag_out ? diag_out : (float*)ws;  // (written in place: no device-to-device copy afterwards)
+  float* Mv = (float*)ws + R;
   float* part = Mv + 4;
   hipLaunchKernelGGL(supcon_diag_kernel, dim3(cy_cdiv(R, 4)), dim3(256), 0, st, P, diag, R, D, 1.f / t);
   CY_CHECK_LAUNCH();
@@ -709,8 +709,6 @@ int cy_supcon_fused_fwd(const float* P, const int32_t* labels, const uint8_t* po
   CY_CHECK_LAUNCH();
   hipLaunchKernelGGL(supcon_fused_finalize_kernel, dim3(1), dim3(256), 0, st, part, Mv, row_stats, loss, R, ns);
   CY_CHECK_LAUNCH();
-  if (diag_out && hipMemcpyAsync(diag_out, diag, (size_t)R * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return CY_ERR_LAUNCH;
   return CY_OK;
 }
 
@@ -801,8 +799,8 @@ int cy_linear_fwd(const float* x, const float* w, const float* b, float* y, int 
   return CY_OK;
 }
 
-int cy_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
-                  float* dw, float* db, int M, int I, int O, int act, float slope, void* stream) {
+static int linear_bwd_impl(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
+                           float* db, int M, int I, int O, int act, float slope, int accumulate, void* stream) {
   if (!x || !w || !y || !dy || M <= 0 || I <= 0 || O <= 0) return CY_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dx) {
@@ -812,10 +810,20 @@ int cy_linear_bwd(const float* x, const float* w, const float* y, const float* d
   }
   if (dw || db) {
     hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cy_cdiv((long)O * I, 256)), dim3(256), 0, st, x,
-                       y, dy, dw, db, M, I, O, act, slope);
+                       y, dy, dw, db, M, I, O, act, slope, accumulate);
     CY_CHECK_LAUNCH();
   }
   return CY_OK;
+}
+
+int cy_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
+                  float* dw, float* db, int M, int I, int O, int act, float slope, void* stream) {
+  return linear_bwd_impl(x, w, y, dy, dx, dw, db, M, I, O, act, slope, 0, stream);
+}
+
+int cy_linear_bwd_into(const float* x, const float* w, const float* y, const float* dy, float* dx,
+                       float* dw, float* db, int M, int I, int O, int act, float slope, void* stream) {
+  return linear_bwd_impl(x, w, y, dy, dx, dw, db, M, I, O, act, slope, 1, stream);
 }
 
 int cy_l2norm_fwd(const float* x, float* z, float* norms, int M, int D, float eps, void* stream) {

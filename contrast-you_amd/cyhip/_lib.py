@@ -11,7 +11,7 @@ from pathlib import Path
 
 CY_F32, CY_BF16, CY_F16 = 0, 1, 2
 CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2 = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _ERRORS = {-1: "CY_ERR_ARG (bad/NULL argument)", -2: "CY_ERR_SHAPE (unsupported shape)",
            -3: "CY_ERR_DTYPE (unsupported dtype)", -4: "CY_ERR_LAUNCH (HIP launch failed)",
@@ -107,6 +107,7 @@ _SIGS = {
     "cy_avgpool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "cy_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "cy_linear_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "cy_linear_bwd_into": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "cy_l2norm_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P]),
     "cy_l2norm_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "cy_supcon_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),

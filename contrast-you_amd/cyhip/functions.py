@@ -469,6 +469,7 @@ class LinearFn(torch.autograd.Function):
         y = ops.linear_fwd(x, w32, None if b is None else b.detach().float().contiguous(), act, slope)
         ctx.save_for_backward(x, w32, y)
         ctx.act, ctx.slope, ctx.has_bias = act, slope, b is not None
+        ctx.params = (w, b)  # (leaf parameters: their .grad buffers take the gradients directly when they can)
         return y
 
     @staticmethod
@@ -476,8 +477,15 @@ class LinearFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         need_dx = ctx.needs_input_grad[0]
         need_dw = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        wp, bp = ctx.params
+        wsink = bsink = None
+        if ctx.needs_input_grad[1] and (not ctx.has_bias or ctx.needs_input_grad[2]):
+            wsink = ops.grad_sink(wp)
+            bsink = ops.grad_sink(bp) if ctx.has_bias and wsink is not None else None
+            if ctx.has_bias and bsink is None:
+                wsink = None
         dx, dw, db = ops.linear_bwd(x, w, y, g.float().contiguous(), ctx.act, ctx.slope, need_dx,
-                                    need_dw)
+                                    need_dw, dw_into=wsink, db_into=bsink)
         return dx, dw if ctx.needs_input_grad[1] else None, db if ctx.has_bias else None, None, None
 
 

@@ -816,10 +816,16 @@ def linear_fwd(x: Tensor, w: Tensor, b: Optional[Tensor], act: int = 0, slope: f
 
 
 def linear_bwd(x: Tensor, w: Tensor, y: Tensor, dy: Tensor, act: int, slope: float, need_dx: bool,
-               need_dw: bool):
+               need_dw: bool, dw_into: Optional[Tensor] = None, db_into: Optional[Tensor] = None):
+    """dx, dw, db; with dw_into / db_into the parameter gradients are ADDED into those buffers (returned as None)"""
     M, I = x.shape
     O = w.shape[0]
     dx = _f32(M * I, x.device).view(M, I) if need_dx else None
+    if dw_into is not None:
+        with ordered(("lin_grad", dw_into.data_ptr())):
+            _lib.call("cy_linear_bwd_into", x.data_ptr(), w.data_ptr(), y.data_ptr(), dy.data_ptr(), _ptr(dx),
+                      dw_into.data_ptr(), _ptr(db_into), M, I, O, act, float(slope), _stream())
+        return dx, None, None
     dw = _f32(O * I, x.device).view(O, I) if need_dw else None
     db = _f32(O, x.device) if need_dw else None
     _lib.call("cy_linear_bwd", x.data_ptr(), w.data_ptr(), y.data_ptr(), dy.data_ptr(), _ptr(dx),

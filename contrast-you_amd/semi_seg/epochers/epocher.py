@@ -210,7 +210,11 @@ class SemiSupervisedEpocher(EpocherBase):
     def _regularization(self, **kwargs):
         if not self._hooks:
             return torch.zeros((), device=self.device, dtype=torch.float)
-        return sum(h(**kwargs) for h in self._hooks)
+        total = None  # (`sum()` starts from 0: one `0 + loss` launch per step)
+        for h in self._hooks:
+            v = h(**kwargs)
+            total = v if total is None else total + v
+        return total
 
     # ---- forward ----------------------------------------------------------------------------------
     def _forward_pass(self, labeled_image, unlabeled_image, unlabeled_image_tf):

@@ -288,6 +288,9 @@ int cy_linear_fwd(const float* x, const float* w, const float* b, float* y, int 
  * dx[m][i], dw[o][i], db[o].  Any of dx/dw/db may be NULL. */
 int cy_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
                   float* dw, float* db, int M, int I, int O, int act, float slope, void* stream);
+/* the same, with dw / db ADDED into (the parameters' .grad buffers: no separate accumulation launch) */
+int cy_linear_bwd_into(const float* x, const float* w, const float* y, const float* dy, float* dx,
+                       float* dw, float* db, int M, int I, int O, int act, float slope, void* stream);
 /* z = x / max(||x||,eps) row-wise; norms[m] saved for backward. */
 int cy_l2norm_fwd(const float* x, float* z, float* norms, int M, int D, float eps, void* stream);
 int cy_l2norm_bwd(const float* x, const float* norms, const float* dz, float* dx, int M, int D,
