@@ -16,7 +16,7 @@ import torch
 
 from cyhip import ops
 from cyhip.functions import (AdaptiveAvgPoolFn, ClusterHeadFn, AvgPoolFn, DenseProjHiddenFn, GroupSoftmaxFn, HeadFn, L2NormFn,
-                             LinearFn)
+                             LinearFn, ProjHeadFn)
 
 from .nn import Flatten, Identical, Normalize, SoftmaxWithT
 
@@ -49,6 +49,9 @@ class ProjectionHead(nn.Module):
 
     def forward(self, features: Tensor) -> Tensor:
         h = self._header
+        if (self._head_type == "mlp" and self._normalize and h[2].bias is not None and h[4].bias is not None
+                and ops.proj_head_ok(features, h[2].weight, h[4].weight)):
+            return ProjHeadFn.apply(features, h[2].weight, h[2].bias, h[4].weight, h[4].bias)  # one launch
         x = AvgPoolFn.apply(features)
         if self._head_type == "mlp":
             x = LinearFn.apply(x, h[2].weight, h[2].bias, 1, 0.01)

@@ -626,6 +626,223 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---------------------------------------------------------------- projection head, one launch per direction
+// ProjectionHead (contrastyou/projectors/heads.py:12-22,81-96): AdaptiveAvgPool2d(1) -> Linear(C, hid) -> LeakyReLU
+// -> Linear(hid, out) -> F.normalize.  The pieces above cost four launches forward and six backward for ~0.4 MFLOP
+// per sample; here one workgroup runs a sample through the whole chain (matrix rows are read coalesced, lanes across
+// the input index, one wave reduction per output), and the parameter gradients -- sums over the samples -- are a
+// second backward kernel with one thread per weight.
+constexpr int PH_MAXC = 512, PH_MAXH = 512;  // one workgroup's LDS: 16 partial vectors of <= 512 floats
+constexpr int PH_NT = 1024, PH_NW = 16;
+
+// y[o] = sum_i w[o][i] * x[i] (+ b[o]); x in LDS.  A wave takes four rows at a time (eight loads in flight for
+// I = 512, four independent reductions): the first version -- four waves, one row per iteration -- spent ~1 us of
+// dependent global latency per output (147 us for 512 -> 256 -> 256).
+__device__ __forceinline__ void ph_matvec(const float* __restrict__ w, const float* __restrict__ b, const float* xs,
+                                          float* ys, int I, int O, int wave, int lane) {
+  for (int o0 = wave * 4; o0 < O; o0 += PH_NW * 4) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = lane * 4; i < I; i += 256) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + i);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int o = o0 + u < O ? o0 + u : O - 1;
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)o * I + i);
+        s[u] = fmaf(wv[0], xv[0], fmaf(wv[1], xv[1], fmaf(wv[2], xv[2], fmaf(wv[3], xv[3], s[u]))));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = wave_sum(s[u]);
+    if (lane < 4 && o0 + lane < O) {
+      const float v = lane == 0 ? s[0] : (lane == 1 ? s[1] : (lane == 2 ? s[2] : s[3]));
+      ys[o0 + lane] = v + (b ? b[o0 + lane] : 0.f);
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PH_NT)
+    proj_head_fwd_kernel(const T* __restrict__ feat, const float* __restrict__ w1, const float* __restrict__ b1,
+                         const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ pooled,
+                         float* __restrict__ y1, float* __restrict__ y2, float* __restrict__ z,
+                         float* __restrict__ norms, int HW, int C, int hid, int out, float slope, float eps) {
+  constexpr int EPC = ElemTr<T>::EPC;
+  __shared__ __attribute__((aligned(16))) float spart[PH_NW * PH_MAXC];  // pooling partials [slice][C]
+  __shared__ __attribute__((aligned(16))) float sp[PH_MAXC];
+  __shared__ __attribute__((aligned(16))) float sh[PH_MAXH];
+  __shared__ __attribute__((aligned(16))) float so[PH_MAXH];
+  __shared__ float sred[PH_NW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x;
+  // average pool: thread = (16-byte channel group, position slice); every load of a thread is independent
+  const int G = C / EPC;
+  const int nsl = PH_NT / G < PH_NW ? PH_NT / G : PH_NW;  // slices (host: G <= 1024)
+  {
+    const int cg = tid % G, sl = tid / G;
+    if (sl < nsl) {
+      float a[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) a[e] = 0.f;
+      const T* xp = feat + (size_t)n * HW * C + cg * EPC;
+      for (int p = sl; p < HW; p += nsl) {
+        float f[EPC];
+        Chunk<T>::unpack(ld16(xp + (size_t)p * C), f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) a[e] += f[e];
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) spart[sl * C + cg * EPC + e] = a[e];
+    }
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)HW;
+  for (int c = tid; c < C; c += PH_NT) {
+    float v = 0.f;
+    for (int q = 0; q < nsl; ++q) v += spart[q * C + c];
+    v *= inv;
+    sp[c] = v;
+    pooled[(size_t)n * C + c] = v;
+  }
+  __syncthreads();
+  ph_matvec(w1, b1, sp, sh, C, hid, wave, lane);
+  __syncthreads();
+  for (int j = tid; j < hid; j += PH_NT) {
+    const float v = sh[j] > 0.f ? sh[j] : slope * sh[j];
+    sh[j] = v;
+    y1[(size_t)n * hid + j] = v;
+  }
+  __syncthreads();
+  ph_matvec(w2, b2, sh, so, hid, out, wave, lane);
+  __syncthreads();
+  float ss = 0.f;
+  for (int o = tid; o < out; o += PH_NT) ss = fmaf(so[o], so[o], ss);
+  ss = wave_sum(ss);
+  if (lane == 0) sred[wave] = ss;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int q = 0; q < PH_NW; ++q) tot += sred[q];
+  const float nrm = sqrtf(tot);
+  const float den = fmaxf(nrm, eps);
+  for (int o = tid; o < out; o += PH_NT) {
+    y2[(size_t)n * out + o] = so[o];
+    z[(size_t)n * out + o] = so[o] / den;
+  }
+  if (tid == 0) norms[n] = nrm;
+}
+
+// per sample: dy2 (normalise backward), dh = (W2^T dy2) * lrelu'(y1), dpooled = W1^T dh, dfeat = dpooled / HW
+template <typename T>
+__global__ void __launch_bounds__(PH_NT)
+    proj_head_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y1, const float* __restrict__ y2,
+                         const float* __restrict__ norms, const float* __restrict__ w1,
+                         const float* __restrict__ w2, float* __restrict__ dy2g, float* __restrict__ dhg,
+                         T* __restrict__ dfeat, int HW, int C, int hid, int out, float slope, float eps) {
+  __shared__ __attribute__((aligned(16))) float sa[PH_MAXH];           // dy2, then dh
+  __shared__ __attribute__((aligned(16))) float sb[PH_NW * PH_MAXC];   // per-wave partial columns
+  __shared__ float sred[PH_NW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x;
+  // dy2 = dz / nrm - y2 * (y2 . dz) / nrm^3   (nrm <= eps: dz / eps), as l2norm_bwd_kernel
+  const float nrm = norms[n];
+  float dot = 0.f;
+  for (int o = tid; o < out; o += PH_NT) dot = fmaf(y2[(size_t)n * out + o], dz[(size_t)n * out + o], dot);
+  dot = wave_sum(dot);
+  if (lane == 0) sred[wave] = dot;
+  __syncthreads();
+  dot = 0.f;
+#pragma unroll
+  for (int q = 0; q < PH_NW; ++q) dot += sred[q];
+  for (int o = tid; o < out; o += PH_NT) {
+    float v;
+    if (nrm > eps) {
+      const float iv = 1.f / nrm;
+      v = dz[(size_t)n * out + o] * iv - y2[(size_t)n * out + o] * (dot * iv * iv * iv);
+    } else {
+      v = dz[(size_t)n * out + o] / eps;
+    }
+    sa[o] = v;
+    dy2g[(size_t)n * out + o] = v;
+  }
+  __syncthreads();
+  // column sums: wave w takes rows w, w + 16, ... of the matrix (loads independent of each other), lanes across
+  // the columns; the sixteen partial vectors meet in LDS
+  auto tmatvec = [&](const float* __restrict__ w, const float* xs, int R, int Ccols) {
+    for (int c0 = lane * 4; c0 < Ccols; c0 += 256) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int rr = wave; rr < R; rr += PH_NW) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)rr * Ccols + c0);
+        const float xv = xs[rr];
+        acc[0] = fmaf(wv[0], xv, acc[0]), acc[1] = fmaf(wv[1], xv, acc[1]);
+        acc[2] = fmaf(wv[2], xv, acc[2]), acc[3] = fmaf(wv[3], xv, acc[3]);
+      }
+      *reinterpret_cast<f32x4*>(&sb[wave * Ccols + c0]) = acc;
+    }
+  };
+  tmatvec(w2, sa, out, hid);
+  __syncthreads();
+  for (int j = tid; j < hid; j += PH_NT) {
+    float g = 0.f;
+#pragma unroll
+    for (int q = 0; q < PH_NW; ++q) g += sb[q * hid + j];
+    const float v = y1[(size_t)n * hid + j] > 0.f ? g : g * slope;
+    sa[j] = v;
+    dhg[(size_t)n * hid + j] = v;
+  }
+  __syncthreads();
+  tmatvec(w1, sa, hid, C);
+  __syncthreads();
+  const float inv = 1.f / (float)HW;
+  float* sdp = sa;  // (dh is in global memory by now)  dpooled / HW, C <= PH_MAXH
+  __syncthreads();
+  for (int c = tid; c < C; c += PH_NT) {
+    float g = 0.f;
+#pragma unroll
+    for (int q = 0; q < PH_NW; ++q) g += sb[q * C + c];
+    sdp[c] = g * inv;
+  }
+  __syncthreads();
+  if (dfeat) {
+    constexpr int EPC = ElemTr<T>::EPC;
+    T* dp = dfeat + (size_t)n * HW * C;
+    const int G = C / EPC;
+    for (long e = tid; e < (long)HW * G; e += PH_NT) {
+      const int cg = (int)(e % G);
+      st16(dp + (e / G) * C + cg * EPC, Chunk<T>::pack(sdp + cg * EPC));
+    }
+  }
+}
+
+// parameter gradients: thread e < out*hid: dW2[o][j] = sum_n dy2[n][o] y1[n][j]; then dW1[j][i] = sum_n dh[n][j] pooled[n][i]
+__global__ void __launch_bounds__(256)
+    proj_head_dw_kernel(const float* __restrict__ dy2, const float* __restrict__ dh, const float* __restrict__ y1,
+                        const float* __restrict__ pooled, float* __restrict__ dw1, float* __restrict__ db1,
+                        float* __restrict__ dw2, float* __restrict__ db2, int B, int C, int hid, int out,
+                        int accumulate) {
+  const long e = blockIdx.x * 256L + threadIdx.x;
+  const long n2 = (long)out * hid, n1 = (long)hid * C;
+  const float *ga, *xa;
+  float *dw, *db;
+  int O, I;
+  long k;
+  if (e < n2) {
+    ga = dy2, xa = y1, dw = dw2, db = db2, O = out, I = hid, k = e;
+  } else if (e < n2 + n1) {
+    ga = dh, xa = pooled, dw = dw1, db = db1, O = hid, I = C, k = e - n2;
+  } else {
+    return;
+  }
+  const int o = (int)(k / I), i = (int)(k % I);
+  float s = 0.f, sbias = 0.f;
+  for (int n = 0; n < B; ++n) {
+    const float g = ga[(size_t)n * O + o];
+    s = fmaf(g, xa[(size_t)n * I + i], s);
+    sbias += g;
+  }
+  if (dw) dw[k] = accumulate ? dw[k] + s : s;
+  if (db && i == 0) db[o] = accumulate ? db[o] + sbias : sbias;
+}
+
 inline int grid_for(long total) {
   long b = (total + 255) / 256;
   if (b > 8192) b = 8192;
@@ -824,6 +1041,62 @@ int cy_linear_bwd(const float* x, const float* w, const float* y, const float* d
 int cy_linear_bwd_into(const float* x, const float* w, const float* y, const float* dy, float* dx,
                        float* dw, float* db, int M, int I, int O, int act, float slope, void* stream) {
   return linear_bwd_impl(x, w, y, dy, dx, dw, db, M, I, O, act, slope, 1, stream);
+}
+
+int cy_proj_head_fwd(const void* feat, const float* w1, const float* b1, const float* w2, const float* b2,
+                     float* pooled, float* y1, float* y2, float* z, float* norms, int B, int HW, int C, int hid,
+                     int out, float slope, float eps, int dtype, void* stream) {
+  if (!feat || !w1 || !w2 || !pooled || !y1 || !y2 || !z || !norms || B <= 0 || HW <= 0) return CY_ERR_ARG;
+  if (C <= 0 || C > PH_MAXC || C % 8 || hid <= 0 || hid > PH_MAXH || hid % 4 || out <= 0 || out > PH_MAXH)
+    return CY_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(proj_head_fwd_kernel<bf16>, dim3(B), dim3(PH_NT), 0, st, (const bf16*)feat, w1, b1, w2, b2,
+                       pooled, y1, y2, z, norms, HW, C, hid, out, slope, eps);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(proj_head_fwd_kernel<f16>, dim3(B), dim3(PH_NT), 0, st, (const f16*)feat, w1, b1, w2, b2,
+                       pooled, y1, y2, z, norms, HW, C, hid, out, slope, eps);
+  else if (dtype == CY_F32)
+    hipLaunchKernelGGL(proj_head_fwd_kernel<float>, dim3(B), dim3(PH_NT), 0, st, (const float*)feat, w1, b1, w2, b2,
+                       pooled, y1, y2, z, norms, HW, C, hid, out, slope, eps);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+size_t cy_proj_head_bwd_ws_bytes(int B, int hid, int out) { return (size_t)B * (hid + out) * sizeof(float); }
+
+int cy_proj_head_bwd(const float* dz, const float* pooled, const float* y1, const float* y2, const float* norms,
+                     const float* w1, const float* w2, void* dfeat, float* dw1, float* db1, float* dw2, float* db2,
+                     int accumulate, void* ws, size_t ws_bytes, int B, int HW, int C, int hid, int out, float slope,
+                     float eps, int dtype, void* stream) {
+  if (!dz || !pooled || !y1 || !y2 || !norms || !w1 || !w2 || !ws || B <= 0 || HW <= 0) return CY_ERR_ARG;
+  if (C <= 0 || C > PH_MAXC || C % 8 || hid <= 0 || hid > PH_MAXH || hid % 4 || out <= 0 || out > PH_MAXH)
+    return CY_ERR_SHAPE;
+  if (ws_bytes < cy_proj_head_bwd_ws_bytes(B, hid, out)) return CY_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* dy2 = (float*)ws;
+  float* dh = dy2 + (size_t)B * out;
+  if (dtype == CY_BF16)
+    hipLaunchKernelGGL(proj_head_bwd_kernel<bf16>, dim3(B), dim3(PH_NT), 0, st, dz, y1, y2, norms, w1, w2, dy2, dh,
+                       (bf16*)dfeat, HW, C, hid, out, slope, eps);
+  else if (dtype == CY_F16)
+    hipLaunchKernelGGL(proj_head_bwd_kernel<f16>, dim3(B), dim3(PH_NT), 0, st, dz, y1, y2, norms, w1, w2, dy2, dh,
+                       (f16*)dfeat, HW, C, hid, out, slope, eps);
+  else if (dtype == CY_F32)
+    hipLaunchKernelGGL(proj_head_bwd_kernel<float>, dim3(B), dim3(PH_NT), 0, st, dz, y1, y2, norms, w1, w2, dy2, dh,
+                       (float*)dfeat, HW, C, hid, out, slope, eps);
+  else
+    return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  if (dw1 || db1 || dw2 || db2) {
+    const long total = (long)out * hid + (long)hid * C;
+    hipLaunchKernelGGL(proj_head_dw_kernel, dim3(cy_cdiv(total, 256)), dim3(256), 0, st, (const float*)dy2,
+                       (const float*)dh, y1, pooled, dw1, db1, dw2, db2, B, C, hid, out, accumulate);
+    CY_CHECK_LAUNCH();
+  }
+  return CY_OK;
 }
 
 int cy_l2norm_fwd(const float* x, float* z, float* norms, int M, int D, float eps, void* stream) {

@@ -108,6 +108,9 @@ _SIGS = {
     "cy_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "cy_linear_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "cy_linear_bwd_into": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "cy_proj_head_fwd": (c_int, [_P] * 10 + [c_int] * 5 + [c_float, c_float, c_int, _P]),
+    "cy_proj_head_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cy_proj_head_bwd": (c_int, [_P] * 12 + [c_int, _P, c_size_t] + [c_int] * 5 + [c_float, c_float, c_int, _P]),
     "cy_l2norm_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P]),
     "cy_l2norm_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "cy_supcon_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),

@@ -489,6 +489,37 @@ class LinearFn(torch.autograd.Function):
         return dx, dw if ctx.needs_input_grad[1] else None, db if ctx.has_bias else None, None, None
 
 
+class ProjHeadFn(torch.autograd.Function):
+    """ProjectionHead, head_type "mlp" with normalisation, as ONE launch forward and two backward
+    (contrastyou/projectors/heads.py:12-22,81-96): pool -> Linear -> LeakyReLU(0.01) -> Linear -> F.normalize."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor):
+        ops.require_gpu(x, w1, w2)
+        x = ops.to_nhwc(x)
+        z, pooled, y1, y2, norms = ops.proj_head_fwd(x, w1.detach().float().contiguous(), b1.detach().float().contiguous(),
+                                                     w2.detach().float().contiguous(), b2.detach().float().contiguous())
+        ctx.save_for_backward(pooled, y1, y2, norms, w1.detach(), w2.detach())
+        ctx.shape, ctx.dtype = tuple(x.shape), x.dtype
+        ctx.params = (w1, b1, w2, b2)
+        return z
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        pooled, y1, y2, norms, w1, w2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        sinks = None
+        if all(need[1:5]):
+            cand = tuple(ops.grad_sink(p) for p in ctx.params)
+            if all(c is not None for c in cand):
+                sinks = cand
+        dx, (dw1, db1, dw2, db2) = ops.proj_head_bwd(g.float().contiguous(), pooled, y1, y2, norms,
+                                                     w1.float().contiguous(), w2.float().contiguous(), ctx.shape,
+                                                     ctx.dtype, need[0], sinks)
+        return (dx, dw1 if need[1] else None, db1 if need[2] else None, dw2 if need[3] else None,
+                db2 if need[4] else None)
+
+
 class L2NormFn(torch.autograd.Function):
     """F.normalize(x, p=2, dim=1) on [M,D] (contrastyou/projectors/nn.py:47-54)."""
 

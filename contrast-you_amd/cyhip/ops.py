@@ -833,6 +833,58 @@ def linear_bwd(x: Tensor, w: Tensor, y: Tensor, dy: Tensor, act: int, slope: flo
     return dx, dw, db
 
 
+def proj_head_ok(x: Tensor, w1: Tensor, w2: Tensor) -> bool:
+    """shapes the one-launch projection head takes (csrc/cy_contrast.hip proj_head_*)"""
+    Cc, hid, out = x.shape[1], w1.shape[0], w2.shape[0]
+    return (x.is_cuda and Cc % 8 == 0 and Cc <= 512 and hid % 4 == 0 and hid <= 512 and out <= 512
+            and x.dtype in (torch.bfloat16, torch.float16, torch.float32))
+
+
+def proj_head_fwd(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, slope: float = 0.01,
+                  eps: float = 1e-12):
+    """x NHWC [B,C,H,W] -> z [B,out] normalised, and (pooled, y1, y2, norms) for the backward"""
+    B, Cc, H, W = x.shape
+    hid, out = w1.shape[0], w2.shape[0]
+    dev = x.device
+    pooled, y1 = _f32(B * Cc, dev).view(B, Cc), _f32(B * hid, dev).view(B, hid)
+    y2, z, norms = _f32(B * out, dev).view(B, out), _f32(B * out, dev).view(B, out), _f32(B, dev)
+    _lib.call("cy_proj_head_fwd", x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+              pooled.data_ptr(), y1.data_ptr(), y2.data_ptr(), z.data_ptr(), norms.data_ptr(), B, H * W, Cc, hid, out,
+              float(slope), float(eps), dtype_code(x.dtype), _stream())
+    return z, pooled, y1, y2, norms
+
+
+def proj_head_bwd(dz: Tensor, pooled: Tensor, y1: Tensor, y2: Tensor, norms: Tensor, w1: Tensor, w2: Tensor, shape,
+                  dtype, need_dx: bool, sinks=None, slope: float = 0.01, eps: float = 1e-12):
+    """-> dx (NHWC, dtype) or None, and (dw1, db1, dw2, db2) -- None each when `sinks` (the parameters' .grad buffers,
+    added into) is given"""
+    B, Cc, H, W = shape
+    hid, out = w1.shape[0], w2.shape[0]
+    dev = dz.device
+    dx = empty_nhwc(B, Cc, H, W, dtype, dev) if need_dx else None
+    nbytes = _lib.load().cy_proj_head_bwd_ws_bytes(B, hid, out)
+    ws = _ws(nbytes, dev)
+    if sinks is not None:
+        g = sinks
+        acc = 1
+    else:
+        g = (_f32(hid * Cc, dev).view(hid, Cc), _f32(hid, dev), _f32(out * hid, dev).view(out, hid), _f32(out, dev))
+        acc = 0
+
+    def launch():
+        _lib.call("cy_proj_head_bwd", dz.data_ptr(), pooled.data_ptr(), y1.data_ptr(), y2.data_ptr(), norms.data_ptr(),
+                  w1.data_ptr(), w2.data_ptr(), _ptr(dx), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
+                  g[3].data_ptr(), acc, ws.data_ptr(), nbytes, B, H * W, Cc, hid, out, float(slope), float(eps),
+                  dtype_code(dtype), _stream())
+
+    if sinks is not None:
+        with ordered(("lin_grad", g[0].data_ptr())):
+            launch()
+        return dx, (None, None, None, None)
+    launch()
+    return dx, g
+
+
 def l2norm_fwd(x: Tensor, eps: float = 1e-12):
     M, D = x.shape
     z = torch.empty_like(x)

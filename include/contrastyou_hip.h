@@ -291,6 +291,19 @@ int cy_linear_bwd(const float* x, const float* w, const float* y, const float* d
 /* the same, with dw / db ADDED into (the parameters' .grad buffers: no separate accumulation launch) */
 int cy_linear_bwd_into(const float* x, const float* w, const float* y, const float* dy, float* dx,
                        float* dw, float* db, int M, int I, int O, int act, float slope, void* stream);
+/* The whole ProjectionHead (contrastyou/projectors/heads.py:12-22,81-96, head_type "mlp", normalize) in one launch:
+ * feat NHWC [B][HW][C] (dtype) -> pooled [B][C] -> y1 = lrelu(W1 pooled + b1) [B][hid] -> y2 = W2 y1 + b2 [B][out]
+ * -> z = y2 / max(|y2|, eps), norms [B]; pooled / y1 / y2 / norms are what the backward needs.
+ * Backward: dfeat (dtype, may be NULL), and dW1 [hid][C], db1, dW2 [out][hid], db2 written or ADDED into
+ * (accumulate); ws: cy_proj_head_bwd_ws_bytes.  C % 8 == 0, hid % 4 == 0; C, hid, out <= 512. */
+int cy_proj_head_fwd(const void* feat, const float* w1, const float* b1, const float* w2, const float* b2,
+                     float* pooled, float* y1, float* y2, float* z, float* norms, int B, int HW, int C, int hid,
+                     int out, float slope, float eps, int dtype, void* stream);
+size_t cy_proj_head_bwd_ws_bytes(int B, int hid, int out);
+int cy_proj_head_bwd(const float* dz, const float* pooled, const float* y1, const float* y2, const float* norms,
+                     const float* w1, const float* w2, void* dfeat, float* dw1, float* db1, float* dw2, float* db2,
+                     int accumulate, void* ws, size_t ws_bytes, int B, int HW, int C, int hid, int out, float slope,
+                     float eps, int dtype, void* stream);
 /* z = x / max(||x||,eps) row-wise; norms[m] saved for backward. */
 int cy_l2norm_fwd(const float* x, float* z, float* norms, int M, int D, float eps, void* stream);
 int cy_l2norm_bwd(const float* x, const float* norms, const float* dz, float* dx, int M, int D,

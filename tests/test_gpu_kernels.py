@@ -353,6 +353,55 @@ def test_projector_pieces(golden_dir):
     assert_close(dfeat, torch.from_numpy(gld["proj_dfeat"]), 1e-4, "dfeat")
 
 
+def test_projection_head_one_launch(golden_dir):
+    """cy_proj_head_fwd / bwd (the whole ProjectionHead per direction) against the reference's own vectors, and at
+    the encoder hook's size (96 x 512 x 14 x 14, bf16) against the separate kernels"""
+    ops = _ops()
+    from oracle import losses as ol
+    gld = np.load(golden_dir / "heads_losses.npz")
+    psd = {k: v.to(DEV) for k, v in ol.init_projector_sd(128, 256, 256, seed=3).items()}
+    w1, b1, w2, b2 = (psd["_header.2.weight"], psd["_header.2.bias"], psd["_header.4.weight"], psd["_header.4.bias"])
+    feat = torch.from_numpy(gld["proj_feat"])
+    fg = nhwc(feat)
+    z, pooled, y1, y2, norms = ops.proj_head_fwd(fg, w1, b1, w2, b2)
+    assert_close(z, torch.from_numpy(gld["proj_z"]), 2e-5, "z (golden)")
+    gz = torch.linspace(-1, 1, z.numel()).view_as(z).to(DEV)
+    dfeat, (dw1, db1, dw2, db2) = ops.proj_head_bwd(gz, pooled, y1, y2, norms, w1, w2, tuple(feat.shape),
+                                                    torch.float32, True)
+    assert_close(dw2, torch.from_numpy(gld["proj_grad__header.4.weight"]), 1e-4, "dW (second linear)")
+    assert_close(db2, torch.from_numpy(gld["proj_grad__header.4.bias"]), 1e-4, "db (second linear)")
+    assert_close(dw1, torch.from_numpy(gld["proj_grad__header.2.weight"]), 1e-4, "dW (first linear)")
+    assert_close(db1, torch.from_numpy(gld["proj_grad__header.2.bias"]), 1e-4, "db (first linear)")
+    assert_close(dfeat, torch.from_numpy(gld["proj_dfeat"]), 1e-4, "dfeat")
+    # accumulation into existing buffers
+    sinks = tuple(torch.ones_like(t) for t in (dw1, db1, dw2, db2))
+    ops.proj_head_bwd(gz, pooled, y1, y2, norms, w1, w2, tuple(feat.shape), torch.float32, False, sinks)
+    for got, ref in zip(sinks, (dw1, db1, dw2, db2)):
+        assert_close(got - 1, ref, 1e-5, "added into")
+
+    g = torch.Generator().manual_seed(21)
+    B, C = 96, 512
+    psd = {k: v.to(DEV) for k, v in ol.init_projector_sd(C, 256, 256, seed=4).items()}
+    w1, b1, w2, b2 = (psd["_header.2.weight"], psd["_header.2.bias"], psd["_header.4.weight"], psd["_header.4.bias"])
+    x = nhwc(rnd(B, C, 14, 14, gen=g), torch.bfloat16)
+    z, pooled, y1, y2, norms = ops.proj_head_fwd(x, w1, b1, w2, b2)
+    p0 = ops.avgpool_fwd(x)
+    h0 = ops.linear_fwd(p0, w1, b1, 1, 0.01)
+    o0 = ops.linear_fwd(h0, w2, b2, 0, 0.0)
+    z0, n0 = ops.l2norm_fwd(o0)
+    assert_close(z, cpu(z0), 1e-5, "z vs separate kernels")
+    gz = rnd(B, 256, gen=g).to(DEV)
+    dx, (dw1, db1, dw2, db2) = ops.proj_head_bwd(gz, pooled, y1, y2, norms, w1, w2, tuple(x.shape), torch.bfloat16,
+                                                 True)
+    do = ops.l2norm_bwd(o0, n0, gz)
+    dh, rw2, rb2 = ops.linear_bwd(h0, w2, o0, do, 0, 0.0, True, True)
+    dp, rw1, rb1 = ops.linear_bwd(p0, w1, h0, dh, 1, 0.01, True, True)
+    rx = ops.avgpool_bwd(dp, tuple(x.shape), torch.bfloat16)
+    assert_close(dw2, cpu(rw2), 1e-5, "dW2"), assert_close(db2, cpu(rb2), 1e-5, "db2")
+    assert_close(dw1, cpu(rw1), 1e-5, "dW1"), assert_close(db1, cpu(rb1), 1e-5, "db1")
+    assert_close(dx, cpu(rx), 1e-2, "dx (bf16)")
+
+
 def test_sgemm():
     ops = _ops()
     g = torch.Generator().manual_seed(8)
