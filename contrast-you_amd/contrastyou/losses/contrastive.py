@@ -54,6 +54,19 @@ def _encode_target(target, n: int, device) -> Tensor:
     return t.contiguous()
 
 
+def _rejoin(a: Tensor, b: Tensor) -> Tensor:
+    """cat([a, b]) -- without the copy (and, in the backward, without the zero-fill + two slice copies of the
+    chunk's gradient) when a and b are the two halves `torch.chunk` made of one contiguous tensor, which is how the
+    InfoNCE hook hands the projector's output over (semi_seg/hooks/infonce.py:226-230 in the reference)"""
+    base = a._base
+    if (base is not None and base is b._base and base.dim() == a.dim() and base.is_contiguous()
+            and a.is_contiguous() and b.is_contiguous() and base.shape[0] == a.shape[0] + b.shape[0]
+            and base.shape[1:] == a.shape[1:] == b.shape[1:] and a.data_ptr() == base.data_ptr()
+            and b.data_ptr() == a.data_ptr() + a.numel() * a.element_size()):
+        return base
+    return torch.cat([a, b], dim=0)
+
+
 class SupConLoss1(nn.Module):
     def __init__(self, temperature=0.07, exclude_other_pos=False):
         super().__init__()
@@ -78,7 +91,7 @@ class SupConLoss1(nn.Module):
             labels = _encode_target(target, n, dev)
         else:
             labels = torch.arange(n, dtype=torch.int32, device=dev)  # SimCLR: only the other view
-        P = torch.cat([proj_feat1, proj_feat2], dim=0)
+        P = _rejoin(proj_feat1, proj_feat2)
         loss, diag, stats = SupConFn.apply(P, labels, pos, float(self._t))
         self._last = (P.detach(), stats, labels, pos)
         # device-side evidence for the reference's two checks: one aminmax launch now, the arithmetic in validate()
