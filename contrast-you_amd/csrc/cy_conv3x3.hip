@@ -17,13 +17,11 @@
 // partial per tile, fixed-order reduction in cy_bn_finalize) and stores
 // 16-byte NHWC chunks after a wave-private LDS transpose.
 #include "cy_conv_plane.h"
-#include "cy_conv_plane8.h"
 #include "cy_conv_stream.h"
+#include "cy_conv_flow.h"
 #include "cy_conv_tile.h"
 
 #include <cstdlib>
-
-#include "cy_conv_pc.h"
 
 namespace {
 
@@ -519,8 +517,8 @@ constexpr int kPlaneTH = 16, kPlaneTW = 14;
 struct ConvPlan {
   bool plane;
   bool stream;      // plane, 16-bit storage, Cin / Cout in {32, 64}, no load transform: persistent streaming kernel (cy_conv_stream.h)
-  bool plane8;      // plane, 128 couts, 16-bit storage: one eight-wave workgroup per 32 x 14 tile (cy_conv_plane8.h)
   bool one_per_cu;  // plane, 128 couts: at most one workgroup per CU, halo prefetch in registers
+  bool flow;        // eight-wave LDS-DMA kernel (cy_conv_flow.h): one workgroup per CU, tile.th x tile.tw x tile.bn
   TileChoice tile;
   int ksplit;         // >1: split-K over input-channel chunks + finish kernel
   int finish_blocks;  // blocks (= stat partials) of the finish kernel
@@ -530,12 +528,12 @@ struct ConvPlan {
 
 // Deep layers (14x14 / 28x28 at small batch) have too few output tiles to fill 256 CUs: split
 // the reduction over input-channel chunks across blockIdx.z.
-ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool plane8_ok = false, bool stream_ok = false,
-                   bool prologue = false) {
+ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool stream_ok = false,
+                   bool prologue = false, FlowChoice fc = FlowChoice{false, 0, 0, 0, false}) {
   ConvPlan p;
   p.plane = use_plane_kernel(W);
-  p.plane8 = false;
   p.stream = false;
+  p.flow = false;
   static const int stream_mode = [] {
     const char* e = getenv("CY_STREAM");
     return e ? atoi(e) : 1;
@@ -552,36 +550,68 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool 
     p.ws_bytes = 0;
     return p;
   }
-  static const int plane8_mode = [] {
-    const char* e = getenv("CY_PLANE8");
-    return e ? atoi(e) : 0;
+  static const int flow_mode = [] {
+    const char* e = getenv("CY_FLOW");
+    return e ? atoi(e) : 1;
   }();
-  if (p.plane && plane8_ok && plane8_mode && elem_bytes == 2 && Cout >= 128 && Cout % 8 == 0) {
-    p.plane8 = true;
-    p.one_per_cu = false;
-    p.tile.th = 32, p.tile.tw = kPlaneTW, p.tile.bn = 128;
-    const long npix8 = (long)N * H * W;
-    const int tiles8 = cy_cdiv((long)N * H, 32) * (W / kPlaneTW);
-    const int blocks8 = tiles8 * cy_cdiv(Cout, 128);
-    const int ncc8 = cy_cdiv(Cin, 32);
-    int Z = 1;
-    if (blocks8 < 192) {  // one workgroup per CU: aim at ~224-256 workgroups, >= 2 chunks each
-      Z = (240 + blocks8 / 2) / blocks8;
-      if (Z > ncc8 / 2) Z = ncc8 / 2;
-      if (Z > 8) Z = 8;
-      if (Z < 1) Z = 1;
+  if (fc.ok && flow_mode) {
+    static const int flow_cfg = [] {  // experiments: 1 = always the big tile, 2 = the 16-row tile wherever it exists
+      const char* e = getenv("CY_FLOW_CFG");
+      return e ? atoi(e) : 0;
+    }();
+    const long npixf = (long)N * H * W;
+    const int nccf = Cin / 16;
+    // One workgroup per CU, all of them in step (load the first chunk, compute, store): the kernel pays off where
+    // one or two full rounds of workgroups cover the layer and the K loop is long enough to amortise the two
+    // ends.  Rules from per-layer A/B runs against the plane kernel on one box (tools/flow_sweep.sh,
+    // DESIGN.md section 3 "Flow kernel"); everything else stays on the plane kernel.
+    int th = fc.th, bn = fc.bn, Z = 1;
+    const int tiles_big = cy_cdiv((long)N * H, th) * (W / fc.tw);
+    const int blocks_big = tiles_big * (Cout / bn);
+    auto fills = [](int blocks) {  // share of the CU-rounds a grid occupies
+      const int rounds = (blocks + 255) / 256;
+      return (double)blocks / (256.0 * rounds);
+    };
+    bool use = false;
+    if (flow_cfg == 1) {
+      use = true;
+    } else if (bn == 64) {
+      use = blocks_big >= 160 && (blocks_big <= 256 || (nccf >= 8 && fills(blocks_big) >= 0.75));
+    } else {
+      if (blocks_big >= 192 && (blocks_big <= 256 || (nccf >= 8 && fills(blocks_big) >= 0.85))) {
+        use = true;
+      } else if (fc.small_ok && blocks_big < 192) {
+        th = 16;
+        const int blocks_small = cy_cdiv((long)N * H, th) * (W / fc.tw) * (Cout / bn);
+        if (blocks_small >= 192) {
+          use = blocks_small <= 256 || (nccf >= 8 && fills(blocks_small) >= 0.85);
+        } else if (Cout >= 256) {  // split-K over >= 4 chunks each (f32 partial slabs: only where many cout blocks share them)
+          Z = (232 + blocks_small / 2) / blocks_small;
+          if (Z > nccf / 4) Z = nccf / 4;
+          if (Z > 8) Z = 8;
+          use = Z >= 1 && blocks_small * Z >= 160;
+          if (Z < 1) Z = 1;
+        }
+      }
     }
+    if (flow_cfg == 2 && fc.small_ok) use = true, th = 16, Z = 1;
     if (const char* ov = getenv("CY_KSPLIT")) {
       const int z = atoi(ov);
-      if (z >= 1) Z = z > ncc8 ? ncc8 : z;
+      if (z >= 1) Z = z > nccf ? nccf : z;
     }
+    if (use) {
+    p.flow = true;
+    p.plane = false;
+    p.one_per_cu = false;
+    p.tile.th = th, p.tile.tw = fc.tw, p.tile.bn = bn;
     p.ksplit = Z;
-    long fb = (npix8 + 15) / 16;
+    long fb = (npixf + 15) / 16;
     if (fb > 1024) fb = 1024;
     p.finish_blocks = (int)fb;
-    p.partials = Z > 1 ? p.finish_blocks : tiles8;
-    p.ws_bytes = Z > 1 ? (size_t)Z * npix8 * Cout * sizeof(float) : 0;
+    p.partials = Z > 1 ? p.finish_blocks : cy_cdiv((long)N * H, th) * (W / fc.tw);
+    p.ws_bytes = Z > 1 ? (size_t)Z * npixf * Cout * sizeof(float) : 0;
     return p;
+    }
   }
   p.tile = choose_tile((long)N * H, W, Cout);
   const long npix = (long)N * H * W;
@@ -654,8 +684,8 @@ int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) return dispatch_conv_stream<T>(a, st);
     return CY_ERR_DTYPE;
   }
-  if (p.plane8) {
-    if constexpr (sizeof(T) == 2) return launch_conv_plane8<T>(a, st);
+  if (p.flow) {
+    if constexpr (sizeof(T) == 2) return dispatch_conv_flow<T>(a, p.tile.th, p.tile.bn, p.tile.tw, st);
     return CY_ERR_DTYPE;
   }
   if (p.plane) {
@@ -694,13 +724,21 @@ int dispatch_conv(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
 // ---------------------------------------------------------------------------
 // weight repacking:  w[Cout][Cin][3][3] f32  ->  wf[tap][co_pad][ci_pad] (T)
 //                                            ->  wd[tap][ci_pad2][co_pad2] (T), flipped taps
+// The stage-contiguous images of cy_conv_flow.h follow the [tap][co][ci] images in the same buffers:
+//   wf + 9*co_pad*ci_pad :  [Cout/64][Cin/16][tap][2 planes][64 rows = couts][8 channels]    (if Cout % 64 == 0, Cin % 16 == 0)
+//   wd + 9*ci_pad2*co_pad2: [Cin/64][Cout/16][8-tap][2 planes][64 rows = cins][8 couts]      (if Cin % 64 == 0, Cout % 16 == 0)
+__host__ __device__ inline long flow_elem_index(int row, int k, int tap, int nchunk) {
+  return ((((long)(row >> 6) * nchunk + (k >> 4)) * 9 + tap) * 2 + ((k >> 3) & 1)) * 512 + (row & 63) * 8 + (k & 7);
+}
+
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf,
                                     T* __restrict__ wd, int Cout, int Cin, int co_pad, int ci_pad,
-                                    int ci_pad2, int co_pad2) {
+                                    int ci_pad2, int co_pad2, long ff, long fd) {
   const long nf = 9L * co_pad * ci_pad;
   const long nd = wd ? 9L * ci_pad2 * co_pad2 : 0;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nf + nd;
+  if (!wd) fd = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nf + nd + ff + fd;
        i += (long)gridDim.x * blockDim.x) {
     if (i < nf) {
       const int ci = (int)(i % ci_pad);
@@ -709,7 +747,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
       float v = 0.f;
       if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * 9 + tap];
       wf[i] = from_f32<T>(v);
-    } else {
+    } else if (i < nf + nd) {
       const long j = i - nf;
       const int co = (int)(j % co_pad2);
       const int ci = (int)((j / co_pad2) % ci_pad2);
@@ -717,6 +755,14 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
       float v = 0.f;
       if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * 9 + (8 - tap)];
       wd[j] = from_f32<T>(v);
+    } else if (i < nf + nd + ff) {
+      const long j = i - nf - nd;  // (co, ci, tap) enumerated in source order
+      const int tap = (int)(j % 9), ci = (int)((j / 9) % Cin), co = (int)(j / (9L * Cin));
+      wf[nf + flow_elem_index(co, ci, tap, Cin / 16)] = from_f32<T>(w[j]);
+    } else {
+      const long j = i - nf - nd - ff;
+      const int tap = (int)(j % 9), ci = (int)((j / 9) % Cin), co = (int)(j / (9L * Cin));
+      wd[nd + flow_elem_index(ci, co, 8 - tap, Cout / 16)] = from_f32<T>(w[j]);
     }
   }
 }
@@ -770,6 +816,26 @@ __global__ void __launch_bounds__(256)
     if (ci0 + hi5 < it.ci_pad2 && co0 + lo5 < it.co_pad2)
       wd_arena[it.off_d + ((size_t)(8 - tap) * it.ci_pad2 + ci0 + hi5) * it.co_pad2 + co0 + lo5] =
           tile[tap][lo5][hi5];
+  }
+  // stage-contiguous images (cy_conv_flow.h): 16-byte items (row, group of 8 k), 9 x 32 x 4 per tile and image
+  if (it.off_ff >= 0 || it.off_fd >= 0) {
+    for (int idx = tid; idx < 9 * 128; idx += 256) {
+      const int tap = idx >> 7, row = (idx >> 2) & 31, g = idx & 3;
+      if (it.off_ff >= 0 && co0 + row < it.Cout && ci0 + 8 * g < it.Cin) {
+        T v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[tap][row][8 * g + j];
+        T* dst = wf_arena + it.off_ff + flow_elem_index(co0 + row, ci0 + 8 * g, tap, it.Cin / 16);
+        *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(v);
+      }
+      if (it.off_fd >= 0 && ci0 + row < it.Cin && co0 + 8 * g < it.Cout) {
+        T v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[tap][8 * g + j][row];
+        T* dst = wd_arena + it.off_fd + flow_elem_index(ci0 + row, co0 + 8 * g, 8 - tap, it.Cout / 16);
+        *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(v);
+      }
+    }
   }
 }
 
@@ -913,7 +979,7 @@ int first_conv_blocks(long npix, int Cout, int W) {
 // ---------------------------------------------------------------------------
 extern "C" {
 
-int cy_abi_version(void) { return 8; }
+int cy_abi_version(void) { return 9; }
 const char* cy_build_arch(void) { return "gfx950"; }
 
 unsigned long long cy_stream_capture_id(void* stream) {
@@ -930,6 +996,12 @@ int cy_conv3x3_packed_dims(int Cout, int Cin, int* co_pad, int* ci_pad) {
   return CY_OK;
 }
 
+long long cy_conv3x3_packed_elems(int Cout, int Cin, int dtype) {
+  if (Cout <= 0 || Cin <= 0) return 0;
+  const long plane = 9L * cy_roundup(Cout, 128) * cy_roundup(Cin, 64);
+  return plane + (dtype == CY_F32 ? 0 : flow_image_elems(Cout, Cin));
+}
+
 int cy_conv3x3_pack_weights(const float* w, void* wf, void* wd, int Cout, int Cin, int dtype,
                             void* stream) {
   if (!w || !wf) return CY_ERR_ARG;
@@ -937,17 +1009,18 @@ int cy_conv3x3_pack_weights(const float* w, void* wf, void* wd, int Cout, int Ci
   cy_conv3x3_packed_dims(Cout, Cin, &co_pad, &ci_pad);
   cy_conv3x3_packed_dims(Cin, Cout, &ci_pad2, &co_pad2);  // dgrad: roles swapped
   hipStream_t st = (hipStream_t)stream;
-  const long total = 9L * co_pad * ci_pad + (wd ? 9L * ci_pad2 * co_pad2 : 0);
+  const long ff = dtype == CY_F32 ? 0 : flow_image_elems(Cout, Cin), fd = dtype == CY_F32 ? 0 : flow_image_elems(Cin, Cout);
+  const long total = 9L * co_pad * ci_pad + ff + (wd ? 9L * ci_pad2 * co_pad2 + fd : 0);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, (bf16*)wf,
-                       (bf16*)wd, Cout, Cin, co_pad, ci_pad, ci_pad2, co_pad2);
+                       (bf16*)wd, Cout, Cin, co_pad, ci_pad, ci_pad2, co_pad2, ff, fd);
   else if (dtype == CY_F16)
     hipLaunchKernelGGL(pack_weights_kernel<f16>, dim3(blocks), dim3(256), 0, st, w, (f16*)wf,
-                       (f16*)wd, Cout, Cin, co_pad, ci_pad, ci_pad2, co_pad2);
+                       (f16*)wd, Cout, Cin, co_pad, ci_pad, ci_pad2, co_pad2, ff, fd);
   else if (dtype == CY_F32)
     hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, w, (float*)wf,
-                       (float*)wd, Cout, Cin, co_pad, ci_pad, ci_pad2, co_pad2);
+                       (float*)wd, Cout, Cin, co_pad, ci_pad, ci_pad2, co_pad2, 0L, 0L);
   else
     return CY_ERR_DTYPE;
   CY_CHECK_LAUNCH();
@@ -992,9 +1065,8 @@ static int conv_check(const cy_conv_desc* d) {
 }
 
 static ConvPlan plan_of(const cy_conv_desc* d) {
-  const bool p8 = !(d->prologue && d->C1 > Plane8Cfg<bf16>::COEF_MAX) && d->mode1 != CY_SRC_POOL2 &&
-                  !(d->C2 != 0 && d->C1 % Plane8Cfg<bf16>::KC);
-  return plan_conv(d->N, d->H, d->W, d->C1 + d->C2, d->Cout, d->in_dtype == CY_F32 ? 4 : 2, p8, stream_applicable(d), d->prologue != 0);
+  return plan_conv(d->N, d->H, d->W, d->C1 + d->C2, d->Cout, d->in_dtype == CY_F32 ? 4 : 2, stream_applicable(d), d->prologue != 0,
+                   flow_choice(d));
 }
 
 int cy_conv3x3_num_partials(const cy_conv_desc* d) {
@@ -1007,7 +1079,7 @@ int cy_conv3x3_plan(const cy_conv_desc* d, cy_conv_plan* plan) {
   if (rc != CY_OK) return rc;
   if (!plan) return CY_ERR_ARG;
   const ConvPlan p = plan_of(d);
-  plan->kernel = p.stream ? 4 : (p.plane8 ? 3 : (p.plane ? 1 : 0));
+  plan->kernel = p.flow ? 5 : (p.stream ? 4 : (p.plane ? 1 : 0));
   plan->th = p.tile.th, plan->tw = p.tile.tw, plan->bn = p.tile.bn;
   plan->ksplit = p.ksplit, plan->one_per_cu = p.one_per_cu ? 1 : 0, plan->partials = p.partials;
   plan->workgroups = cy_cdiv((long)d->N * d->H, p.tile.th) * cy_cdiv(d->W, p.tile.tw) *
@@ -1048,6 +1120,11 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
     a.bytes_o2 = d->split_c > 0 ? ((opx - 1) * d->ldo2 + (d->Cout - d->split_c)) * ob : 0;
   }
   cy_conv3x3_packed_dims(d->Cout, d->C1 + d->C2, &a.w_co_pad, &a.w_ci_pad);
+  {
+    const long fe = d->in_dtype == CY_F32 ? 0 : flow_image_elems(d->Cout, d->C1 + d->C2);
+    a.wflow = fe ? (const unsigned char*)w_packed + 9L * a.w_co_pad * a.w_ci_pad * 2 : nullptr;
+    a.bytes_w = fe * 2;
+  }
   const ConvPlan p = plan_of(d);
   a.bytes_st = stats ? (long long)p.partials * 2 * d->Cout * 4 : 0;
   a.ksplit = p.ksplit;
@@ -1061,97 +1138,10 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
          : d->in_dtype == CY_F16 ? launch_finish<f16>(a, p, st) : launch_finish<float>(a, p, st);
 }
 
-// ---- persistent producer / consumer kernel (cy_conv_pc.h) ------------------------------------------
-static int pc_check(const cy_conv_desc* d) {
-  const int rc = conv_check(d);
-  if (rc != CY_OK) return rc;
-  if (d->in_dtype != CY_BF16) return CY_ERR_DTYPE;
-  if (d->W % 14) return CY_ERR_SHAPE;
-  if (d->mode1 == CY_SRC_POOL2 && d->C2) return CY_ERR_ARG;
-  if (d->prologue && d->C1 > 512) return CY_ERR_SHAPE;  // (prologue coefficients are LDS-resident: 512 channels)
+// development aid: shader-clock stamps of workgroup 0 of the streaming kernel (-DCY_STREAM_STAMPS, tools/stream_stamps.py)
+int cy_debug_conv_stamps(unsigned long long* dev_buf) {
+  g_conv_stamp_buf = dev_buf;
   return CY_OK;
-}
-static PcPlan pc_plan_of(const cy_conv_desc* d) { return plan_pc(d->N, d->H, d->W, d->C1 + d->C2, d->Cout); }
-
-long long cy_conv3x3_pc_packed_elems(int Cout, int Cin) {
-  if (Cout <= 0 || Cin <= 0) return CY_ERR_ARG;
-  return pc_packed_elems(Cout, Cin);
-}
-
-int cy_conv3x3_pc_pack(const float* w, void* wpc_f, void* wpc_d, int Cout, int Cin, int dtype, void* stream) {
-  if (!w || !wpc_f || Cout <= 0 || Cin <= 0) return CY_ERR_ARG;
-  if (dtype != CY_BF16) return CY_ERR_DTYPE;
-  hipStream_t st = (hipStream_t)stream;
-  {
-    const long items = pc_packed_elems(Cout, Cin) / 8;
-    const int blocks = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
-    hipLaunchKernelGGL(pack_weights_pc_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, (bf16*)wpc_f, Cout, Cin,
-                       pc_bn_for(Cout), 0);
-    CY_CHECK_LAUNCH();
-  }
-  if (wpc_d) {
-    const long items = pc_packed_elems(Cin, Cout) / 8;
-    const int blocks = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
-    hipLaunchKernelGGL(pack_weights_pc_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, (bf16*)wpc_d, Cout, Cin,
-                       pc_bn_for(Cin), 1);
-    CY_CHECK_LAUNCH();
-  }
-  return CY_OK;
-}
-
-int cy_debug_p8_weights(const void* pc_image) {
-  g_p8_w_dma = pc_image;
-  return CY_OK;
-}
-
-int cy_debug_pc_stamps(unsigned long long* dev_buf) {
-  g_pc_stamp_buf = dev_buf;
-  g_p8_stamp_buf = dev_buf;
-  return CY_OK;
-}
-
-int cy_conv3x3_pc_num_partials(const cy_conv_desc* d) {
-  if (pc_check(d) != CY_OK) return CY_ERR_ARG;
-  return pc_plan_of(d).partials;
-}
-
-size_t cy_conv3x3_pc_ws_bytes(const cy_conv_desc* d) {
-  if (pc_check(d) != CY_OK) return 0;
-  return pc_plan_of(d).ws_bytes;
-}
-
-int cy_conv3x3_pc_fwd(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
-                      const float* shift, const void* w_pc, void* out, void* out2, float* stats, void* ws,
-                      size_t ws_bytes, void* stream) {
-  int rc = pc_check(d);
-  if (rc != CY_OK) return rc;
-  if (!src1 || !w_pc || !out) return CY_ERR_ARG;
-  if (d->C2 && !src2) return CY_ERR_ARG;
-  if (d->prologue && (!scale || !shift)) return CY_ERR_ARG;
-  if (d->split_c > 0 && !out2) return CY_ERR_ARG;
-  const PcPlan p = pc_plan_of(d);
-  if (p.ksplit > 1 && (!ws || ws_bytes < p.ws_bytes)) return CY_ERR_WORKSPACE;
-  PcArgs pa = {};
-  ConvArgs& a = pa.c;
-  a.src1 = src1, a.src2 = src2, a.scale = scale, a.shift = shift, a.w = nullptr;
-  a.out = out, a.out2 = out2, a.stats = stats;
-  a.N = d->N, a.H = d->H, a.W = d->W, a.NH = d->N * d->H;
-  a.C1 = d->C1, a.C2 = d->C2, a.Cout = d->Cout;
-  a.mode1 = d->mode1, a.prologue = d->prologue;
-  a.ld1 = d->ld1, a.ld2 = d->ld2, a.ldo = d->ldo, a.ldo2 = d->ldo2, a.split_c = d->split_c;
-  a.ksplit = p.ksplit, a.ws = (float*)ws;
-  pa.wpc = w_pc, pa.tiles = p.tiles, pa.nblk = p.nblk, pa.nst = p.nst, pa.units = p.units;
-  pa.inv_h = 1.0f / (float)d->H;
-  pa.inv_ks = 1.0f / (float)p.ksplit, pa.inv_tiles = 1.0f / (float)p.tiles, pa.inv_tiles_w = 1.0f / (float)(d->W / 14);
-  hipStream_t st = (hipStream_t)stream;
-  if (p.bn == 128 && p.ncw == 8) rc = launch_conv_pc<bf16, 128, 8>(pa, p, st);
-  else if (p.bn == 128) rc = launch_conv_pc<bf16, 128>(pa, p, st);
-  else if (p.bn == 64) rc = launch_conv_pc<bf16, 64>(pa, p, st);
-  else rc = launch_conv_pc<bf16, 32>(pa, p, st);
-  if (rc != CY_OK || p.ksplit == 1) return rc;
-  ConvPlan fp = {};
-  fp.ksplit = p.ksplit, fp.finish_blocks = p.finish_blocks;
-  return launch_finish<bf16>(a, fp, st);
 }
 
 int cy_conv3x3_first_num_partials(int N, int H, int W, int Cout) {

@@ -1,0 +1,501 @@
+// "Flow" form of the plane kernel (cy_conv_plane.h) for the MFMA-bound layers (Cout >= 64, 16-bit storage):
+// the same GEMM view (M = flattened halo grid, a tap = one uniform address shift, LDS planes
+// [16-byte channel group][position]) and the same register epilogue, but NO register staging and NO per-tap
+// barrier.  Where a workgroup's time went in the plane kernel's 128-cout build: nine __syncthreads() per
+// 32-channel chunk, each draining the next tap's weight request (vmcnt(0)) and followed by a ds_write commit,
+// plus a synchronous 41 KB halo staging at every chunk boundary -- 40 cycles per MFMA in the tap loop and two
+// workgroups per CU needed just to cover each other's commits.  Here
+//   * ONE workgroup of eight waves per CU owns 512 (32 x 16) or 1024 (64 x 16) positions x 128 / 64 couts --
+//     all 256 KB of accumulators a CU can hold, so the weight stream per MFMA is half the plane kernel's;
+//   * a stage = one 16-channel chunk: the halo tile (2 planes) AND all nine taps of the weights (18 slices of
+//     BN rows x 16 B), both brought by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPRs, no ds_write, no commit
+//     phase): activations with per-lane gather offsets (padding = out of range = zeros; nearest-x2 and the
+//     second source of a concat are other offsets), weights from a stage-contiguous image
+//     [64-cout block][16-channel chunk][tap][plane][64 rows][8 channels] in 1 KB pieces;
+//   * two stages: the DMA of chunk c+1 is issued right behind the barrier that opens chunk c, spread over
+//     the taps, and has a whole chunk of MFMAs (2304 cycles per wave, two waves per SIMD) to land; ONE
+//     s_barrier per chunk (per 72 MFMAs of a wave) instead of nine;
+//   * the BN+ReLU prologue is an in-place LDS pass over the items the wave's own DMA brought (fixed eight
+//     channels per wave), between its vmcnt wait and the barrier; 2x2-max-on-load layers stay on the plane kernel;
+//   * W16: widths that are multiples of 16 (224, 112 and every level of a 256 x 256 input) use 16-wide tiles on
+//     an 18-wide halo pitch -- no thrown-away accumulator columns (the 16 x 14 tiling wastes 2 of 16) -- with
+//     the lanes of a 32-position block permuted so that each of ds_read_b128's 16-lane groups reads one halo row
+//     (256 contiguous bytes: conflict-free on any pitch); the epilogue stores per lane, so the permutation is free.
+#pragma once
+#include "cy_conv_plane.h"
+
+namespace {
+
+template <typename T, int TH_, int BN_, int WGM_, int WGN_, bool W16_> struct FlowCfg {
+  static constexpr int TH = TH_, BN = BN_, WGM = WGM_, WGN = WGN_;
+  static constexpr bool W16 = W16_;
+  static constexpr int NW = WGM * WGN, NTHR = 64 * NW;
+  static constexpr int EPC = ElemTr<T>::EPC;
+  static constexpr int KC = 16, CPP = 2;
+  static constexpr int HP = W16 ? 18 : 16, TW = W16 ? 16 : 14;
+  static constexpr int NPOS = (TH + 2) * HP;   // halo positions; LDS position index = 1 + hr * HP + hc
+  static constexpr int ZB = NPOS + 2;          // all-zero row (18 positions + margin)
+  static constexpr int APL = ((ZB + 20 + 15) / 16) * 16;
+  static constexpr int APLB = APL * 16;        // bytes of one activation plane
+  static constexpr int A_BYTES = CPP * APLB;
+  static constexpr int BPLB = BN * 16;         // one (tap, plane) slice of the weights
+  static constexpr int B_BYTES = 9 * CPP * BPLB;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int MT = TH / 2;            // 32-position blocks (two rows of 16)
+  static constexpr int M_REP = MT / WGM, N_REP = BN / (32 * WGN);
+  static constexpr int NGA = (NPOS + 63) / 64;                 // halo position groups of 64
+  static constexpr int NAI = (NGA + NW / 2 - 1) / (NW / 2);    // ... per wave (wave -> plane wave & 1), at most
+  static constexpr int NBITEMS = 9 * CPP * (BN / 64);          // 1 KB weight pieces per chunk
+  static constexpr int NBI = (NBITEMS + NW - 1) / NW;
+  static constexpr int COEF_MAX = 512;  // prologue channels held in LDS
+  static constexpr int COEF_BYTES = 2 * COEF_MAX * 4;
+  static constexpr int TAB_BYTES = ((3 * TH + 4) * 4 + 15) & ~15;
+  static constexpr int SMEM = 2 * STAGE + COEF_BYTES + TAB_BYTES;
+  static_assert(sizeof(T) == 2 && EPC == 8, "16-bit storage types only");
+  static_assert(NW % 2 == 0 && MT % WGM == 0 && BN % (32 * WGN) == 0 && BN % 64 == 0, "wave split");
+  static_assert(NAI <= 9 && NBI <= 9, "one DMA slot per tap");
+  static_assert(WGM * 2 * BN * 4 <= STAGE, "statistics scratch");
+  static_assert(SMEM <= 160 * 1024, "LDS");
+  static_assert(COEF_MAX <= NTHR, "one prologue coefficient pair per thread");
+};
+
+// elements of the stage-contiguous weight image of a (Cout, Cin) kernel (0: this geometry has none)
+inline long flow_image_elems(int Cout, int Cin) {
+  if (Cout % 64 || Cin % 16) return 0;
+  return 9L * Cout * Cin;
+}
+
+template <typename T, int TH, int BN, int WGM, int WGN, bool W16>
+__global__ void __launch_bounds__(64 * WGM * WGN, 2)
+    conv3x3_flow_kernel(const ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (buffer-descriptor type and builtins exist in the device pass only)
+  using C = FlowCfg<T, TH, BN, WGM, WGN, W16>;
+  using M = Mma<T>;
+  constexpr int EPC = C::EPC, KC = C::KC, HP = C::HP, TW = C::TW, NW = C::NW;
+  constexpr int M_REP = C::M_REP, N_REP = C::N_REP, NAI = C::NAI, NBI = C::NBI;
+  constexpr int APLB = C::APLB, BPLB = C::BPLB;
+  constexpr unsigned OOB = 0x80000000u;  // (every tensor is below 2 GiB: out of range whatever the scalar offset adds)
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_coef = reinterpret_cast<float*>(smem + 2 * C::STAGE);
+  int* s_row1 = reinterpret_cast<int*>(smem + 2 * C::STAGE + C::COEF_BYTES);
+  int* s_row2 = s_row1 + (TH + 2);
+  int* s_flag = s_row2 + (TH + 2);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int r = lane & 31, h = lane >> 5;
+  // position of lane r inside a 32-position block: (row 0 / 1, column 0..15)
+  int prow, pcol;
+  if constexpr (W16) {
+    // ds_read_b128 serves lanes {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} together: each group = one row
+    const int grp = (r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28;
+    prow = grp;
+    pcol = grp ? (r < 12 ? r - 4 : (r < 20 ? r - 8 : r - 16)) : (r < 4 ? r : (r < 16 ? r - 8 : r - 12));
+  } else {
+    prow = r >> 4;
+    pcol = r & 15;
+  }
+
+  int tile = blockIdx.x;
+  if (a.xcd_remap) {  // contiguous band of tiles per XCD (see conv3x3_plane_kernel)
+    const int nt = gridDim.x, x = tile & 7, i = tile >> 3, q = nt >> 3, rr = nt & 7;
+    tile = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
+  }
+  const int ct = tile % a.tiles_w;
+  const int rt = tile / a.tiles_w;
+  const int R0 = rt * TH, w0 = ct * TW;
+  const int n0 = blockIdx.y * BN;
+  const int Cin = a.C1 + a.C2;
+  const int ncc = Cin / KC;  // host: Cin % 16 == 0
+  const int cc0 = (ncc * (int)blockIdx.z) / a.ksplit;
+  const int cc1 = (ncc * ((int)blockIdx.z + 1)) / a.ksplit;
+
+  // ---- descriptors (from wave-uniform scalars only: no waterfall loops around the loads) ---------------------
+  auto make_rsrc = [&](const void* p, long long bytes) {
+    const unsigned long long b = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, (int)bytes, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.src1, a.bytes1);
+  const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(a.src2 ? a.src2 : a.src1, a.src2 ? a.bytes2 : 0);
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wflow, a.bytes_w);
+
+  // ---- weights: piece j = wave + NW i of a chunk = (tap * 2 + plane, 64-row half) ------------------------------
+  const unsigned wlane = (unsigned)lane * 16u;
+  const unsigned wblk = (unsigned)(blockIdx.y * (BN / 64)) * (unsigned)ncc * 18432u;
+  auto b_dma = [&](int cc, auto I, int st) {
+    constexpr int i = decltype(I)::value;
+    const int j = wave + NW * i;  // wave-uniform
+    if (j >= C::NBITEMS) return;
+    const int tp = j / (BN / 64), half = j % (BN / 64);
+    const unsigned soff = wblk + ((unsigned)half * (unsigned)ncc + (unsigned)cc) * 18432u + (unsigned)tp * 1024u;
+    auto* dst = (__attribute__((address_space(3))) void*)(smem + st + C::A_BYTES + tp * BPLB + half * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wlane, soff, 0, 0);
+  };
+  // BN+ReLU coefficients of the previous layer: requested BEFORE any DMA (vmcnt retires in order: a load behind the
+  // DMAs would wait for all of them), written to LDS behind the halo requests
+  float csc = 0.f, csh = 0.f;
+  if (a.prologue && tid < a.C1) {  // host: C1 <= COEF_MAX <= NTHR
+    csc = a.scale[tid];
+    csh = a.shift[tid];
+  }
+  // (the first chunk's weights need nothing from the tables below: request them first)
+  plane_static_for<0, NBI>([&](auto I) { b_dma(cc0, I, 0); });
+
+  for (int idx = tid; idx < 2 * C::CPP * 20; idx += C::NTHR) {  // the zero rows of both stages (never touched by DMA)
+    const int pl = idx / 20, z = idx % 20;
+    st16(smem + (pl >> 1) * C::STAGE + (pl & 1) * APLB + (C::ZB - 1 + z) * 16, u32x4{0u, 0u, 0u, 0u});
+  }
+  conv_row_tables(a, TH, R0, tid, s_row1, s_row2, s_flag, false);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the DMA stays in flight)
+
+  // ---- halo: item i of this wave = position group g = (wave >> 1) + (NW / 2) i of plane (wave & 1) ----------
+  const int apl = wave & 1;
+  unsigned poff1[NAI], poff2[NAI];
+#pragma unroll
+  for (int i = 0; i < NAI; ++i) {
+    const int lin = ((wave >> 1) + (NW / 2) * i) * 64 + lane;
+    const int hr = lin / HP, hc = lin - hr * HP;
+    const int w = w0 - 1 + hc;
+    poff1[i] = poff2[i] = OOB;
+    if (lin < C::NPOS && w >= 0 && w < a.W) {
+      const int r1 = s_row1[hr], r2 = s_row2[hr];
+      const int wsh = a.mode1 == CY_SRC_UP2 ? 1 : 0;
+      if (r1 >= 0) poff1[i] = ((unsigned)(r1 + (w >> wsh)) * (unsigned)a.ld1 + (unsigned)(apl * EPC)) * (unsigned)sizeof(T);
+      if (r2 >= 0 && a.C2 > 0) poff2[i] = ((unsigned)(r2 + w) * (unsigned)a.ld2 + (unsigned)(apl * EPC)) * (unsigned)sizeof(T);
+    }
+  }
+  auto a_dma = [&](int cc, auto I, int st) {
+    constexpr int i = decltype(I)::value;
+    const int g = (wave >> 1) + (NW / 2) * i;  // wave-uniform
+    if (g >= C::NGA) return;
+    const int c0 = cc * KC;
+    const bool in2 = c0 >= a.C1;  // host: C1 % 16 == 0
+    const unsigned soff = (unsigned)((in2 ? c0 - a.C1 : c0) * (int)sizeof(T));
+    auto* dst = (__attribute__((address_space(3))) void*)(smem + st + apl * APLB + 16 + g * 1024);
+    if (g * 64 + 64 <= C::NPOS || lane < C::NPOS - g * 64) {  // the last group may be part of a wave
+      if (in2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, dst, 16, poff2[i], soff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, poff1[i], soff, 0, 0);
+    }
+  };
+  // BN+ReLU prologue: in place over this wave's own items of chunk cc (after its vmcnt wait, before the barrier);
+  // padding positions stay zero
+  auto a_transform = [&](int cc, int st) {
+    const int cabs = cc * KC + apl * EPC;
+    if (cabs >= a.C1) return;
+    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(s_coef + cabs);
+    const f32x4 sc1 = *reinterpret_cast<const f32x4*>(s_coef + cabs + 4);
+    const f32x4 sh0 = *reinterpret_cast<const f32x4*>(s_coef + C::COEF_MAX + cabs);
+    const f32x4 sh1 = *reinterpret_cast<const f32x4*>(s_coef + C::COEF_MAX + cabs + 4);
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+      const int g = (wave >> 1) + (NW / 2) * i;
+      if (g >= C::NGA) continue;
+      if (poff1[i] != OOB) {
+        unsigned char* p = smem + st + apl * APLB + 16 + (g * 64 + lane) * 16;
+        float f[EPC];
+        Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(p), f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f[j] = fmaxf(fmaf(sc0[j], f[j], sh0[j]), 0.f);
+          f[4 + j] = fmaxf(fmaf(sc1[j], f[4 + j], sh1[j]), 0.f);
+        }
+        st16(p, Chunk<T>::pack(f));
+      }
+    }
+  };
+
+  // ---- per-lane fragment bases (bytes inside a stage) ------------------------------------------------------
+  int amid[M_REP];
+  unsigned aflag = 0;
+#pragma unroll
+  for (int m = 0; m < M_REP; ++m) {
+    const int ty = 2 * (wm * M_REP + m) + prow;
+    amid[m] = ((ty + 1) * HP + pcol + (C::W16 ? 1 : 0)) * 16 + h * APLB;
+    aflag |= (unsigned)s_flag[ty] << (2 * m);
+  }
+  const int azer = (C::ZB + pcol) * 16 + h * APLB;
+  auto aaddr = [&](int m, int d) {  // d: tap row 0..2; first / last row of an image: the neighbour is the zero row
+    if (d == 1) return amid[m];
+    const bool z = (aflag >> (2 * m + (d == 0 ? 0 : 1))) & 1u;
+    return z ? azer : amid[m] + (d == 0 ? -HP * 16 : HP * 16);
+  };
+  int bbase[N_REP];
+#pragma unroll
+  for (int n = 0; n < N_REP; ++n) bbase[n] = C::A_BYTES + ((wn * N_REP + n) * 32 + r) * 16 + h * BPLB;
+
+  f32x16 acc[M_REP][N_REP];
+#pragma unroll
+  for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+    for (int n = 0; n < N_REP; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+  auto frag = [&](const unsigned char* p) {
+    typename M::Frag f;
+    f.v = *reinterpret_cast<const decltype(f.v)*>(p);
+    return f;
+  };
+
+  // first chunk's halo tile
+  plane_static_for<0, NAI>([&](auto I) { a_dma(cc0, I, 0); });
+  if (a.prologue) {  // wave-uniform
+    if (tid < a.C1) {
+      s_coef[tid] = csc;
+      s_coef[C::COEF_MAX + tid] = csh;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+
+  int st_cur = 0, st_nxt = C::STAGE;
+  for (int cc = cc0; cc < cc1; ++cc) {
+    // (1) this wave's part of chunk cc has landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.prologue) a_transform(cc, st_cur);
+    // (2) every wave's part has, and every wave is done reading the other stage
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const bool more = cc + 1 < cc1;
+    // (3) nine taps; the DMA of chunk cc + 1 is issued behind the MFMAs of taps 0.. (one halo item and one
+    //     weight piece per tap and wave)
+    typename M::Frag fa[2][M_REP], fb[2][N_REP];
+    const unsigned char* sb = smem + st_cur;
+    auto load_tap = [&](int set, auto TAP) {
+      constexpr int t = decltype(TAP)::value;
+      constexpr int d = t / 3, dw = t % 3 - 1;
+#pragma unroll
+      for (int n = 0; n < N_REP; ++n) fb[set][n] = frag(sb + bbase[n] + t * 2 * BPLB);
+#pragma unroll
+      for (int m = 0; m < M_REP; ++m) fa[set][m] = frag(sb + aaddr(m, d) + (dw + 1) * 16);
+    };
+    load_tap(0, TapC<0>{});
+    plane_static_for<0, 9>([&](auto TAP) {
+      constexpr int t = decltype(TAP)::value;
+      if constexpr (t + 1 < 9) load_tap((t + 1) & 1, TapC<(t + 1 < 9 ? t + 1 : 0)>{});
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+        for (int n = 0; n < N_REP; ++n) M::mma(fb[t & 1][n], fa[t & 1][m], acc[m][n]);  // rows = couts
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        if constexpr (t < NBI) b_dma(cc + 1, TapC<(t < NBI ? t : 0)>{}, st_nxt);
+        if constexpr (t < NAI) a_dma(cc + 1, TapC<(t < NAI ? t : 0)>{}, st_nxt);
+      }
+    });
+    const int s = st_cur;
+    st_cur = st_nxt;
+    st_nxt = s;
+  }
+  __syncthreads();  // the statistics scratch aliases the operand buffers
+
+  // ---------------- epilogue (as conv3x3_plane_kernel): accumulators -> NHWC from registers ----------------
+  auto position = [&](int m, int& R, int& w) -> bool {
+    R = R0 + 2 * (wm * M_REP + m) + prow;
+    if constexpr (C::W16) {
+      w = w0 + pcol;
+      return R < a.NH && w < a.W;
+    } else {
+      w = w0 + pcol - 1;
+      return pcol >= 1 && pcol <= TW && R < a.NH && w < a.W;
+    }
+  };
+  if (a.ksplit > 1) {
+    float* wsz = a.ws + (size_t)blockIdx.z * ((size_t)a.NH * a.W) * a.Cout;
+#pragma unroll
+    for (int m = 0; m < M_REP; ++m) {
+      int R, w;
+      if (!position(m, R, w)) continue;
+      float* dst = wsz + ((size_t)R * a.W + w) * a.Cout;
+#pragma unroll
+      for (int n = 0; n < N_REP; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = n0 + (wn * N_REP + n) * 32 + 8 * g + 4 * h;
+          if (co < a.Cout)
+            *reinterpret_cast<f32x4*>(dst + co) = f32x4{acc[m][n][4 * g], acc[m][n][4 * g + 1],
+                                                        acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+        }
+    }
+    return;
+  }
+  float* sstat = reinterpret_cast<float*>(smem);
+  const bool do_stats = a.stats != nullptr;
+  T* o1 = reinterpret_cast<T*>(a.out);
+  T* o2 = reinterpret_cast<T*>(a.out2);
+#pragma unroll
+  for (int n = 0; n < N_REP; ++n) {
+    float s1v[16], s2v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s1v[i] = s2v[i] = 0.f;
+#pragma unroll
+    for (int m = 0; m < M_REP; ++m) {
+      int R, w;
+      const bool ok = position(m, R, w);
+      const size_t gp = (size_t)R * a.W + w;
+      u32x2 packed[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        T pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pk[j] = from_f32<T>(acc[m][n][4 * g + j]);
+          if (do_stats && ok) {
+            const float qv = to_f32<T>(pk[j]);
+            s1v[4 * g + j] += qv;
+            s2v[4 * g + j] += qv * qv;
+          }
+        }
+        packed[g] = __builtin_bit_cast(u32x2, *reinterpret_cast<const s16x4*>(pk));
+      }
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {  // half-wave swaps pair the 8-byte channel runs into 16-byte stores
+        u32x2 lo = packed[g], hi = packed[g + 1];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(lo[j], hi[j], false, false);
+          lo[j] = sw[0];
+          hi[j] = sw[1];
+        }
+        const int co = n0 + (wn * N_REP + n) * 32 + 8 * g + 8 * h;
+        if (ok && co < a.Cout) {
+          T* dst = (a.split_c > 0 && co >= a.split_c) ? o2 + gp * a.ldo2 + (co - a.split_c)
+                                                      : o1 + gp * a.ldo + co;
+          *reinterpret_cast<u32x4*>(dst) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+      }
+    }
+    if (do_stats) {  // reduce-scatter over the 32 lanes of each half (see conv3x3_plane_kernel)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool up = (lane & 16) != 0;
+        const float snd1 = up ? s1v[i] : s1v[i + 8], snd2 = up ? s2v[i] : s2v[i + 8];
+        const float kp1 = up ? s1v[i + 8] : s1v[i], kp2 = up ? s2v[i + 8] : s2v[i];
+        s1v[i] = kp1 + __shfl_xor(snd1, 16, 64);
+        s2v[i] = kp2 + __shfl_xor(snd2, 16, 64);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool up = (lane & 8) != 0;
+        const float snd1 = up ? s1v[i] : s1v[i + 4], snd2 = up ? s2v[i] : s2v[i + 4];
+        const float kp1 = up ? s1v[i + 4] : s1v[i], kp2 = up ? s2v[i + 4] : s2v[i];
+        s1v[i] = kp1 + __shfl_xor(snd1, 8, 64);
+        s2v[i] = kp2 + __shfl_xor(snd2, 8, 64);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool up = (lane & 4) != 0;
+        const float snd1 = up ? s1v[i] : s1v[i + 2], snd2 = up ? s2v[i] : s2v[i + 2];
+        const float kp1 = up ? s1v[i + 2] : s1v[i], kp2 = up ? s2v[i + 2] : s2v[i];
+        s1v[i] = kp1 + __shfl_xor(snd1, 4, 64);
+        s2v[i] = kp2 + __shfl_xor(snd2, 4, 64);
+      }
+      {
+        const bool up = (lane & 2) != 0;
+        const float snd1 = up ? s1v[0] : s1v[1], snd2 = up ? s2v[0] : s2v[1];
+        const float kp1 = up ? s1v[1] : s1v[0], kp2 = up ? s2v[1] : s2v[0];
+        s1v[0] = kp1 + __shfl_xor(snd1, 2, 64);
+        s2v[0] = kp2 + __shfl_xor(snd2, 2, 64);
+      }
+      s1v[0] += __shfl_xor(s1v[0], 1, 64);
+      s2v[0] += __shfl_xor(s2v[0], 1, 64);
+      if ((lane & 1) == 0) {
+        const int reg = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        const int col = (wn * N_REP + n) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        sstat[(wm * 2 + 0) * BN + col] = s1v[0];
+        sstat[(wm * 2 + 1) * BN + col] = s2v[0];
+      }
+    }
+  }
+  if (do_stats) {
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int qq = 0; qq < WGM; ++qq) {
+        t1 += sstat[(qq * 2 + 0) * BN + tid];
+        t2 += sstat[(qq * 2 + 1) * BN + tid];
+      }
+      a.stats[((size_t)tile * 2 + 0) * a.Cout + n0 + tid] = t1;
+      a.stats[((size_t)tile * 2 + 1) * a.Cout + n0 + tid] = t2;
+    }
+  }
+#endif
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------
+struct FlowChoice {
+  bool ok;
+  int th, bn, tw;  // big tile: 32 rows x 128 couts (4 x 2 waves) or 64 rows x 64 couts (8 x 1 waves); 16- or 14-wide
+  bool small_ok;   // Cout % 128 == 0: also 16 rows x 128 couts (4 x 2 waves of 64 positions x 64 couts)
+};
+
+// applicability beyond the plane kernel's: 16-bit storage, no 2x2 max on load, 16-channel chunks read one source,
+// 64-cout blocks, the stage-contiguous weight image exists, every tensor below 2 GiB (32-bit buffer offsets)
+inline FlowChoice flow_choice(const cy_conv_desc* d) {
+  FlowChoice f = {false, 0, 0, 0, false};
+  const int Cin = d->C1 + d->C2;
+  if (d->in_dtype == CY_F32 || d->mode1 == CY_SRC_POOL2) return f;
+  if (d->C1 % 16 || d->C2 % 16 || d->Cout % 64) return f;
+  if (d->prologue && d->C1 > 512) return f;
+  if (d->split_c > 0 && d->split_c % 8) return f;
+  if (d->W % 16 == 0) f.tw = 16;
+  else if (d->W % 14 == 0) f.tw = 14;
+  else return f;
+  const long eb = 2, opx = (long)d->N * d->H * d->W;
+  const long px1 = d->mode1 == CY_SRC_UP2 ? (long)d->N * (d->H / 2) * (d->W / 2) : opx;
+  const long lim = (1L << 31) - 1;
+  if (px1 * d->ld1 * eb > lim || (d->C2 && opx * d->ld2 * eb > lim)) return f;
+  if (flow_image_elems(d->Cout, Cin) == 0) return f;
+  if (d->Cout % 128 == 0) f.th = 32, f.bn = 128, f.small_ok = true;
+  else f.th = 64, f.bn = 64;
+  f.ok = true;
+  return f;
+}
+
+template <typename T, int TH, int BN, int WGM, int WGN, bool W16>
+int launch_conv_flow(ConvArgs a, hipStream_t st) {
+  using C = FlowCfg<T, TH, BN, WGM, WGN, W16>;
+  auto kern = conv3x3_flow_kernel<T, TH, BN, WGM, WGN, W16>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM) != hipSuccess)
+      return CY_ERR_LAUNCH;
+    attr_done = true;
+  }
+  if (a.W % C::TW != 0 || a.Cout % BN != 0) return CY_ERR_SHAPE;
+  a.tiles_w = a.W / C::TW;
+  static const int xcd = [] {
+    const char* e = getenv("CY_PLANE_XCD");
+    return e ? atoi(e) : 1;
+  }();
+  a.xcd_remap = xcd;
+  dim3 grid(cy_cdiv(a.NH, TH) * a.tiles_w, a.Cout / BN, a.ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), C::SMEM, st, a);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+template <typename T>
+int dispatch_conv_flow(const ConvArgs& a, int th, int bn, int tw, hipStream_t st) {
+  if (th == 16 && bn == 128) {
+    if (tw == 16) return launch_conv_flow<T, 16, 128, 4, 2, true>(a, st);
+    return launch_conv_flow<T, 16, 128, 4, 2, false>(a, st);
+  }
+  if (th == 32 && bn == 128) {
+    if (tw == 16) return launch_conv_flow<T, 32, 128, 4, 2, true>(a, st);
+    return launch_conv_flow<T, 32, 128, 4, 2, false>(a, st);
+  }
+  if (th == 64 && bn == 64) {
+    if (tw == 16) return launch_conv_flow<T, 64, 64, 8, 1, true>(a, st);
+    return launch_conv_flow<T, 64, 64, 8, 1, false>(a, st);
+  }
+  return CY_ERR_SHAPE;
+}
+
+}  // namespace

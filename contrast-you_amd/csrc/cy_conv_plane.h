@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256, PREFA ? 1 : 2)
       if constexpr (INTERLEAVE) {
         // bf16: the LDS reads of k-step ks+1 are issued BETWEEN the MFMAs of k-step ks (an MFMA holds the
         // SIMD's issue port for 8 of its 32 cycles), not as a burst in front of them during which the matrix
-        // pipe idles: in-kernel stamps of the same loop in cy_conv_pc.h, 48 -> 40 cycles per MFMA
+        // pipe idles: in-kernel stamps of the same loop in round 2's producer / consumer experiment, 48 -> 40 cycles per MFMA
 #pragma unroll
         for (int m = 0; m < M_REP; ++m)
 #pragma unroll

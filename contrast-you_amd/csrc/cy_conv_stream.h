@@ -17,9 +17,19 @@
 //   * BN partial sums per (tile, wave row) straight from registers, no second barrier.
 // Layers with a load transform (BN+ReLU prologue, 2x2 max) stay on the plane kernel.
 #pragma once
-#include "cy_conv_plane8.h"  // (P8_STAMP, g_p8_stamp_buf: the development stamps)
+#include "cy_conv_plane.h"
 
 namespace {
+
+static unsigned long long* g_conv_stamp_buf = nullptr;  // set by cy_debug_conv_stamps
+#define P8_STAMP()                                                                              \
+  do {                                                                                          \
+    if (stamping && nst < 96) {                                                                 \
+      const unsigned long long t__ = __builtin_amdgcn_s_memtime();                              \
+      if (lane == 0) s_stamp[wave * 96 + nst] = t__;                                            \
+      ++nst;                                                                                    \
+    }                                                                                           \
+  } while (0)
 
 // Shapes: four waves along the 256 halo positions of a tile (two 32-position blocks each) per block of 32 couts
 // (NBW blocks per wave: 1); NBUF tile buffers (2 for Cin 64 -> Cout 32, so that two workgroups fit a CU's LDS).  Two
@@ -526,14 +536,7 @@ int launch_conv_stream(ConvArgs a, hipStream_t st) {
         return (int)CY_ERR_LAUNCH;
       attr_done = true;
     }
-    a.stamps = g_p8_stamp_buf;
-    {
-      static const int dbg = [] {
-        const char* e = getenv("CY_P8_DEBUG");
-        return e ? atoi(e) : 0;
-      }();
-      a.full_tiles = dbg;
-    }
+    a.stamps = g_conv_stamp_buf;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::SMEM, st, a);
     return (int)CY_OK;
   };

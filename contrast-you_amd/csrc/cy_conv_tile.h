@@ -21,6 +21,8 @@ struct ConvArgs {
   const float* scale;
   const float* shift;
   const void* w;  // packed [9][w_co_pad][w_ci_pad]
+  const void* wflow;  // stage-contiguous image behind it (cy_conv_flow.h), or null
+  long long bytes_w;  // ... its size in bytes
   void* out;
   void* out2;
   float* stats;  // [tiles][2][Cout] or null
@@ -36,7 +38,7 @@ struct ConvArgs {
   int xcd_remap;   // plane kernel: workgroup b -> tile such that the 8 XCDs own contiguous bands of tiles
   long long bytes1, bytes2;    // sizes of the source tensors in bytes (buffer descriptors of the LDS-DMA kernels), or 0
   long long bytes_o1, bytes_o2, bytes_st;  // ... of the outputs and the statistics partials
-  unsigned long long* stamps;  // development aid (cy_debug_pc_stamps): shader-clock stamps of workgroup 0, or null
+  unsigned long long* stamps;  // development aid (cy_debug_conv_stamps): shader-clock stamps of workgroup 0, or null
 };
 
 // ---- MFMA fragment abstraction: one "k-step" is 16 input channels ----------

@@ -11,7 +11,7 @@ from pathlib import Path
 
 CY_F32, CY_BF16, CY_F16 = 0, 1, 2
 CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2 = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _ERRORS = {-1: "CY_ERR_ARG (bad/NULL argument)", -2: "CY_ERR_SHAPE (unsupported shape)",
            -3: "CY_ERR_DTYPE (unsupported dtype)", -4: "CY_ERR_LAUNCH (HIP launch failed)",
@@ -39,7 +39,7 @@ class PackItem(C.Structure):
     """mirror of cy_pack_item"""
     _fields_ = [("w", c_void_p), ("off_f", C.c_longlong), ("off_d", C.c_longlong), ("first", C.c_longlong),
                 ("Cout", c_int32), ("Cin", c_int32), ("co_pad", c_int32), ("ci_pad", c_int32),
-                ("ci_pad2", c_int32), ("co_pad2", c_int32)]
+                ("ci_pad2", c_int32), ("co_pad2", c_int32), ("off_ff", C.c_longlong), ("off_fd", C.c_longlong)]
 
 
 class ConvPlan(C.Structure):
@@ -62,6 +62,7 @@ _SIGS = {
     "cy_stream_capture_id": (C.c_ulonglong, [_P]),
     "cy_debug_stamp": (c_int, [_P, c_int, _P]),
     "cy_conv3x3_packed_dims": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "cy_conv3x3_packed_elems": (C.c_longlong, [c_int, c_int, c_int]),
     "cy_conv3x3_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "cy_conv3x3_pack_weights_batched": (c_int, [_P, c_int, C.c_longlong, _P, _P, c_int, _P]),
     "cy_conv3x3_num_partials": (c_int, [_PCD]),
@@ -69,14 +70,8 @@ _SIGS = {
     "cy_conv3x3_wgrad_plan": (c_int, [_PCD, c_int, POINTER(WgradPlan)]),
     "cy_conv3x3_fwd_ws_bytes": (c_size_t, [_PCD]),
     "cy_conv3x3_fwd": (c_int, [_PCD, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
-    "cy_conv3x3_pc_packed_elems": (C.c_longlong, [c_int, c_int]),
-    "cy_debug_p8_weights": (c_int, [_P]),
     "cy_debug_wgrad_stamps": (c_int, [_P]),
-    "cy_debug_pc_stamps": (c_int, [_P]),
-    "cy_conv3x3_pc_pack": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
-    "cy_conv3x3_pc_num_partials": (c_int, [_PCD]),
-    "cy_conv3x3_pc_ws_bytes": (c_size_t, [_PCD]),
-    "cy_conv3x3_pc_fwd": (c_int, [_PCD, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "cy_debug_conv_stamps": (c_int, [_P]),
     "cy_conv3x3_wgrad_ws_bytes": (c_size_t, [_PCD]),
     "cy_conv3x3_wgrad": (c_int, [_PCD, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "cy_conv3x3_wgrad_pair_ws_bytes": (c_size_t, [_PCD, c_int]),
@@ -157,7 +152,7 @@ _SIGS = {
 }
 
 # functions whose int return is a count / size, not a status
-_COUNT_FUNCS = {"cy_abi_version", "cy_conv3x3_num_partials", "cy_conv3x3_first_num_partials", "cy_conv3x3_pc_num_partials",
+_COUNT_FUNCS = {"cy_abi_version", "cy_conv3x3_num_partials", "cy_conv3x3_first_num_partials",
                 "cy_bn_bwd_num_partials"}
 
 _lib = None

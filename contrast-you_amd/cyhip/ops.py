@@ -120,19 +120,24 @@ def packed_dims(Cout: int, Cin: int) -> Tuple[int, int]:
     return a.value, b.value
 
 
+def packed_elems(Cout: int, Cin: int, dtype: torch.dtype) -> int:
+    """elements of a packed weight image: [9, co_pad, ci_pad], then (16-bit, Cout % 64 == 0, Cin % 16 == 0) the
+    stage-contiguous image of the LDS-DMA kernel (csrc/cy_conv_flow.h)"""
+    return int(_lib.load().cy_conv3x3_packed_elems(Cout, Cin, dtype_code(dtype)))
+
+
 def pack_weights(w: Tensor, dtype: torch.dtype, want_dgrad: bool = True):
-    """w: [Cout,Cin,3,3] f32 -> (wf [9,co_pad,ci_pad], wd [9,ci_pad',co_pad'] or None) of `dtype`."""
+    """w: [Cout,Cin,3,3] f32 -> (wf, wd or None): flat packed images of `dtype` (forward GEMM / data-gradient
+    GEMM), packed_elems(Cout, Cin) / packed_elems(Cin, Cout) elements."""
     require_gpu(w)
     Cout, Cin = w.shape[0], w.shape[1]
     w = w.detach()
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
-    cop, cip = packed_dims(Cout, Cin)
-    wf = torch.empty((9, cop, cip), dtype=dtype, device=w.device)
+    wf = torch.empty(packed_elems(Cout, Cin, dtype), dtype=dtype, device=w.device)
     wd = None
     if want_dgrad:
-        cip2, cop2 = packed_dims(Cin, Cout)
-        wd = torch.empty((9, cip2, cop2), dtype=dtype, device=w.device)
+        wd = torch.empty(packed_elems(Cin, Cout, dtype), dtype=dtype, device=w.device)
     _lib.call("cy_conv3x3_pack_weights", w.data_ptr(), wf.data_ptr(), _ptr(wd), Cout, Cin,
               dtype_code(dtype), _stream())
     return wf, wd
@@ -143,17 +148,20 @@ class _PackSet:
 
     def __init__(self, weights, dtype):
         items = (_lib.PackItem * len(weights))()
-        self.views = []  # per weight: (offset, shape) of the forward and of the dgrad image
+        self.views = []  # per weight: (offset, elements) of the forward and of the dgrad image
         off_f = off_d = first = 0
         for it, w in zip(items, weights):
             Cout, Cin = w.shape[0], w.shape[1]
             cop, cip = packed_dims(Cout, Cin)
             cip2, cop2 = packed_dims(Cin, Cout)
+            nf, nd = packed_elems(Cout, Cin, dtype), packed_elems(Cin, Cout, dtype)
             it.w, it.off_f, it.off_d, it.first = w.data_ptr(), off_f, off_d, first
             it.Cout, it.Cin, it.co_pad, it.ci_pad, it.ci_pad2, it.co_pad2 = Cout, Cin, cop, cip, cip2, cop2
-            self.views.append(((off_f, (9, cop, cip)), (off_d, (9, cip2, cop2))))
-            off_f += 9 * cop * cip
-            off_d += 9 * cip2 * cop2
+            it.off_ff = off_f + 9 * cop * cip if nf > 9 * cop * cip else -1
+            it.off_fd = off_d + 9 * cip2 * cop2 if nd > 9 * cip2 * cop2 else -1
+            self.views.append(((off_f, nf), (off_d, nd)))
+            off_f += nf
+            off_d += nd
             first += -(-max(cop, cop2) // 32) * -(-max(cip, cip2) // 32)  # 32 x 32 (co, ci) tiles
         self.n, self.size_f, self.size_d, self.total = len(weights), off_f, off_d, first
         raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
@@ -185,9 +193,8 @@ def pack_weights_batched(weights, dtype: torch.dtype):
     _lib.call("cy_conv3x3_pack_weights_batched", ps.table.data_ptr(), ps.n, ps.total, af.data_ptr(),
               ad.data_ptr(), dtype_code(dtype), _stream())
     out = []
-    for (of, shf), (od, shd) in ps.views:
-        nf, nd = shf[0] * shf[1] * shf[2], shd[0] * shd[1] * shd[2]
-        out.append((af[of:of + nf].view(shf), ad[od:od + nd].view(shd)))
+    for (of, nf), (od, nd) in ps.views:
+        out.append((af[of:of + nf], ad[od:od + nd]))
     return out
 
 
@@ -217,7 +224,7 @@ def _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, ld1, ld2, ldo, split_c=0, l
     return p
 
 
-KERNEL_NAMES = {0: "conv3x3_igemm_kernel", 1: "conv3x3_plane_kernel", 2: "conv3x3_pc_kernel", 3: "conv3x3_plane8_kernel", 4: "conv3x3_stream_kernel"}
+KERNEL_NAMES = {0: "conv3x3_igemm_kernel", 1: "conv3x3_plane_kernel", 4: "conv3x3_stream_kernel", 5: "conv3x3_flow_kernel"}
 
 
 def conv3x3_plan(N, H, W, C1, C2, Cout, dtype: torch.dtype, mode: int = 0, prologue: bool = False) -> dict:
@@ -283,58 +290,6 @@ def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, 
     _lib.call("cy_conv3x3_fwd", d.ref, src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
               wf.data_ptr(), out.data_ptr(), _ptr(out2), _ptr(stats), _ptr(ws), nbytes, _stream())
     if ev is not None:  # algorithmic bytes: every input and output element once, packed weights once
-        esz = src1.element_size()
-        nb = esz * (src1.numel() + (0 if src2 is None else src2.numel()) + N * H * W * Cout + 9 * (C1 + C2) * Cout)
-        _prof_end(ev, "conv3x3_igemm", 2.0 * N * H * W * 9 * (C1 + C2) * Cout, float(nb))
-    if split:
-        return (out, out2), None
-    return out, stats
-
-
-def pack_weights_pc(w: Tensor, dtype: torch.dtype, want_dgrad: bool = True):
-    """w [Cout,Cin,3,3] f32 -> (forward image, data-gradient image or None) in the stage-contiguous layout of
-    the persistent producer / consumer kernel (cy_conv3x3_pc_fwd)"""
-    require_gpu(w)
-    Cout, Cin = w.shape[0], w.shape[1]
-    w = w.detach()
-    if w.dtype != torch.float32 or not w.is_contiguous():
-        w = w.float().contiguous()
-    lib = _lib.load()
-    wf = torch.empty(lib.cy_conv3x3_pc_packed_elems(Cout, Cin), dtype=dtype, device=w.device)
-    wd = torch.empty(lib.cy_conv3x3_pc_packed_elems(Cin, Cout), dtype=dtype, device=w.device) if want_dgrad else None
-    _lib.call("cy_conv3x3_pc_pack", w.data_ptr(), wf.data_ptr(), _ptr(wd), Cout, Cin, dtype_code(dtype), _stream())
-    return wf, wd
-
-
-def conv3x3_pc_fwd(src1: Tensor, src2: Optional[Tensor], wpc: Tensor, Cout: int, *, mode: int = 0,
-                   scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
-                   want_stats: bool = True, split: Optional[int] = None):
-    """conv3x3_fwd on the persistent producer / consumer kernel (same contract; `wpc` from pack_weights_pc)"""
-    require_gpu(src1, wpc)
-    N, C1 = src1.shape[0], src1.shape[1]
-    C2 = 0 if src2 is None else src2.shape[1]
-    H, W = _out_hw(src1, mode)
-    dt = dtype_code(src1.dtype)
-    dev = src1.device
-    prologue = 1 if scale is not None else 0
-    if split:
-        out = empty_nhwc(N, split, H, W, src1.dtype, dev)
-        out2 = empty_nhwc(N, Cout - split, H, W, src1.dtype, dev)
-        d = _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, C1, C2, split, split, Cout - split)
-    else:
-        out = empty_nhwc(N, Cout, H, W, src1.dtype, dev)
-        out2 = None
-        d = _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, C1, C2, Cout)
-    stats = None
-    if want_stats:
-        npart = _lib.call("cy_conv3x3_pc_num_partials", d.ref)
-        stats = _f32(npart * 2 * Cout, dev).view(npart, 2, Cout)
-    nbytes = _lib.load().cy_conv3x3_pc_ws_bytes(d.ref)
-    ws = _ws(nbytes, dev) if nbytes else None
-    ev = _prof_begin()
-    _lib.call("cy_conv3x3_pc_fwd", d.ref, src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
-              wpc.data_ptr(), out.data_ptr(), _ptr(out2), _ptr(stats), _ptr(ws), nbytes, _stream())
-    if ev is not None:
         esz = src1.element_size()
         nb = esz * (src1.numel() + (0 if src2 is None else src2.numel()) + N * H * W * Cout + 9 * (C1 + C2) * Cout)
         _prof_end(ev, "conv3x3_igemm", 2.0 * N * H * W * 9 * (C1 + C2) * Cout, float(nb))

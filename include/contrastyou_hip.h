@@ -85,9 +85,15 @@ typedef struct cy_conv_desc {
 /* Packed weight geometry for a (Cout,Cin) 3x3 kernel: [9][co_pad][ci_pad]. */
 int cy_conv3x3_packed_dims(int Cout, int Cin, int* co_pad, int* ci_pad);
 
+/* Elements of the packed image of a (Cout, Cin) kernel in `dtype`: the [9][co_pad][ci_pad] image, followed for
+ * 16-bit dtypes with Cout % 64 == 0 and Cin % 16 == 0 by the stage-contiguous image of the LDS-DMA kernel
+ * (csrc/cy_conv_flow.h): [Cout/64][Cin/16][tap][2][64 couts][8 channels] = 9*Cout*Cin elements. */
+long long cy_conv3x3_packed_elems(int Cout, int Cin, int dtype);
+
 /* Repack reference-layout weights w[Cout][Cin][3][3] (f32) into the forward
- * image wf[tap][co_pad][ci_pad] and (if wd != NULL) the data-gradient image
- * wd[tap][ci_pad'][co_pad'] = w[co][ci][2-kh][2-kw], both of `dtype`. */
+ * image wf (cy_conv3x3_packed_elems(Cout, Cin, dtype) elements: [tap][co_pad][ci_pad], then the stage-contiguous
+ * image) and (if wd != NULL) the data-gradient image wd (cy_conv3x3_packed_elems(Cin, Cout, dtype) elements:
+ * wd[tap][ci_pad'][co_pad'] = w[co][ci][2-kh][2-kw], then its stage-contiguous image), both of `dtype`. */
 int cy_conv3x3_pack_weights(const float* w, void* wf, void* wd, int Cout, int Cin, int dtype,
                             void* stream);
 
@@ -105,6 +111,7 @@ typedef struct cy_pack_item {
   int Cout, Cin;
   int co_pad, ci_pad;      /* forward image  [9][co_pad][ci_pad]   (cy_conv3x3_packed_dims(Cout, Cin)) */
   int ci_pad2, co_pad2;    /* dgrad image    [9][ci_pad2][co_pad2] (cy_conv3x3_packed_dims(Cin, Cout)) */
+  long long off_ff, off_fd; /* element offsets of the stage-contiguous images in the same arenas, or -1 (none) */
 } cy_pack_item;
 int cy_conv3x3_pack_weights_batched(const cy_pack_item* items, int n_items, long long total,
                                     void* wf_arena, void* wd_arena, int dtype, void* stream);
@@ -117,7 +124,7 @@ int cy_conv3x3_num_partials(const cy_conv_desc* d);
  * Parity tests assert on it, so that every instantiation that appears in profiles/ is known to be
  * covered by a test that provably took it (the plan depends on N, H, W, channel counts and dtype). */
 typedef struct cy_conv_plan {
-  int32_t kernel;     /* 0: conv3x3_igemm_kernel, 1: conv3x3_plane_kernel, 2: conv3x3_pc_kernel */
+  int32_t kernel;     /* 0: conv3x3_igemm_kernel, 1: conv3x3_plane_kernel, 4: conv3x3_stream_kernel, 5: conv3x3_flow_kernel */
   int32_t th, tw, bn; /* output tile (rows x columns) and output channels per workgroup */
   int32_t ksplit;     /* >1: split-K over input-channel chunks + conv_splitk_finish_kernel */
   int32_t one_per_cu; /* plane kernel, 128 couts: the one-workgroup-per-CU build with halo prefetch */
@@ -134,28 +141,12 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
                    const float* shift, const void* w_packed, void* out, void* out2, float* stats,
                    void* ws, size_t ws_bytes, void* stream);
 
-/* The same convolution on the persistent producer / consumer kernel (csrc/cy_conv_pc.h; bf16, widths that
- * are multiples of 14): one 512-thread workgroup per CU walks a list of (tile, cout block, K split) units,
- * four loader waves keep a double-buffered LDS ring full (weights by LDS-DMA), four MFMA waves compute.
- * It reads its own stage-contiguous weight image: cy_conv3x3_pc_packed_elems(Cout, Cin) elements for the
- * forward GEMM, cy_conv3x3_pc_packed_elems(Cin, Cout) for the data-gradient GEMM (wpc_d may be NULL).
- * Statistic partials: cy_conv3x3_pc_num_partials(d) rows (one per workgroup and wave row). */
-long long cy_conv3x3_pc_packed_elems(int Cout, int Cin);
-/* development aid: workgroup 0 of every following cy_conv3x3_pc_fwd launch records shader-clock stamps of
- * its 8 waves into dev_buf[8][128] (DEVICE memory; NULL switches it off again). */
-int cy_debug_pc_stamps(unsigned long long* dev_buf);
-/* development aid: route the eight-wave plane kernel's weights through LDS-DMA from this cy_conv3x3_pc_pack
- * image (NULL: packed image of cy_conv3x3_pack_weights as usual). */
-int cy_debug_p8_weights(const void* pc_image);
+/* development aid: workgroup 0 of every following streaming-kernel launch (library built with -DCY_STREAM_STAMPS)
+ * records shader-clock stamps of its waves into dev_buf[8][128] (DEVICE memory; NULL switches it off again). */
+int cy_debug_conv_stamps(unsigned long long* dev_buf);
 /* development aid: per-wave phase totals (shader clocks) of the twelve-wave weight-gradient kernel's tile loop
  * (library built with -DCY_WGRAD_STAMPS), [12 waves][8] = {request, mfma loop, commit, barrier, tiles}. */
 int cy_debug_wgrad_stamps(unsigned long long* dev_buf);
-int cy_conv3x3_pc_pack(const float* w, void* wpc_f, void* wpc_d, int Cout, int Cin, int dtype, void* stream);
-int cy_conv3x3_pc_num_partials(const cy_conv_desc* d);
-size_t cy_conv3x3_pc_ws_bytes(const cy_conv_desc* d);
-int cy_conv3x3_pc_fwd(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
-                      const float* shift, const void* w_pc, void* out, void* out2, float* stats, void* ws,
-                      size_t ws_bytes, void* stream);
 
 /* Weight gradient dw[Cout][Cin][3][3] (f32, reference layout) =
  *   sum_p dy[p][co] * in[p+tap][ci]  with `in` addressed exactly as in

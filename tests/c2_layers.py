@@ -37,12 +37,11 @@ def conv_kernel_name(plan: dict, dtype_tag: str = "DF16b", cin: int = 0, stats: 
         wgm, wgn, pitch, allt = (2, 2, 128, 0) if plan["bn"] == 128 else (4, 1, 64, 1)
         return ("conv3x3_plane_kernelI" + dtype_tag + i(plan["th"]) + i(plan["bn"]) + i(wgm) + i(wgn) + i(pitch)
                 + b(allt) + b(plan["one_per_cu"]) + "E")
-    if plan["kernel"] == "conv3x3_plane8_kernel":
-        return "conv3x3_plane8_kernelI" + dtype_tag + "E"
+    if plan["kernel"] == "conv3x3_flow_kernel":
+        wgm, wgn = (4, 2) if plan["bn"] == 128 else (8, 1)
+        return ("conv3x3_flow_kernelI" + dtype_tag + i(plan["th"]) + i(plan["bn"]) + i(wgm) + i(wgn) + b(plan["tw"] == 16) + "E")
     if plan["kernel"] == "conv3x3_stream_kernel":
         return ("conv3x3_stream_kernelI" + dtype_tag + i(cin // 32) + i(plan["bn"] // 32) + b(stats) + b(pro) + "E")
-    if plan["kernel"] == "conv3x3_pc_kernel":
-        return "conv3x3_pc_kernelI" + dtype_tag + i(plan["bn"])
     wgm, wgn = ((1, 4) if (plan["th"], plan["tw"]) in ((8, 28), (16, 14)) else (2, 2)) if plan["bn"] == 128 else (4, 1)
     pitch, allt = (128, 0) if plan["bn"] == 128 else (64, 1)
     return ("conv3x3_igemm_kernelI" + dtype_tag + "S0_" + i(plan["th"]) + i(plan["tw"]) + i(plan["bn"]) + i(wgm)
@@ -62,7 +61,7 @@ def profiled_conv_kernels(path: Path):
     names = set()
     for line in path.read_text().splitlines():
         tok = line.split("  ")[0].strip()
-        m = re.search(r"(conv3x3_(?:plane8|plane|igemm|pc|stream)_kernelI\w+?)Ev", tok)
+        m = re.search(r"(conv3x3_(?:plane|igemm|stream|flow)_kernelI\w+?)Ev", tok)
         if m:
             names.add(m.group(1))
         if "wgrad12s_kernel" in tok:

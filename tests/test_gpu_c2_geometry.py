@@ -105,7 +105,7 @@ C2_LAYERS = cl.unet_layers(224, 512)
 @pytest.mark.parametrize("N", [16, 32])
 @pytest.mark.parametrize("layer", C2_LAYERS, ids=[l[0] for l in C2_LAYERS])
 def test_c2_layer_bf16(layer, N):
-    plan, dplan = _run_layer(N, layer, BF, seed=1000 + N, expect_kernel=("conv3x3_plane_kernel", "conv3x3_plane8_kernel", "conv3x3_stream_kernel"))
+    plan, dplan = _run_layer(N, layer, BF, seed=1000 + N, expect_kernel=("conv3x3_plane_kernel", "conv3x3_flow_kernel", "conv3x3_stream_kernel"))
     # the claims of VERDICT r01 / ADVICE r01: these geometries reach split-K above 1, 512-channel operands and
     # (where the plane kernel is planned) the one-workgroup-per-CU build
     name = layer[0]
@@ -168,7 +168,7 @@ C4_LAYERS = cl.unet_layers(256, 512)
 @pytest.mark.parametrize("layer", C4_LAYERS, ids=[l[0] for l in C4_LAYERS])
 def test_c4_layer_bf16_igemm_path(layer):
     """BASELINE config 4 geometry: 256 x 256 inputs (widths 256..16: the igemm kernel), 4 images"""
-    _run_layer(4, layer, BF, seed=4000, expect_kernel=("conv3x3_igemm_kernel",))
+    _run_layer(4, layer, BF, seed=4000, expect_kernel=("conv3x3_igemm_kernel", "conv3x3_flow_kernel"))
 
 
 def test_full_size_c2_step_f32_matches_oracle():
@@ -180,36 +180,3 @@ def test_full_size_c2_step_f32_matches_oracle():
     assert r["rel_sup"] < 1e-4 and r["rel_reg"] < 1e-4 and r["rel_total"] < 1e-4, r
     assert r["rel_logits"] < 1e-4 and r["rel_logits_tf"] < 1e-4, r
     assert r["rel_running_mean"] < 1e-4, r
-
-
-PC_LAYERS = [l for l in C2_LAYERS if l[0] in ("Conv1b", "Conv2a", "Conv3b", "Conv5b", "Up_conv5a", "Up4", "Up3", "Up2")]
-
-
-@pytest.mark.parametrize("layer", PC_LAYERS, ids=lambda l: l[0])
-def test_pc_kernel_c2_layer_bf16(layer):
-    """the experimental persistent producer / consumer kernel (csrc/cy_conv_pc.h, cy_conv3x3_pc_fwd; not
-    on the default path): forward + statistics, data gradient and the split (concat) epilogue on C2 layers
-    that cover its three cout variants, resident and streamed weights, split-K, pool / upsample / concat /
-    prologue loads"""
-    from cyhip import ops
-    N = 16
-    name, H, C1, C2, Cout, mode, pro = layer
-    x1, x2, w, dy, scale, shift = _case(N, layer, BF, 901)
-    ref = F.conv2d(_conv_input(x1, x2, mode, scale, shift, BF), w, None, 1, 1)
-    kw = dict(mode=mode, scale=None if scale is None else scale.to(DEV), shift=None if shift is None else shift.to(DEV))
-    pf, pd = ops.pack_weights_pc(w.to(DEV), BF)
-    g1, g2 = nhwc(x1, BF), None if x2 is None else nhwc(x2, BF)
-    out, stats = ops.conv3x3_pc_fwd(g1, g2, pf, Cout, **kw)
-    assert_close(out, ref, 1.2e-2, f"pc {name} fwd")
-    o = cpu(out).double()
-    s = cpu(stats).double().sum(0)
-    cnt = N * H * H
-    assert_close(s[0] / cnt, o.sum(dim=(0, 2, 3)) / cnt, 1e-4, f"pc {name} stat sum")
-    assert_close(s[1] / cnt, (o * o).sum(dim=(0, 2, 3)) / cnt, 1e-4, f"pc {name} stat sumsq")
-    rd = F.conv_transpose2d(dy, w, None, 1, 1)
-    din, _ = ops.conv3x3_pc_fwd(nhwc(dy, BF), None, pd, C1 + C2, want_stats=False)
-    assert_close(din, rd, 1.2e-2, f"pc {name} dgrad")
-    if C2:
-        (d1, d2), _ = ops.conv3x3_pc_fwd(nhwc(dy, BF), None, pd, C1 + C2, want_stats=False, split=C1)
-        assert_close(d1, rd[:, :C1], 1.2e-2, f"pc {name} dgrad split 1")
-        assert_close(d2, rd[:, C1:], 1.2e-2, f"pc {name} dgrad split 2")

@@ -66,23 +66,17 @@ def main():
         shift = torch.rand(C1, device=dev) - 0.5 if pro else None
         dy = ops.empty_nhwc(N, Cout, H, H, dt, dev).normal_()
         flops = 2.0 * N * H * H * 9 * (C1 + C2) * Cout
-        p8dma = os.environ.get("CY_P8_DMA", "0") != "0"  # development aid: eight-wave plane kernel, weights by LDS-DMA
-        if p8dma:
-            from cyhip import _lib
-            pf, pd = ops.pack_weights_pc(w, dt)
-            _lib.call("cy_debug_p8_weights", pf.data_ptr() if Cout >= 128 and (C1 + C2) % 32 == 0 else 0)
         t_f = timeit(lambda: ops.conv3x3_fwd(x1, x2, wf, Cout, mode=mode, scale=scale, shift=shift), a.iters, 1)
-        if p8dma:
-            _lib.call("cy_debug_p8_weights", pd.data_ptr() if C1 + C2 >= 128 and Cout % 32 == 0 else 0)
         t_d = timeit(lambda: ops.conv3x3_fwd(dy, None, wd, C1 + C2, want_stats=False), a.iters, 1)
-        if p8dma:
-            _lib.call("cy_debug_p8_weights", 0)
         t_w = timeit(lambda: ops.conv3x3_wgrad(x1, x2, dy, mode=mode, scale=scale, shift=shift), a.iters, 1)
         tot["fwd"] += t_f
         tot["dgrad"] += t_d
         tot["wgrad"] += t_w
         totf += flops
-        print(f"{name:12s} {H:5d} {C1+C2:5d} {Cout:5d} | {t_f:8.3f} {flops/t_f/1e9:7.1f} | {t_d:8.3f} {flops/t_d/1e9:7.1f} | {t_w:8.3f} {flops/t_w/1e9:7.1f}")
+        pf_ = ops.conv3x3_plan(N, H, H, C1, C2, Cout, dt, mode, bool(pro))
+        pd_ = ops.conv3x3_plan(N, H, H, Cout, 0, C1 + C2, dt, 0, False)
+        tag = lambda q: f"{q['kernel'][8:-7]}:{q['th']}x{q['bn']}z{q['ksplit']}w{q['workgroups']}"  # noqa: E731
+        print(f"{name:12s} {H:5d} {C1+C2:5d} {Cout:5d} | {t_f:8.3f} {flops/t_f/1e9:7.1f} | {t_d:8.3f} {flops/t_d/1e9:7.1f} | {t_w:8.3f} {flops/t_w/1e9:7.1f} | {tag(pf_)} {tag(pd_)}")
     for k, v in tot.items():
         print(f"total {k}: {v:.3f} ms  {totf/v/1e9:.1f} TFLOP/s")
     print(f"sum: {sum(tot.values()):.3f} ms for N={a.n}")

@@ -29,7 +29,7 @@ gdy = nhwc(dy, BF)
 print(ops.conv3x3_plan(N, H, H, C1, C2, Cout, BF, mode, bool(pro)) if which == "fwd"
       else ops.conv3x3_plan(N, H, H, Cout, 0, C1 + C2, BF, 0, False))
 stamps = torch.zeros(12 * 128, dtype=torch.int64, device="cuda")
-_lib.call("cy_debug_pc_stamps", stamps.data_ptr())
+_lib.call("cy_debug_conv_stamps", stamps.data_ptr())
 for _ in range(3):
     if which == "fwd":
         ops.conv3x3_fwd(g1, g2, wf, Cout, **kw)
