@@ -169,12 +169,14 @@ class SelfPacedSupConLoss(nn.Module):
         if mask is not None:
             assert mask.shape == torch.Size([n, n])
             pos = (mask == 1).float().to(dev)
+            neg = (mask == 0).float().to(dev)  # (contrastive.py:120-121: other values, e.g. -1, are neither)
         elif target is not None:
             t = _encode_target(target, n, dev)
             pos = torch.eq(t[:, None], t[None, :]).float()
+            neg = 1 - pos
         else:
             pos = torch.eye(n, dtype=torch.float, device=dev)
-        neg = 1 - pos
+            neg = 1 - pos
         R = 2 * n
         off_diag = 1 - torch.eye(R, dtype=torch.float, device=dev)
         pos_mask, neg_mask = pos.repeat(2, 2) * off_diag, neg.repeat(2, 2) * off_diag

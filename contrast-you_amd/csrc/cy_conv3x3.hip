@@ -585,12 +585,17 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool 
         const int blocks_small = cy_cdiv((long)N * H, th) * (W / fc.tw) * (Cout / bn);
         if (blocks_small >= 192) {
           use = blocks_small <= 256 || (nccf >= 8 && fills(blocks_small) >= 0.85);
-        } else if (Cout >= 256) {  // split-K over >= 4 chunks each (f32 partial slabs: only where many cout blocks share them)
-          Z = (232 + blocks_small / 2) / blocks_small;
-          if (Z > nccf / 4) Z = nccf / 4;
-          if (Z > 8) Z = 8;
-          use = Z >= 1 && blocks_small * Z >= 160;
-          if (Z < 1) Z = 1;
+        } else {
+          // too few tiles for the chip: split-K over >= 4 chunks each only where the f32 partial slabs are shared
+          // by many cout blocks and the K loop is long (28x28 at N=16, 256 -> 256: 112 workgroups without a
+          // split take 33 us, 224 with one 36); otherwise the tiles there are run as they are
+          if (Cout >= 256 && (blocks_small < 96 || nccf >= 32)) {
+            Z = (232 + blocks_small / 2) / blocks_small;
+            if (Z > nccf / 4) Z = nccf / 4;
+            if (Z > 8) Z = 8;
+            if (Z < 1) Z = 1;
+          }
+          use = blocks_small * Z >= 48;
         }
       }
     }

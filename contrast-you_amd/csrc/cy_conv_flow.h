@@ -22,7 +22,7 @@
 //     the lanes of a 32-position block permuted so that each of ds_read_b128's 16-lane groups reads one halo row
 //     (256 contiguous bytes: conflict-free on any pitch); the epilogue stores per lane, so the permutation is free.
 #pragma once
-#include "cy_conv_plane.h"
+#include "cy_conv_stream.h"  // (g_conv_stamp_buf)
 
 namespace {
 
@@ -65,6 +65,19 @@ inline long flow_image_elems(int Cout, int Cin) {
   return 9L * Cout * Cin;
 }
 
+// development aid (-DCY_FLOW_STAMPS, tools/flow_stamps.py): every workgroup records {wall clock (100 MHz) at
+// start, shader clock at start / tables ready / first chunk landed / loop end / epilogue issued, wall clock at
+// end, XCC id} into a.stamps[workgroup][8]
+#ifdef CY_FLOW_STAMPS
+#define FLOW_STAMP(K, V)                                                                    \
+  do {                                                                                      \
+    if (a.stamps != nullptr && tid == 0)                                                    \
+      a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (K)] = (V); \
+  } while (0)
+#else
+#define FLOW_STAMP(K, V) do { } while (0)
+#endif
+
 template <typename T, int TH, int BN, int WGM, int WGN, bool W16>
 __global__ void __launch_bounds__(64 * WGM * WGN, 2)
     conv3x3_flow_kernel(const ConvArgs a) {
@@ -87,6 +100,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
   const int r = lane & 31, h = lane >> 5;
+  FLOW_STAMP(0, __builtin_amdgcn_s_memrealtime());
+  FLOW_STAMP(1, __builtin_amdgcn_s_memtime());
   // position of lane r inside a 32-position block: (row 0 / 1, column 0..15)
   int prow, pcol;
   if constexpr (W16) {
@@ -151,6 +166,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
   }
   conv_row_tables(a, TH, R0, tid, s_row1, s_row2, s_flag, false);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the DMA stays in flight)
+  FLOW_STAMP(2, __builtin_amdgcn_s_memtime());
 
   // ---- halo: item i of this wave = position group g = (wave >> 1) + (NW / 2) i of plane (wave & 1) ----------
   const int apl = wave & 1;
@@ -251,47 +267,78 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 
-  int st_cur = 0, st_nxt = C::STAGE;
-  for (int cc = cc0; cc < cc1; ++cc) {
-    // (1) this wave's part of chunk cc has landed
+  // ---- main loop ------------------------------------------------------------------------------------------------
+  // Per chunk: nine taps of M_REP x N_REP MFMAs; the fragments of tap t+1 are requested before the MFMAs of tap t
+  // (two register sets).  The pipeline runs ACROSS the chunk boundary: the fragments of a chunk's last tap are in
+  // registers when the wave reaches the barrier, and behind the barrier it first requests tap 0 of the next chunk
+  // and then issues the last tap's MFMAs -- the matrix pipe has work while the first fragments of the new stage
+  // are on their way (stamps: 820 of 5430 cycles per chunk were boundary, barrier + exposed fragment latency).
+  // Nine taps per chunk flip the parity of the register sets, so the loop body is two chunks (static set names).
+  typename M::Frag fa[2][M_REP], fb[2][N_REP];
+  auto load_tap = [&](int st, auto SET, auto TAP) {
+    constexpr int set = decltype(SET)::value, t = decltype(TAP)::value;
+    constexpr int d = t / 3, dw = t % 3 - 1;
+    const unsigned char* sb = smem + st;
+#pragma unroll
+    for (int n = 0; n < N_REP; ++n) fb[set][n] = frag(sb + bbase[n] + t * 2 * BPLB);
+#pragma unroll
+    for (int m = 0; m < M_REP; ++m) fa[set][m] = frag(sb + aaddr(m, d) + (dw + 1) * 16);
+  };
+  auto mma_set = [&](auto SET) {
+    constexpr int set = decltype(SET)::value;
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+      for (int n = 0; n < N_REP; ++n) M::mma(fb[set][n], fa[set][m], acc[m][n]);  // rows = couts
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // the wave's part of chunk cc has landed (and is transformed); every wave's has; the other stage is free
+  auto open_chunk = [&](int cc, int st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (a.prologue) a_transform(cc, st_cur);
-    // (2) every wave's part has, and every wave is done reading the other stage
+    if (a.prologue) a_transform(cc, st);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  int st_cur = 0, st_nxt = C::STAGE;
+  open_chunk(cc0, st_cur);
+  FLOW_STAMP(3, __builtin_amdgcn_s_memtime());
+  load_tap(st_cur, TapC<0>{}, TapC<0>{});
+  // one chunk whose tap t sits in register set (t + P) & 1; entered with tap 0 requested
+  auto chunk = [&](int cc, auto PAR) {
+    constexpr int P = decltype(PAR)::value;
     const bool more = cc + 1 < cc1;
-    // (3) nine taps; the DMA of chunk cc + 1 is issued behind the MFMAs of taps 0.. (one halo item and one
-    //     weight piece per tap and wave)
-    typename M::Frag fa[2][M_REP], fb[2][N_REP];
-    const unsigned char* sb = smem + st_cur;
-    auto load_tap = [&](int set, auto TAP) {
+    plane_static_for<0, 8>([&](auto TAP) {
       constexpr int t = decltype(TAP)::value;
-      constexpr int d = t / 3, dw = t % 3 - 1;
-#pragma unroll
-      for (int n = 0; n < N_REP; ++n) fb[set][n] = frag(sb + bbase[n] + t * 2 * BPLB);
-#pragma unroll
-      for (int m = 0; m < M_REP; ++m) fa[set][m] = frag(sb + aaddr(m, d) + (dw + 1) * 16);
-    };
-    load_tap(0, TapC<0>{});
-    plane_static_for<0, 9>([&](auto TAP) {
-      constexpr int t = decltype(TAP)::value;
-      if constexpr (t + 1 < 9) load_tap((t + 1) & 1, TapC<(t + 1 < 9 ? t + 1 : 0)>{});
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int m = 0; m < M_REP; ++m)
-#pragma unroll
-        for (int n = 0; n < N_REP; ++n) M::mma(fb[t & 1][n], fa[t & 1][m], acc[m][n]);  // rows = couts
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
+      load_tap(st_cur, TapC<(t + 1 + P) & 1>{}, TapC<t + 1>{});
+      mma_set(TapC<(t + P) & 1>{});
+      // the DMA of chunk cc + 1 behind the MFMAs of taps 0..: one halo item and one weight piece per tap and wave
       if (more) {
         if constexpr (t < NBI) b_dma(cc + 1, TapC<(t < NBI ? t : 0)>{}, st_nxt);
         if constexpr (t < NAI) a_dma(cc + 1, TapC<(t < NAI ? t : 0)>{}, st_nxt);
       }
     });
-    const int s = st_cur;
+    if (more) {
+      if constexpr (8 < NBI) b_dma(cc + 1, TapC<(8 < NBI ? 8 : 0)>{}, st_nxt);
+      if constexpr (8 < NAI) a_dma(cc + 1, TapC<(8 < NAI ? 8 : 0)>{}, st_nxt);
+      open_chunk(cc + 1, st_nxt);  // (the last tap's fragments are in registers: lgkmcnt(0) in front of the barrier)
+      load_tap(st_nxt, TapC<(9 + P) & 1>{}, TapC<0>{});
+    }
+    mma_set(TapC<(8 + P) & 1>{});
+    const int sw = st_cur;
     st_cur = st_nxt;
-    st_nxt = s;
+    st_nxt = sw;
+  };
+  {
+    int cc = cc0;
+    for (; cc + 1 < cc1; cc += 2) {
+      chunk(cc, TapC<0>{});
+      chunk(cc + 1, TapC<1>{});
+    }
+    if (cc < cc1) chunk(cc, TapC<0>{});
   }
+  FLOW_STAMP(4, __builtin_amdgcn_s_memtime());
   __syncthreads();  // the statistics scratch aliases the operand buffers
 
   // ---------------- epilogue (as conv3x3_plane_kernel): accumulators -> NHWC from registers ----------------
@@ -322,17 +369,33 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
                                                         acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
         }
     }
+    FLOW_STAMP(5, __builtin_amdgcn_s_memtime());
+    FLOW_STAMP(6, __builtin_amdgcn_s_memrealtime());
     return;
   }
   float* sstat = reinterpret_cast<float*>(smem);
   const bool do_stats = a.stats != nullptr;
   T* o1 = reinterpret_cast<T*>(a.out);
   T* o2 = reinterpret_cast<T*>(a.out2);
+  // Statistics of the ROUNDED outputs.  A lane's column is fixed, so when every row of the tile is inside the
+  // grid (all but the last row tile) the per-element validity select is ONE select per sum at the end, and the
+  // sums run as packed f32 pairs straight off the packed 16-bit store payload (stamps: the statistics were
+  // 11 of the epilogue's 17 thousand cycles -- eight waves of pure VALU work with nothing to overlap).
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const bool rows_full = R0 + TH <= a.NH;  // wave-uniform
+  bool col_ok;
+  {
+    int R, w;
+    (void)position(0, R, w);
+    col_ok = C::W16 ? (w < a.W) : (pcol >= 1 && pcol <= TW && w < a.W);
+  }
+  auto epilogue = [&](auto STATS_, auto MASKED_) {
+    constexpr bool STATS = decltype(STATS_)::value != 0, MASKED = decltype(MASKED_)::value != 0;
 #pragma unroll
   for (int n = 0; n < N_REP; ++n) {
-    float s1v[16], s2v[16];
+    f32x2 p1[8], p2[8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s1v[i] = s2v[i] = 0.f;
+    for (int i = 0; i < 8; ++i) p1[i] = p2[i] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < M_REP; ++m) {
       int R, w;
@@ -343,15 +406,24 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
       for (int g = 0; g < 4; ++g) {
         T pk[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          pk[j] = from_f32<T>(acc[m][n][4 * g + j]);
-          if (do_stats && ok) {
-            const float qv = to_f32<T>(pk[j]);
-            s1v[4 * g + j] += qv;
-            s2v[4 * g + j] += qv * qv;
+        for (int j = 0; j < 4; ++j) pk[j] = from_f32<T>(acc[m][n][4 * g + j]);
+        packed[g] = __builtin_bit_cast(u32x2, *reinterpret_cast<const s16x4*>(pk));
+        if constexpr (STATS) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            f32x2 q;
+            if constexpr (sizeof(T) == 2 && ElemTr<T>::EPC == 8 && __is_same(T, bf16)) {
+              q = f32x2{__uint_as_float(packed[g][k] << 16), __uint_as_float(packed[g][k] & 0xffff0000u)};
+            } else {
+              q = f32x2{to_f32<T>(pk[2 * k]), to_f32<T>(pk[2 * k + 1])};
+            }
+            if constexpr (MASKED) {
+              if (!ok) q = f32x2{0.f, 0.f};
+            }
+            p1[2 * g + k] += q;
+            p2[2 * g + k] += q * q;
           }
         }
-        packed[g] = __builtin_bit_cast(u32x2, *reinterpret_cast<const s16x4*>(pk));
       }
 #pragma unroll
       for (int g = 0; g < 4; g += 2) {  // half-wave swaps pair the 8-byte channel runs into 16-byte stores
@@ -369,8 +441,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
           *reinterpret_cast<u32x4*>(dst) = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
       }
+      __builtin_amdgcn_sched_barrier(0);  // (one fragment at a time: hoisted conversions would not fit the registers)
     }
-    if (do_stats) {  // reduce-scatter over the 32 lanes of each half (see conv3x3_plane_kernel)
+    float s1v[16], s2v[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool keep = col_ok || MASKED;  // (the slow path has masked per element)
+      s1v[2 * i] = keep ? p1[i][0] : 0.f;
+      s1v[2 * i + 1] = keep ? p1[i][1] : 0.f;
+      s2v[2 * i] = keep ? p2[i][0] : 0.f;
+      s2v[2 * i + 1] = keep ? p2[i][1] : 0.f;
+    }
+    if constexpr (STATS) {  // reduce-scatter over the 32 lanes of each half (see conv3x3_plane_kernel)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const bool up = (lane & 16) != 0;
@@ -412,6 +494,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
       }
     }
   }
+  };
+  // (compile-time variants: a run-time `do_stats` inside the unrolled loops turns every sum into a phi web)
+  if (!do_stats) epilogue(TapC<0>{}, TapC<0>{});
+  else if (rows_full) epilogue(TapC<1>{}, TapC<0>{});
+  else epilogue(TapC<1>{}, TapC<1>{});
   if (do_stats) {
     __syncthreads();
     if (tid < BN && n0 + tid < a.Cout) {
@@ -425,6 +512,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
       a.stats[((size_t)tile * 2 + 1) * a.Cout + n0 + tid] = t2;
     }
   }
+  FLOW_STAMP(5, __builtin_amdgcn_s_memtime());
+  FLOW_STAMP(6, __builtin_amdgcn_s_memrealtime());
+#ifdef CY_FLOW_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the output stores have been acknowledged)
+  FLOW_STAMP(7, __builtin_amdgcn_s_memrealtime());
+#endif
 #endif
 }
 
@@ -470,6 +563,7 @@ int launch_conv_flow(ConvArgs a, hipStream_t st) {
   }
   if (a.W % C::TW != 0 || a.Cout % BN != 0) return CY_ERR_SHAPE;
   a.tiles_w = a.W / C::TW;
+  a.stamps = g_conv_stamp_buf;
   static const int xcd = [] {
     const char* e = getenv("CY_PLANE_XCD");
     return e ? atoi(e) : 1;

@@ -11,7 +11,7 @@ from contrastyou.utils.utils import ntuple
 
 from .consistency import ConsistencyTrainerHook
 from .discretemi import DiscreteMITrainHook, decoder_names
-from .infonce import INFONCEHook
+from .infonce import INFONCEHook, SelfPacedINFONCEHook, SuperPixelInfoNCEHook
 from .midl import IIDSegmentationTrainerHook
 from .mt import MeanTeacherTrainerHook
 
@@ -62,6 +62,48 @@ def create_infonce_hooks(*, model: nn.Module, feature_names: Union[str, List[str
     hooks = [_infonce_hook(model=model, feature_name=f, weight=w, contrast_on=c, data_name=data_name,
                            spatial_size=ss, global_negatives=global_negatives)
              for f, w, c, ss in zip(rep(feature_names), rep(weights), rep(contrast_ons), rep(spatial_size))]
+    return CombineTrainerHook(*hooks)
+
+
+def _infonce_sp_hook(*, model: nn.Module, feature_name: str, weight: float, contrast_on: str, data_name: str,
+                     begin_value: float = 1e6, end_value: float = 1e6, max_epoch: int, mode: str = "soft", p=0.5,
+                     correct_grad=False):
+    return SelfPacedINFONCEHook(name=f"spinfoce/{feature_name}/{contrast_on}", model=model, feature_name=feature_name,
+                                weight=weight, data_name=data_name, contrast_on=contrast_on, mode=mode, p=p,
+                                begin_value=begin_value, end_value=end_value, max_epoch=max_epoch,
+                                correct_grad=correct_grad)
+
+
+def create_sp_infonce_hooks(*, model: nn.Module, feature_names: Union[str, List[str]],
+                            weights: Union[float, List[float]], contrast_ons: Union[str, List[str]], data_name: str,
+                            begin_values: Union[float, List[float]] = 1e10,
+                            end_values: Union[float, List[float]] = 1e10, mode: str, p=0.5, max_epoch: int,
+                            correct_grad: Union[bool, List[bool]] = False):
+    """one SelfPacedINFONCEHook per feature (creator.py:122-145)"""
+    n = 1 if isinstance(feature_names, str) else len(feature_names)
+    rep = ntuple(n)
+    hooks = [_infonce_sp_hook(model=model, feature_name=f, weight=w, contrast_on=c, data_name=data_name,
+                              begin_value=b, end_value=e, max_epoch=max_epoch, mode=mode, p=p, correct_grad=g)
+             for f, w, c, b, e, g in zip(rep(feature_names), rep(weights), rep(contrast_ons), rep(begin_values),
+                                         rep(end_values), rep(correct_grad))]
+    return CombineTrainerHook(*hooks)
+
+
+def _create_superpixel_hook(*, model: nn.Module, feature_name: str, weight: float, data_name: str,
+                            spatial_size: int):
+    return SuperPixelInfoNCEHook(name=f"infonce/{feature_name}/superpixel", model=model, feature_name=feature_name,
+                                 weight=weight, data_name=data_name, contrast_on="self",
+                                 spatial_size=(spatial_size, spatial_size))
+
+
+def create_superpixel_hooks(*, model: nn.Module, feature_names: Union[str, List[str]],
+                            weights: Union[float, List[float]], spatial_size: Union[int, Sequence[int]],
+                            data_name: str):
+    """creator.py:263-281"""
+    n = 1 if isinstance(feature_names, str) else len(feature_names)
+    rep = ntuple(n)
+    hooks = [_create_superpixel_hook(model=model, feature_name=f, weight=w, data_name=data_name, spatial_size=ss)
+             for f, w, ss in zip(rep(feature_names), rep(weights), rep(spatial_size))]
     return CombineTrainerHook(*hooks)
 
 

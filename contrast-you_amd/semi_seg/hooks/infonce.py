@@ -1,6 +1,7 @@
-"""InfoNCE regulariser on an encoder feature map (semi_seg/hooks/infonce.py:84-245) and its dense
+"""InfoNCE regulariser on an encoder feature map (semi_seg/hooks/infonce.py:84-245), its dense
 variant on decoder feature maps (`_INFONCEDenseHook`, infonce.py:251-279; `region_extractor`,
-infonce.py:31-46).
+infonce.py:31-46), the self-paced variant (`SelfPacedINFONCEHook` + `PScheduler`, infonce.py:58-80,146-178,
+281-305) and the superpixel-labelled dense variant (`SuperPixelInfoNCEHook`, infonce.py:180-194,308-340).
 
 `INFONCEHook` (TrainerHook) owns the feature tap, the projection head and the SupCon criterion;
 once per epoch it hands out an `_INFONCEEpochHook` whose `_call_implementation`:
@@ -21,7 +22,7 @@ from torch import nn
 
 from contrastyou.arch.utils import SingleFeatureExtractor
 from contrastyou.hooks.base import EpocherHook, TrainerHook
-from contrastyou.losses.contrastive import SupConLoss1
+from contrastyou.losses.contrastive import SelfPacedSupConLoss, SupConLoss1
 from contrastyou.meters import AverageValueMeter, MeterInterface
 from contrastyou.utils.utils import fix_all_seed_for_transforms
 from cyhip import ops, parallel
@@ -47,6 +48,28 @@ def region_extractor(normalize_features: torch.Tensor, *, point_nums=5, seed: in
     idx = np.asarray([(i * h + a) * w + b for i, im in enumerate(pts) for a, b in im], dtype=np.int32)
     rows = normalize_features.permute(0, 2, 3, 1).reshape(n * h * w, d)
     return GatherRowsFn.apply(rows, ops.pinned.upload(torch.from_numpy(idx), normalize_features.device))
+
+
+class PScheduler:
+    """gamma of the self-paced loss over the epochs (infonce.py:58-80):
+    begin + (end - begin) * (epoch / max_epoch) ** p"""
+
+    def __init__(self, max_epoch, begin_value=0.0, end_value=1.0, p=0.5):
+        self.max_epoch = max_epoch
+        self.begin_value = float(begin_value)
+        self.end_value = float(end_value)
+        self.epoch = 0
+        self.p = p
+
+    def step(self):
+        self.epoch += 1
+
+    @property
+    def value(self):
+        return self.get_lr(self.epoch)
+
+    def get_lr(self, cur_epoch):
+        return self.begin_value + (self.end_value - self.begin_value) * np.power(cur_epoch / self.max_epoch, self.p)
 
 
 class INFONCEHook(TrainerHook):
@@ -100,10 +123,58 @@ class INFONCEHook(TrainerHook):
         return self._feature_name in self._model.encoder_names
 
 
+class SelfPacedINFONCEHook(INFONCEHook):
+    """self-paced contrastive loss per layer (infonce.py:146-178): every epoch's hook gets the criterion with the
+    scheduler's current gamma, then the scheduler steps"""
+
+    def __init__(self, *, name, model: nn.Module, feature_name: str, weight: float = 1.0, spatial_size=(1, 1),
+                 data_name: str, contrast_on: str, mode="soft", p=0.5, begin_value=1e6, end_value=1e6,
+                 correct_grad: bool = False, max_epoch: int) -> None:
+        self._mode = mode
+        self._p = float(p)
+        self._begin_value = float(begin_value)
+        self._end_value = float(end_value)
+        self._max_epoch = int(max_epoch)
+        self._correct_grad = correct_grad
+        super().__init__(name=name, model=model, feature_name=feature_name, weight=weight, spatial_size=spatial_size,
+                         data_name=data_name, contrast_on=contrast_on)
+
+    def init_criterion(self) -> SelfPacedSupConLoss:
+        self._scheduler = PScheduler(max_epoch=self._max_epoch, begin_value=self._begin_value,
+                                     end_value=self._end_value, p=self._p)
+        self._criterion = SelfPacedSupConLoss(weight_update=self._mode, correct_grad=self._correct_grad)
+        return self._criterion
+
+    def __call__(self):
+        gamma = self._scheduler.value
+        self._scheduler.step()
+        self._criterion.set_gamma(gamma)
+        return _SPINFONCEEpochHook(name=self._hook_name, weight=self._weight, extractor=self._extractor,
+                                   projector=self._projector, criterion=self._criterion,
+                                   label_generator=self._label_generator)
+
+
+class SuperPixelInfoNCEHook(INFONCEHook):
+    """dense InfoNCE whose classes are the superpixel ids under the sampled positions (infonce.py:180-194);
+    decoder features only"""
+
+    def __init__(self, *, name, model: nn.Module, feature_name: str, weight: float = 1.0,
+                 spatial_size: t.Sequence[int] = None, data_name: str, contrast_on: str) -> None:
+        super().__init__(name=name, model=model, feature_name=feature_name, weight=weight, spatial_size=spatial_size,
+                         data_name=data_name, contrast_on=contrast_on)
+        assert self.is_encoder is False, f"{self.__class__.__name__} only supports decoder features"
+
+    def __call__(self) -> "_SuperPixelInfoNCEEPochHook":
+        return _SuperPixelInfoNCEEPochHook(name=self._hook_name, weight=self._weight, extractor=self._extractor,
+                                           projector=self._projector, criterion=self._criterion,
+                                           label_generator=self._label_generator)
+
+
 class _INFONCEEpochHook(EpocherHook):
 
-    def __init__(self, *, name: str, weight: float, extractor, projector, criterion: Union[SupConLoss1],
-                 label_generator, global_negatives: bool = False) -> None:
+    def __init__(self, *, name: str, weight: float, extractor, projector,
+                 criterion: Union[SupConLoss1, SelfPacedSupConLoss], label_generator,
+                 global_negatives: bool = False) -> None:
         super().__init__(name=name)
         self._global_negatives = global_negatives
         self._extractor = extractor
@@ -111,7 +182,7 @@ class _INFONCEEpochHook(EpocherHook):
         self._weight = weight
         self._projector = projector
         self._criterion = criterion
-        self._criterion.defer_checks = True
+        self._criterion.defer_checks = True  # (SupConLoss1: checks once per epoch; a no-op attribute elsewhere)
         self._label_generator = label_generator
         self._n = 0
 
@@ -152,8 +223,56 @@ class _INFONCEEpochHook(EpocherHook):
 
     def close(self):
         self._extractor.remove()
-        self._criterion.validate()  # the reference's per-batch asserts, once per epoch
+        if hasattr(self._criterion, "validate"):
+            self._criterion.validate()  # the reference's per-batch asserts, once per epoch
         self._criterion.defer_checks = False
+
+
+class _SPINFONCEEpochHook(_INFONCEEpochHook):
+    """`_INFONCEEpochHook` + the self-paced meters (infonce.py:281-305)"""
+    _criterion: SelfPacedSupConLoss
+
+    def configure_meters_given_epocher(self, meters: MeterInterface):
+        meters = super().configure_meters_given_epocher(meters)
+        meters.register_meter("sp_weight", AverageValueMeter())
+        meters.register_meter("age_param", AverageValueMeter())
+        return meters
+
+    def _call_implementation(self, **kwargs):
+        loss = super()._call_implementation(**kwargs)
+        self.meters["sp_weight"].add(self._criterion.downgrade_ratio)
+        self.meters["age_param"].add(self._criterion.age_param)
+        return loss
+
+
+class _SuperPixelInfoNCEEPochHook(_INFONCEEpochHook):
+    """infonce.py:308-340: project both views densely, sample 5 positions per image (same seed for both views and
+    for the superpixel map), label every sampled vector with the superpixel id under it"""
+
+    def _call_implementation(self, *, affine_transformer, seed, unlabeled_tf_logits, unlabeled_logits_tf,
+                             partition_group, label_group, batch_data: t.Dict[str, t.Any] = None, **kwargs):
+        assert batch_data is not None
+        n_unl = len(unlabeled_logits_tf)
+        feature_ = self._extractor.tail(n_unl * 2)
+        unlabeled_features, unlabeled_tf_features = torch.chunk(feature_, 2, dim=0)
+        unlabeled_features_tf = affine_transformer(unlabeled_features, seed=seed)
+        sh, sw = self._projector._spatial_size
+        pts = region_points(n_unl, sh, sw, point_nums=5, seed=seed)
+        rows = self._projector.project_points(torch.cat([unlabeled_features_tf, unlabeled_tf_features], dim=0),
+                                              pts + pts)
+        norm_features_tf_selected, norm_tf_features_selected = torch.chunk(rows, 2)
+        dev = rows.device
+        superpixel_mask = (batch_data["superpixel"][0].to(dev) * 255.0).type(torch.uint8).float()
+        superpixel_mask_tf = affine_transformer(superpixel_mask)
+        # F.interpolate(mode="nearest") to (sh, sw), then the sampled positions: source index floor(dst * in / out)
+        H, W = superpixel_mask_tf.shape[-2:]
+        labels = [int(superpixel_mask_tf[i, 0, (a * H) // sh, (b * W) // sw].item())
+                  for i, im in enumerate(pts) for a, b in im]
+        labels = [int(v) & 0xff for v in labels]  # (.type(torch.uint8), infonce.py:336)
+        loss = self._criterion(norm_features_tf_selected, norm_tf_features_selected, target=labels)
+        self.meters["loss"].add(loss.detach())
+        self._n += 1
+        return loss * self._weight
 
 
 class _INFONCEDenseHook(_INFONCEEpochHook):

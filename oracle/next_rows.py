@@ -8,7 +8,7 @@ the reference's own modules (tests/golden/gen_goldens.py --only next).
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Sequence, Tuple
+from typing import Optional, Dict, List, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -234,15 +234,21 @@ def redundancy_criterion(x_out: Tensor, x_tf_out: Tensor, *, alpha: float, lamda
     return -(target * (p + eps).log()).sum() + constrained
 
 
-def self_paced_supcon(z1: Tensor, z2: Tensor, target: Sequence[int], *, gamma: float, weight_update: str = "hard",
-                      correct_grad: bool = False, t: float = 0.07):
+def self_paced_supcon(z1: Tensor, z2: Tensor, target: Optional[Sequence[int]] = None, *, gamma: float,
+                      weight_update: str = "hard", correct_grad: bool = False, t: float = 0.07,
+                      mask: Optional[Tensor] = None):
     """losses/contrastive.py:103-212: SupConLoss1 with the positives weighted by a no-grad self-paced mask;
-    returns (loss, downgrade ratio)"""
+    returns (loss, downgrade ratio).  With an explicit `mask` the positives are mask == 1 and the negatives
+    mask == 0 (:117-121): any other value (e.g. -1) drops the pair from both."""
     n = z1.shape[0]
-    lab = torch.as_tensor(list(target))
-    pos = torch.eq(lab[:, None], lab[None, :]).to(z1.dtype)
+    if mask is not None:
+        pos, neg = (mask == 1).to(z1.dtype), (mask == 0).to(z1.dtype)
+    else:
+        lab = torch.as_tensor(list(target))
+        pos = torch.eq(lab[:, None], lab[None, :]).to(z1.dtype)
+        neg = 1 - pos
     off = 1 - torch.eye(2 * n, dtype=z1.dtype)
-    pos_mask, neg_mask = pos.repeat(2, 2) * off, (1 - pos).repeat(2, 2) * off
+    pos_mask, neg_mask = pos.repeat(2, 2) * off, neg.repeat(2, 2) * off
     P = torch.cat([z1, z2], 0)
     sim = P @ P.t() / t
     logits = sim - sim.max().detach()

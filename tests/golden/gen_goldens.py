@@ -42,6 +42,8 @@ STUBS = {
     "medpy/__init__.py": "",
     "medpy/metric/__init__.py": "def assd(*a, **k):\n    raise NotImplementedError\n",
     "medpy/metric/binary.py": "def __surface_distances(*a, **k):\n    raise NotImplementedError\n",
+    "skimage/__init__.py": "",  # semi_seg/epochers/helper.py:8 (image dumps only)
+    "skimage/io.py": "def imsave(*a, **k):\n    raise NotImplementedError\n",
 }
 
 
@@ -249,8 +251,78 @@ def gen_round2(scratch):
     np.savez_compressed(OUT / "round2.npz", **out)
 
 
+def gen_round3(scratch):
+    """rows pinned in round 3: `region_extractor` (semi_seg/hooks/infonce.py:31-46: the seeded numpy draws of the
+    dense InfoNCE hook) and `PScheduler` (infonce.py:58-80: the gamma law of SelfPacedINFONCEHook) -> round3.npz.
+    semi_seg/hooks/__init__.py pulls every hook (tensorboard, ...): the package is entered as a bare namespace with
+    its real path, so that only infonce.py and what it names are executed; `contrastyou.writer` (tensorboard) is
+    pre-seeded with a no-op `get_tb_writer` (VERDICT r02 #7)."""
+    import types
+
+    writer = types.ModuleType("contrastyou.writer")
+    writer.get_tb_writer = lambda *a, **k: None
+    writer.SummaryWriter = type("SummaryWriter", (), {})
+    sys.modules["contrastyou.writer"] = writer
+    hooks_pkg = types.ModuleType("semi_seg.hooks")
+    hooks_pkg.__path__ = [str(scratch / "ref" / "semi_seg" / "hooks")]
+    sys.modules["semi_seg.hooks"] = hooks_pkg
+    from semi_seg.hooks.infonce import PScheduler, region_extractor
+
+    out = {}
+    g = torch.Generator().manual_seed(2024)
+    for (h, w) in ((14, 14), (20, 12)):
+        for seed in (1, 7, 123456):
+            feat = torch.nn.functional.normalize(torch.randn(3, 6, h, w, generator=g), dim=1)
+            sel = region_extractor(feat, point_nums=5, seed=seed)
+            t = f"re_{h}x{w}_s{seed}"
+            out[f"{t}_feat"], out[f"{t}_out"] = npy(feat), npy(sel)
+    # the global numpy / torch streams are restored by the reference's context manager: pin that too
+    np.random.seed(99)
+    before = np.random.get_state()[1][:4].copy()
+    region_extractor(torch.zeros(1, 2, 8, 8), point_nums=5, seed=3)
+    out["re_state_restored"] = np.array([int((np.random.get_state()[1][:4] == before).all())])
+    for tag, kw in (("a", dict(max_epoch=20, begin_value=1e6, end_value=1e6, p=0.5)),
+                    ("b", dict(max_epoch=10, begin_value=4.0, end_value=0.5, p=0.5)),
+                    ("c", dict(max_epoch=7, begin_value=0.0, end_value=3.0, p=2.0))):
+        sch = PScheduler(**kw)
+        vals = []
+        for _ in range(kw["max_epoch"] + 1):
+            vals.append(float(sch.value))
+            sch.step()
+        out[f"ps_{tag}"] = np.array(vals, dtype=np.float64)
+        out[f"ps_{tag}_cfg"] = np.array([kw["max_epoch"], kw["begin_value"], kw["end_value"], kw["p"]], dtype=np.float64)
+    # SelfPacedSupConLoss with an explicit mask holding values other than 0 / 1 (ADVICE r02: mask == 0 are the
+    # negatives, contrastive.py:120-121; -1 = neither)
+    from contrastyou.losses.contrastive import SelfPacedSupConLoss
+    n = 8
+    z1 = torch.nn.functional.normalize(torch.randn(n, 16, generator=g), dim=1)
+    z2 = torch.nn.functional.normalize(z1 + 0.5 * torch.randn(n, 16, generator=g), dim=1)
+    lab = torch.tensor([0, 1, 2, 3, 0, 1, 2, 3])
+    mask = torch.eq(lab[:, None], lab[None, :]).float()
+    ignore = torch.rand(n, n, generator=g) < 0.3
+    ignore = (ignore | ignore.t()) & (mask == 0)
+    mask[ignore] = -1.0
+    out["spm_z1"], out["spm_z2"], out["spm_mask"] = npy(z1), npy(z2), npy(mask)
+    for mode, gamma in (("hard", 2.5), ("soft", 4.0)):
+        a, b = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+        crit = SelfPacedSupConLoss(temperature=0.07, weight_update=mode)
+        crit.set_gamma(gamma)
+        l = crit(a, b, mask=mask)
+        l.backward()
+        t = f"spm_{mode}"
+        out[f"{t}_loss"], out[f"{t}_dz1"], out[f"{t}_dz2"] = npy(l), npy(a.grad), npy(b.grad)
+        out[f"{t}_ratio"] = np.array(crit.downgrade_ratio)
+    np.savez_compressed(OUT / "round3.npz", **out)
+
+
 def main():
     sys.path.insert(0, str(REPO))
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "round3":
+        scratch = setup_reference()
+        gen_round3(scratch)
+        shutil.rmtree(scratch, ignore_errors=True)
+        print("wrote round3.npz")
+        return
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "round2":
         scratch = setup_reference()
         gen_round2(scratch)

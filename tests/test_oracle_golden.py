@@ -217,3 +217,57 @@ def test_round2_cluster_heads_redundancy_selfpaced(golden_dir):
                 assert torch.allclose(a.grad, torch.from_numpy(g[f"{t}_dz1"]), rtol=1e-4, atol=1e-6), t
     # the one numeric identity the reference's own files hold (contrastive.py:241-248): gamma -> inf == SupConLoss1
     assert abs(float(g["sp_soft_g1e+10_c0_loss"]) - float(g["sp_supcon_loss"])) < 1e-6
+
+
+# ---------------------------------------------------------------- round-3 rows (tests/golden/round3.npz)
+def test_region_extractor_matches_reference(golden_dir):
+    """`region_extractor` of the REFERENCE (semi_seg/hooks/infonce.py:31-46, imported by gen_goldens.py --only
+    round3) on 3 seeds x 2 grid sizes: the oracle's restatement picks the same vectors (the row
+    was pinned to the numpy-stream law only)"""
+    from oracle import next_rows as onr
+    g = np.load(golden_dir / "round3.npz")
+    n = 0
+    for key in g.files:
+        if not key.endswith("_out") or not key.startswith("re_"):
+            continue
+        tag = key[:-4]
+        seed = int(tag.split("_s")[-1])
+        feat = torch.from_numpy(g[tag + "_feat"])
+        got = onr.region_extractor(feat, seed)
+        assert np.array_equal(got.numpy(), g[key]), tag
+        n += 1
+    assert n == 6
+    assert int(g["re_state_restored"][0]) == 1
+
+
+def test_pscheduler_matches_reference(golden_dir):
+    """gamma law of SelfPacedINFONCEHook (infonce.py:58-80): the product's PScheduler against the reference's
+    sequences"""
+    import sys
+    sys.path.insert(0, str(golden_dir.parents[1] / "contrast-you_amd"))
+    from semi_seg.hooks.infonce import PScheduler
+    g = np.load(golden_dir / "round3.npz")
+    for tag in ("a", "b", "c"):
+        max_epoch, begin, end, p = g[f"ps_{tag}_cfg"]
+        sch = PScheduler(max_epoch=int(max_epoch), begin_value=begin, end_value=end, p=p)
+        vals = []
+        for _ in range(int(max_epoch) + 1):
+            vals.append(float(sch.value))
+            sch.step()
+        assert np.array_equal(np.array(vals), g[f"ps_{tag}"]), tag
+
+
+def test_self_paced_supcon_with_ignore_mask_matches_reference(golden_dir):
+    """mask values other than 0 / 1 are neither positives nor negatives (contrastive.py:117-121)"""
+    from oracle import next_rows as onr
+    g = np.load(golden_dir / "round3.npz")
+    z1, z2, mask = (torch.from_numpy(g[k]) for k in ("spm_z1", "spm_z2", "spm_mask"))
+    assert (mask == -1).any()
+    for mode, gamma in (("hard", 2.5), ("soft", 4.0)):
+        a, b = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+        l, ratio = onr.self_paced_supcon(a, b, gamma=gamma, weight_update=mode, mask=mask)
+        l.backward()
+        close(l, g[f"spm_{mode}_loss"], rtol=2e-5)
+        assert abs(ratio - float(g[f"spm_{mode}_ratio"])) < 1e-6
+        close(a.grad, g[f"spm_{mode}_dz1"], rtol=1e-4, atol=1e-6)
+        close(b.grad, g[f"spm_{mode}_dz2"], rtol=1e-4, atol=1e-6)

@@ -34,8 +34,10 @@ def test_every_profiled_conv_instantiation_has_a_parity_case():
 def test_plan_query_matches_partials_and_split():
     from cyhip import ops
     p = ops.conv3x3_plan(16, 28, 28, 256, 0, 256, torch.bfloat16, 0, 1)  # Conv4b at N=16
-    assert p["kernel"] == "conv3x3_flow_kernel" and p["bn"] == 128 and p["th"] == 16 and p["ksplit"] == 2
-    assert p["workgroups"] >= 192
+    assert p["kernel"] == "conv3x3_flow_kernel" and p["bn"] == 128 and p["th"] == 16 and p["ksplit"] == 1
+    assert p["workgroups"] == 112
+    p5 = ops.conv3x3_plan(16, 14, 14, 512, 0, 512, torch.bfloat16, 0, 1)  # Conv5b at N=16: split-K over 8-chunk ranges
+    assert p5["kernel"] == "conv3x3_flow_kernel" and p5["ksplit"] == 4 and p5["workgroups"] == 224
     q = ops.conv3x3_plan(16, 28, 28, 128, 0, 256, torch.bfloat16, 1, 0)  # Conv4a: 2x2 max on load stays on the plane kernel
     assert q["kernel"] == "conv3x3_plane_kernel" and q["bn"] == 128
     w = ops.conv3x3_wgrad_plan(16, 14, 14, 512, 0, 512, torch.bfloat16, 0, 1)
