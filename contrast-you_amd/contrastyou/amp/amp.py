@@ -35,7 +35,10 @@ class AMPScaler:
             # data-parallel + loss scaling: the gradient mean must be taken BEFORE the scaler's inf check, so
             # that every rank sees the same infs and skips (or takes) the same step (what DDP's in-backward
             # all-reduce gives the reference); FusedRAdam.step() then does not reduce a second time
-            if hasattr(optimizer, "all_reduce_grads") and isinstance(self.scaler, torch.amp.GradScaler):
+            # (only an ENABLED GradScaler inspects the gradients: the disabled one of the f32 path keeps the
+            # bucket / RAdam overlap of FusedRAdam.step())
+            if hasattr(optimizer, "all_reduce_grads") and isinstance(self.scaler, torch.amp.GradScaler) \
+                    and self.scaler.is_enabled():
                 optimizer.all_reduce_grads()
             self.scaler.step(optimizer)
             self.scaler.update()

@@ -138,6 +138,17 @@ class FusedRAdam(torch.optim.Optimizer):
             vals = meta.tolist()
             st["step"], st["steps"] = int(vals[0]), [int(v) for v in vals[1:]]
 
+    def broadcast_buffers(self, *modules, src: int = 0):
+        """rank `src`'s module buffers (BatchNorm running statistics, batch counters) to every replica -- the other
+        half of what DistributedDataParallel's constructor broadcasts; called by the trainer after a resume / before
+        the first epoch (COLLECTIVE, like `broadcast_state`)"""
+        if not self._dp:
+            return
+        src_global = dist.get_global_rank(self._pg, src) if self._pg is not None else src
+        for m in modules:
+            for b in m.buffers():
+                dist.broadcast(b, src=src_global, group=self._pg)
+
     def _needs_flat(self) -> bool:
         return any(f is None or f.stale() for f in self._flat)
 
@@ -211,7 +222,10 @@ class FusedRAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, state):
         """hyper-parameters apply at once; the moments are copied when the flat buffers exist on the
-        parameters' final device (a Trainer loads checkpoints before `.to(device)`)"""
+        parameters' final device (a Trainer loads checkpoints before `.to(device)`).
+        Data parallel: COLLECTIVE -- every rank must call it (rank 0's moments and parameters are then broadcast,
+        so only rank 0's checkpoint content matters); a call on one rank alone would leave its broadcasts without
+        partners.  Module buffers (BN running statistics) travel with `broadcast_buffers(*modules)`."""
         for g, sg in zip(self.param_groups, state["param_groups"]):
             g.update(sg)
         self._pending = state

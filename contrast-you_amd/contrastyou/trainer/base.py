@@ -149,6 +149,8 @@ class Trainer(DDPMixin, ModuleBase):
         if not self._initialized:
             raise RuntimeError(f"{self.__class__.__name__} should call `init()` first")
         self.to(self.device)
+        if hasattr(self._optimizer, "broadcast_buffers"):  # data parallel: replicas start from rank 0's BN statistics too
+            self._optimizer.broadcast_buffers(self._model)
         self._start_training(**kwargs)
         if self.on_master:
             Path(self.absolute_save_dir, ".success").touch()

@@ -102,7 +102,7 @@ def test_self_paced_infonce_hook_gamma_schedule_and_loss():
 
         class Spy(EpocherHook):
             def _call_implementation(self, *, seed, partition_group, label_group, **kw):
-                tap["seed"], tap["partition"] = seed, list(partition_group)
+                tap["seed"], tap["partition"], tap["group"] = seed, list(partition_group), list(label_group)
                 tap["conv5"] = sp_hook._extractor.feature()[-2 * n:].detach().float().cpu()
                 return torch.zeros((), device=DEV)
 
@@ -119,11 +119,7 @@ def test_self_paced_infonce_hook_gamma_schedule_and_loss():
         f_u, f_utf = torch.chunk(tap["conv5"], 2, 0)
         z = ol.projection_head(psd, torch.cat([ol.affine_nearest(f_u, theta), f_utf], 0))
         z1, z2 = torch.chunk(z, 2, 0)
-        target = ol.partition_labels(tap["partition"]) if hasattr(ol, "partition_labels") else None
-        if target is None:
-            from semi_seg.hooks.utils import get_label
-            target = get_label(contrast_on="partition", data_name="acdc", partition_group=tap["partition"],
-                               label_group=None)
+        target = ol.get_label("partition", "acdc", tap["partition"], tap["group"])
         want, ratio = onr.self_paced_supcon(z1, z2, list(target), gamma=gamma, weight_update="soft")
         assert abs(stats[key]["loss"] - want.item()) < 3e-4 * abs(want.item()), (epoch, stats[key], want.item())
         assert abs(stats[key]["sp_weight"] - ratio) < 1e-4, (epoch, stats[key], ratio)

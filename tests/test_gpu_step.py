@@ -43,6 +43,18 @@ def test_bf16_step_runs_and_tracks_oracle():
     assert 0.0 <= r["dice"] <= 1.0
 
 
+def test_bf16_step_gradients_with_pinned_routing():
+    """the BENCHMARKED mode, deterministically: bf16 storage, routing (ReLU / max-pool decisions)
+    pinned to the device's own and the oracle fed the device's bf16 activation values -- what remains is bf16
+    rounding of the activations inside the backward chain and accumulation order.  Whole gradient vector within 1 %
+    (the per-parameter worst case is dominated by cancellation in near-zero decoder BN-bias gradients, as for fp16)"""
+    from tests.step_harness import compare_step_with_oracle
+    g = compare_step_with_oracle(n_l=4, n_unl=4, hw=64, max_channel=128, dtype=torch.bfloat16, pin_routing=True)
+    assert g["rel_grad_l2"] < 1e-2, g
+    assert g["rel_grad_worst"] < 0.5, g
+    assert g["rel_sup"] < 5e-2 and g["rel_reg"] < 8e-2, g
+
+
 def test_fp16_gradscaler_step_c4_geometry():
     """BASELINE config 4 in small: 8 classes, 256 x 256 (the igemm kernels), the reference's own AMP mode --
     fp16 autocast + torch GradScaler (contrastyou/amp/amp.py:13-45) -- against the oracle with fp16 storage
