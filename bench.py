@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -179,10 +180,17 @@ def kernel_roofline(ctx, device, steps: int = 3):
     # HBM bytes per launch of the same family from the two PMC passes (FETCH_SIZE, WRITE_SIZE) of this
     # command, summarised by tools/traffic_summary.py into profiles/ (a profiler cannot wrap itself)
     def latest(suffix):
-        files = sorted((REPO / "profiles").glob(f"r*_{suffix}.json"))
-        return json.load(open(files[-1])) if files else {}
+        # profiles/rNN_<workload>_<suffix>.json of the newest round that has one for THIS workload; a PMC pass of
+        # another workload's geometry says nothing about this one (None then)
+        wl = ctx.get("workload", "c2")
+        best = None
+        for f in (REPO / "profiles").glob(f"r*_{wl}_{suffix}.json"):
+            m = re.match(r"r(\d+)_", f.name)
+            if m and (best is None or int(m.group(1)) > best[0]):
+                best = (int(m.group(1)), f)
+        return (json.load(open(best[1])), best[1].name) if best else ({}, None)
 
-    traffic_all, mfma_all = latest("traffic"), latest("mfma")
+    (traffic_all, traffic_src), (mfma_all, mfma_src) = latest("traffic"), latest("mfma")
     traffic = traffic_all.get(dom, {}).get("hbm_bytes_per_launch")
     avg_s = sec / cnt
     roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -193,7 +201,8 @@ def kernel_roofline(ctx, device, steps: int = 3):
             # command, profiles/rNN_traffic.json and rNN_mfma.json; durations from this run's HIP events)
             "hbm_gbps": None if traffic is None else round(traffic / avg_s / 1e9, 1),
             "hbm_frac": None if traffic is None else round(traffic / avg_s / PEAK_HBM_BPS, 4),
-            "mfma_busy": mfma_all.get(dom, {}).get("mfma_busy")}
+            "mfma_busy": mfma_all.get(dom, {}).get("mfma_busy"),
+            "profile_source": [x for x in (traffic_src, mfma_src) if x] or None}
     detail = {}
     for k, v in fam.items():
         d = {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / steps * 1e3, 3),
@@ -291,6 +300,7 @@ def main():
         a.no_cpu_baseline = True
     else:
         ctx = build_step(device, rank, a.n_labeled, a.n_unlabeled, a.hw, a.max_channel)
+    ctx["workload"] = a.workload  # (the PMC summaries under profiles/ are keyed by it)
     note("model / hooks / optimizer built")
 
     def barrier():

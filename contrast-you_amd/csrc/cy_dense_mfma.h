@@ -383,12 +383,17 @@ __global__ void __launch_bounds__(256, 2)
     xhi[s] = dpm_xoff(rh, 2 * gsel + (p4 >> 1)) + 8 * (p4 & 1);
   }
 
-  // (Only the first pixel block of the next job is requested ahead here.  With the next job's 16 coefficient loads in
-  //  flight as well -- the form the dx kernel below runs -- THIS kernel's dW1 / db1 came out different from run to run
+  // (Only the first pixel block of the next job is requested ahead here, and in the dx kernel below.  With the next
+  //  job's 16 coefficient loads in flight as well, THIS kernel's dW1 / db1 came out different from run to run
   //  (relative 3e-3) on geometries where a wave gets three or more jobs; full s_waitcnt's
   //  (-mllvm -amdgpu-waitcnt-forcezero) made it exact again, a full vmcnt wait before the hand-over, an lgkmcnt wait
-  //  around the x tile or s_nops behind the MFMAs did not.  Cause not identified; the coefficient loads cost one
-  //  dependent round trip per job here instead.)
+  //  around the x tile or s_nops behind the MFMAs did not.  Round 3 re-read the ISA of both forms (carried loads:
+  //  8 + 2 + 8 loads issued at the top of a job, `vmcnt(1)` / `vmcnt(0)` of the first block's row loads retire all of
+  //  them in order before any MFMA of the job, `vmcnt(14) / (4) / (0)` in front of the hand-over on the path that
+  //  skips the block loop): every counted wait is sufficient on every path, no load is left in flight across an
+  //  MFMA block in either form -- so the difference between the forms is timing only, and the cause is not a missing
+  //  wait on these loads.  Not identified; NO kernel of the library runs the carried form, and the parity test
+  //  asserts run-to-run bit equality of dx, dW1 and db1 at 3-4 jobs per wave.)
   DpRec cur = dpm_rec(recs, slot, njobs, -1);
   float dpos[HB];
   u32x4 f0[2], f1[2];

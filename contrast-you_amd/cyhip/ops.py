@@ -292,7 +292,7 @@ def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, 
     if ev is not None:  # algorithmic bytes: every input and output element once, packed weights once
         esz = src1.element_size()
         nb = esz * (src1.numel() + (0 if src2 is None else src2.numel()) + N * H * W * Cout + 9 * (C1 + C2) * Cout)
-        _prof_end(ev, "conv3x3_igemm", 2.0 * N * H * W * 9 * (C1 + C2) * Cout, float(nb))
+        _prof_end(ev, "conv3x3_fwd_dgrad", 2.0 * N * H * W * 9 * (C1 + C2) * Cout, float(nb))
     if split:
         return (out, out2), None
     return out, stats

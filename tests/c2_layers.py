@@ -57,21 +57,37 @@ def wgrad_kernel_name(plan: dict) -> str:
 
 def profiled_conv_kernels(path: Path):
     """conv / weight-gradient kernel instantiations named in a `rocprofv3 --kernel-trace --stats` summary
-    (profiles/rNN_bench_c2_kernel_stats_single_stream.txt)"""
+    (profiles/rNN_bench_c2_kernel_stats_single_stream.txt).  Every row that names a conv3x3 / wgrad main kernel
+    must parse into an instantiation -- a row this function cannot read would otherwise be invisible to the
+    coverage gate (rocprofv3's own demangling mutilated the streaming kernel's template
+    arguments; tools/profile_round.sh now keeps the names mangled)."""
     names = set()
     for line in path.read_text().splitlines():
         tok = line.split("  ")[0].strip()
+        if not tok or tok.startswith("#") or tok == "kernel":
+            continue
+        is_conv = "conv3x3_" in tok and not any(k in tok for k in ("conv3x3_first", "splitk"))
+        is_wgrad = "wgrad" in tok and not any(k in tok for k in ("reduce", "first_wgrad"))
+        if not (is_conv or is_wgrad):
+            continue
+        found = False
         m = re.search(r"(conv3x3_(?:plane|igemm|stream|flow)_kernelI\w+?)Ev", tok)
         if m:
             names.add(m.group(1))
+            found = True
         if "wgrad12s_kernel" in tok:
             names.add("wgrad12s_kernel")
+            found = True
         m = re.match(r"(wgrad(?:12)?_kernel<)(?:[A-Za-z_]\w*, )?(\d+, \d+, \d+)", tok)
         if m:
             names.add(m.group(1) + m.group(2))
+            found = True
         m = re.search(r"(wgrad(?:12)?_kernel)I(?:DF16[b_]|f)?Li(\d+)ELi(\d+)ELi(\d+)E", tok)  # mangled form
         if m:
             names.add(f"{m.group(1)}<{m.group(2)}, {m.group(3)}, {m.group(4)}")
+            found = True
+        if not found:
+            raise AssertionError(f"{path.name}: cannot tell which instantiation this row is: {tok!r}")
     return names
 
 

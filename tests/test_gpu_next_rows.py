@@ -114,6 +114,8 @@ def test_dense_projector_points_equal_full_map_and_oracle(dtype, tol):
     (2, 56, 7, 128, torch.float16),      # H % s == 0: no shared pixels, every odd cell segment is empty
     (3, 45, 8, 256, torch.float16),      # ragged bins
     (1, 33, 32, 128, torch.bfloat16),    # bins of two pixels: most single-bin segments are empty
+    (5, 112, 20, 128, torch.bfloat16),   # 7605 cells on 2048 waves: 3-4 jobs per wave in BOTH backward kernels (the
+                                         # run-to-run assertion below on the geometry class VERDICT r02 #1 names)
 ])
 def test_dense_projector_matrix_core_kernels(n, hw, s, hid, dtype):
     """16-bit maps with 32 channels and 128 / 256 hidden units run the matrix-core kernels of cy_dense_mfma.h

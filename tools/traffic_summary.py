@@ -12,7 +12,7 @@ import sys
 from collections import defaultdict
 
 # bench.py's name of a kernel family -> substrings of the kernel names that belong to it
-FAMILIES = {"conv3x3_igemm": ("conv3x3_igemm_kernel", "conv3x3_plane_kernel", "conv3x3_stream_kernel", "conv3x3_flow_kernel"),
+FAMILIES = {"conv3x3_fwd_dgrad": ("conv3x3_igemm_kernel", "conv3x3_plane_kernel", "conv3x3_stream_kernel", "conv3x3_flow_kernel"),
             "conv3x3_wgrad": ("wgrad_kernel", "wgrad12_kernel", "wgrad12s_kernel")}
 
 
