@@ -671,6 +671,7 @@ __global__ void __launch_bounds__(256)
 struct WgPlan {
   bool twelve;  // bf16: the twelve-wave kernel (CY_WGRAD12=0 keeps wgrad_kernel, for A/B runs)
   bool spec;    // ... in its wave-specialised form (64 x 64 blocks; CY_WGRAD_SPEC=0 keeps wgrad12_kernel)
+  bool dma;     // ... with the loader waves on LDS-DMA (CY_WGRAD_DMA=0: register staging)
   int wco, wci, wk;
   int TH, TW, tiles_h, tiles_w, S, co_pad, ci_pad;
 };
@@ -703,6 +704,17 @@ WgPlan plan_wgrad(const cy_conv_desc* d) {
   // (the kernel is written for any block shape; on the 32- / 64-channel layers of the 224^2 and 112^2 levels, where a
   //  tile's loads outweigh its MFMAs 4 : 1, four loader waves are too few: Conv1b 89 -> 109 us, Up_conv2b 80 -> 95 us)
   p.spec = p.twelve && spec_enabled && p.wco == 2 && p.wci == 2 && d->mode1 != CY_SRC_POOL2 && d->W >= 28;
+  static const bool dma_enabled = [] {
+    const char* e = getenv("CY_WGRAD_DMA");
+    return !(e && e[0] == '0');
+  }();
+  {  // 32-bit buffer offsets: every tensor below 2 GiB (the caller's total batch is in d->N); a chunk reads one source
+    const long lim = (1L << 31) - 1, eb = 2;
+    const long opx = (long)d->N * d->H * d->W;
+    const long px1 = d->mode1 == CY_SRC_UP2 ? opx / 4 : opx;
+    const bool small = px1 * d->ld1 * eb <= lim && (!d->C2 || opx * d->ld2 * eb <= lim) && opx * d->ldo * eb <= lim;
+    p.dma = p.spec && dma_enabled && small && (d->C2 == 0 || d->C1 % 64 == 0);
+  }
   p.co_pad = cy_roundup(d->Cout, 32 * p.wco);
   p.ci_pad = cy_roundup(Cin, 32 * p.wci);
   // spatial tile: TW <= 32 columns (halo row pitch is fixed at 36 pixels), TH <= 8 rows with

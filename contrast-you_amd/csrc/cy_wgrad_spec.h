@@ -136,7 +136,157 @@ __device__ __forceinline__ void wg12s_mfma_role(const WgradArgs& g, unsigned cha
   }
 }
 
+// LOADER role by LDS-DMA (DMA = true; 64 x 64 blocks: 128-byte pixels on both sides): the same LDS image -- dy
+// [tile pixel][128 B], halo [halo pixel at pitch 36][128 B], pair-swizzled chunks -- filled by
+// `buffer_load_dwordx4 ... lds` instead of gather -> register -> ds_write.  A wave-instruction writes 1 KB = eight
+// consecutive LDS pixels x eight 16-byte slots; lane (pixel 8q + lane/8, slot lane%8) fetches the channel chunk the
+// swizzle puts into that slot (linear destination, permuted SOURCE, swizzled read: cdna_hip_programming.md rule 21;
+// the swizzle term ((pixel >> 1) & 1) depends on the lane only, 8q being a multiple of 4, so a lane's chunk is the
+// same for every item).  Padding, the pad pixels of the pitch and the rows of a short last k-step read out of range
+// = zeros.  The item geometry (tile pixel -> (ty, tx), halo pixel -> (row, column)) is computed once per kernel;
+// per tile an item costs a handful of VALU instructions and ONE vector-memory instruction, nothing is held in
+// registers, nothing is committed.  The BN+ReLU prologue is an in-place LDS pass over the wave's own items.
+// Stamps of the register-staging loaders: ~450 cycles per item on a SIMD they share with two MFMA
+// waves, 8 700 cycles per tile against an MFMA loop of 4 000 -- the loaders were the long pole.
 template <typename T, int WCO, int WCI>
+__device__ __forceinline__ void wg12s_dma_loader(const WgradArgs& g, unsigned char* smem, int lw, int lane, int TH,
+                                                 int TW, int npix, int npix_pad, int co0, int ci0, int split,
+                                                 int nmine) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using C = Wg12sCfg<WCO, WCI>;
+  static_assert(C::PA == 128 && C::PB == 128, "128-byte pixels");
+  constexpr int HW2 = C::HP, EPC = 8;
+  constexpr unsigned OOB = 0x80000000u;  // (host: every tensor below 2 GiB)
+  constexpr int NDI = (C::MAXPIX / 8 + 3) / 4, NHI = (C::MAXHALO / 8 + 3) / 4;
+  const ConvArgs& a = g.c;
+  const int sub = lane >> 3, slot = lane & 7;
+  const int chunk = slot ^ (((sub >> 1) & 1) << 2);  // logical 16-byte channel chunk of this lane's slot
+  const int ndq = npix_pad / 8, nhq = ((TH + 2) * HW2 + 7) / 8;
+  const int cabs = ci0 + chunk * EPC;
+  const bool in2 = ci0 >= a.C1;  // (host: C1 % 64 == 0 when there is a second source)
+  const bool cvalid = cabs < a.C1 + a.C2, covalid = co0 + chunk * EPC < a.Cout;
+  const bool up2 = !in2 && a.mode1 == CY_SRC_UP2;
+  const int ldx = in2 ? a.ld2 : a.ld1;
+  const unsigned xcol = (unsigned)((in2 ? cabs - a.C1 : cabs) * (int)sizeof(T));
+  const unsigned ycol = (unsigned)((co0 + chunk * EPC) * (int)sizeof(T));
+  const int Hs = up2 ? a.H >> 1 : a.H, Ws = up2 ? a.W >> 1 : a.W;  // source geometry per image
+  // item geometry
+  int dty[NDI], dtx[NDI], hhr[NHI], hhc[NHI];
+#pragma unroll
+  for (int i = 0; i < NDI; ++i) {
+    const int k = (lw + 4 * i) * 8 + sub;
+    dty[i] = k / TW;
+    dtx[i] = k - dty[i] * TW;
+    if (k >= npix) dty[i] = -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NHI; ++i) {
+    const int P = (lw + 4 * i) * 8 + sub;
+    hhr[i] = P / HW2;
+    hhc[i] = P - hhr[i] * HW2;
+    if (hhr[i] >= TH + 2 || hhc[i] >= TW + 2) hhr[i] = -1000;
+  }
+  auto make_rsrc = [&](const void* p, long long bytes) {
+    const unsigned long long b = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, (int)bytes, 0x00020000);
+  };
+  // per segment: extents of dy and of the source this ci block reads
+  const int n_a = (g.tiles_h_a * TH) / a.H, n_b = a.N - n_a;
+  auto seg_bytes = [&](int n, long px_per_img, int ld, int cols) { return n > 0 ? (((long long)n * px_per_img - 1) * ld + cols) * (long long)sizeof(T) : 0ll; };
+  const long pxo = (long)a.H * a.W, pxs = (long)Hs * Ws;
+  const int xcols = in2 ? a.C2 : a.C1;
+  const void* xa = in2 ? a.src2 : a.src1;
+  const void* xb = in2 ? g.src2_b : g.src1_b;
+  const long long by_a = seg_bytes(n_a, pxo, g.ldy, a.Cout), by_b = g.dy_b ? seg_bytes(n_b, pxo, g.ldy, a.Cout) : 0;
+  const long long bx_a = seg_bytes(n_a, pxs, ldx, xcols), bx_b = xb ? seg_bytes(n_b, pxs, ldx, xcols) : 0;
+  const bool pro = a.prologue && !in2 && cvalid;
+  float psc[EPC], psh[EPC];
+  int coef_seg = -1;
+  unsigned hok = 0;  // bit i: halo item i of the tile just requested holds data (else zeros: stays untouched)
+
+  auto request = [&](int tr, unsigned char* sDy, unsigned char* sIn) {
+    const int ct = tr % g.tiles_w, rt_all = tr / g.tiles_w;
+    const bool second = rt_all >= g.tiles_h_a;
+    const int rt = second ? rt_all - g.tiles_h_a : rt_all;
+    const int R0 = rt * TH, w0 = ct * TW;
+    const int n = R0 / a.H, hh0 = R0 - n * a.H;
+    // (descriptors of this tile's segment, rebuilt per tile: four resident ones spill scalar registers)
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(second ? g.dy_b : g.dy, second ? by_b : by_a);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(second ? xb : xa, second ? bx_b : bx_a);
+#pragma unroll
+    for (int i = 0; i < NDI; ++i) {
+      const int q = lw + 4 * i;  // wave-uniform
+      if (q >= ndq) continue;
+      const int w = w0 + dtx[i];
+      const bool ok = dty[i] >= 0 && covalid && w < a.W;
+      const unsigned off = ok ? (unsigned)((R0 + dty[i]) * a.W + w) * (unsigned)(g.ldy * (int)sizeof(T)) + ycol : OOB;
+      auto* dst = (__attribute__((address_space(3))) void*)(sDy + q * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, dst, 16, off, 0, 0, 0);
+    }
+    unsigned nhok = 0;
+#pragma unroll
+    for (int i = 0; i < NHI; ++i) {
+      const int q = lw + 4 * i;
+      if (q >= nhq) continue;
+      const int hh = hh0 - 1 + hhr[i], w = w0 - 1 + hhc[i];
+      const bool ok = cvalid && hh >= 0 && hh < a.H && w >= 0 && w < a.W;  // (hhr = -1000: never)
+      const int pix = up2 ? (n * Hs + (hh >> 1)) * Ws + (w >> 1) : (n * a.H + hh) * a.W + w;
+      const unsigned off = ok ? (unsigned)pix * (unsigned)(ldx * (int)sizeof(T)) + xcol : OOB;
+      auto* dst = (__attribute__((address_space(3))) void*)(sIn + q * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, off, 0, 0, 0);
+      nhok |= (ok ? 1u : 0u) << i;
+    }
+    hok = nhok;
+    if (pro && (int)second != coef_seg) {  // coefficients of the segment whose data is on its way
+      const float* sc = second ? g.scale_b : a.scale;
+      const float* sh = second ? g.shift_b : a.shift;
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) {
+        psc[j] = sc[cabs + j];
+        psh[j] = sh[cabs + j];
+      }
+      coef_seg = second ? 1 : 0;
+    }
+  };
+  // BN+ReLU prologue over this wave's own halo items, after they have landed (padding stays zero)
+  auto transform = [&](unsigned char* sIn) {
+    if (!pro) return;
+#pragma unroll
+    for (int i = 0; i < NHI; ++i) {
+      const int q = lw + 4 * i;
+      if (q >= nhq) continue;
+      if ((hok >> i) & 1u) {
+        unsigned char* p = sIn + q * 1024 + lane * 16;
+        float f[EPC];
+        Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(p), f);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(psc[j], f[j], psh[j]), 0.f);
+        st16(p, Chunk<T>::pack(f));
+      }
+    }
+  };
+
+  __syncthreads();  // tables published
+  if (nmine > 0) {
+    request(split, smem, smem + C::A_BYTES);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    transform(smem + C::A_BYTES);
+  }
+  __syncthreads();  // first tile staged
+  for (int j = 0; j < nmine; ++j) {
+    if (j + 1 < nmine) {
+      unsigned char* nb = smem + ((j + 1) & 1) * C::BUF;
+      request(split + (j + 1) * g.S, nb, nb + C::A_BYTES);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      transform(nb + C::A_BYTES);
+    }
+    __syncthreads();  // tile j consumed by the MFMA waves, tile j + 1 staged
+  }
+#endif
+}
+
+template <typename T, int WCO, int WCI, bool DMA = false>
 __global__ void __launch_bounds__(768, 1)
     wgrad12s_kernel(const WgradArgs g) {
   using C = Wg12sCfg<WCO, WCI>;
@@ -189,6 +339,13 @@ __global__ void __launch_bounds__(768, 1)
     }
   }
 
+  if constexpr (DMA) {
+    if (loader) {
+      __builtin_amdgcn_s_setprio(3);
+      wg12s_dma_loader<T, WCO, WCI>(g, smem, wave - 8, lane, TH, TW, npix, npix_pad, co0, ci0, split, nmine);
+      return;
+    }
+  }
   if (loader) {
     // (the loaders' few hundred instructions per tile go in front of the MFMA waves' on the shared SIMD)
     __builtin_amdgcn_s_setprio(3);
@@ -393,10 +550,10 @@ __global__ void __launch_bounds__(768, 1)
                                        split);
 }
 
-template <typename T, int WCO, int WCI>
+template <typename T, int WCO, int WCI, bool DMA = false>
 int launch_wgrad12s(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
   using C = Wg12sCfg<WCO, WCI>;
-  auto kern = wgrad12s_kernel<T, WCO, WCI>;
+  auto kern = wgrad12s_kernel<T, WCO, WCI, DMA>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -414,6 +571,6 @@ int launch_wgrad12s(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
 
 template <typename T>
 int dispatch_wgrad12s(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
-  if (p.wco == 2 && p.wci == 2) return launch_wgrad12s<T, 2, 2>(g, p, st);
+  if (p.wco == 2 && p.wci == 2) return p.dma ? launch_wgrad12s<T, 2, 2, true>(g, p, st) : launch_wgrad12s<T, 2, 2>(g, p, st);
   return CY_ERR_SHAPE;  // (<2,1>, <1,2>, <1,1> compile and pass the parity tests but are slower than wgrad12_kernel: not built)
 }
