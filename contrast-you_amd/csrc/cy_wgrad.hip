@@ -672,6 +672,7 @@ struct WgPlan {
   bool twelve;  // bf16: the twelve-wave kernel (CY_WGRAD12=0 keeps wgrad_kernel, for A/B runs)
   bool spec;    // ... in its wave-specialised form (64 x 64 blocks; CY_WGRAD_SPEC=0 keeps wgrad12_kernel)
   bool dma;     // ... with the loader waves on LDS-DMA (CY_WGRAD_DMA=0: register staging)
+  bool blk_order;  // ... and 4 x 4 pixel patches as k-steps where the tile allows (CY_WGRAD_BLK=0: row-major k)
   int wco, wci, wk;
   int TH, TW, tiles_h, tiles_w, S, co_pad, ci_pad;
 };
@@ -714,6 +715,11 @@ WgPlan plan_wgrad(const cy_conv_desc* d) {
     const long px1 = d->mode1 == CY_SRC_UP2 ? opx / 4 : opx;
     const bool small = px1 * d->ld1 * eb <= lim && (!d->C2 || opx * d->ld2 * eb <= lim) && opx * d->ldo * eb <= lim;
     p.dma = p.spec && dma_enabled && small && (d->C2 == 0 || d->C1 % 64 == 0);
+    static const bool blk_enabled = [] {
+      const char* e = getenv("CY_WGRAD_BLK");
+      return !(e && e[0] == '0');
+    }();
+    p.blk_order = p.dma && blk_enabled;
   }
   p.co_pad = cy_roundup(d->Cout, 32 * p.wco);
   p.ci_pad = cy_roundup(Cin, 32 * p.wci);

@@ -32,7 +32,18 @@ template <int WCO, int WCI> struct Wg12sCfg : Wg12Cfg<WCO, WCI, 4 / (WCO * WCI)>
 // MFMA role of wgrad12s_kernel: block `blk` (co block = blk / WCI, ci block = blk % WCI), taps TAP0 .. TAP0 + NTAP - 1,
 // steps wk, wk + WK, ... of every tile (WK = 4 / blocks pixel splits; their accumulators are added through LDS
 // at the end, in split order)
-template <typename T, int WCO, int WCI, int TAP0, int NTAP>
+// BLK (with the DMA loaders, TH % 4 == 0 and TW % 4 == 0): k-step s is a 4 x 4 patch of the tile (row quad s / (TW/4),
+// column block s % (TW/4)) instead of 16 consecutive pixels of the row-major tile.  The reduction order over pixels is
+// free as long as dy and the input use the same one, and with patches every fragment address is a LANE CONSTANT
+// plus a wave-uniform offset of the step -- the swizzle terms included (a patch origin is a multiple of four pixels).
+// Stamps with the loaders on DMA showed the MFMA waves as the long pole at ~500 cycles per k-step for 4-5 MFMAs, and
+// the instruction mix why: ~35 vector-ALU instructions of index arithmetic per k-step and wave (pixel -> halo
+// pixel, three swizzle variants, four quarter-rate multiplies) on a SIMD that three waves share; here it is 7 adds
+// (7 100 -> 6 000 cycles per tile).  Requesting the fragments of the next k-step ahead of the MFMAs (two register
+// sets, branch-free so that the LDS waits stay counted) was measured three times on the way and lost every time
+// (+5-10 %): the twelve transposed reads per k-step and wave keep the LDS pipe busy ~4.5 cycles each, more reads in
+// flight only lengthen its queue.
+template <typename T, int WCO, int WCI, int TAP0, int NTAP, bool BLK = false>
 __device__ __forceinline__ void wg12s_mfma_role(const WgradArgs& g, unsigned char* smem, const int* s_ktab, int blk,
                                                 int wk, int lane, int nsteps, int nmine, int co0, int ci0,
                                                 int split) {
@@ -61,6 +72,37 @@ __device__ __forceinline__ void wg12s_mfma_role(const WgradArgs& g, unsigned cha
   for (int j = 0; j < nmine; ++j) {
     const unsigned char* sDy = smem + (j & 1) * C::BUF;
     const unsigned char* sIn = sDy + C::A_BYTES;
+    if constexpr (BLK) {
+      const int l = 8 * h + q;  // this lane's pixel of a patch: row l >> 2 (+ 1 for the second read), column l & 3
+      const unsigned a_lane = (unsigned)(l * PA + (cola ^ (SWA ? (((l >> 1) & 1) << 6) : 0)));
+      const int p1l = (2 * h + 1) * HW2 + q + 1, p2l = p1l + HW2;  // halo pixel of patch (0, 0)'s pixel l / l + 4
+      unsigned b1c[3], b2c[3];  // per tap column dw: base of tap (-1, -1); the taps are non-negative immediates
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        b1c[d] = (unsigned)((p1l - HW2 - 1) * PB + (colb ^ (SWB ? ((((p1l + d - 1) >> 1) & 1) << 6) : 0)));
+        b2c[d] = (unsigned)((p2l - HW2 - 1) * PB + (colb ^ (SWB ? ((((p2l + d - 1) >> 1) & 1) << 6) : 0)));
+      }
+      const int cbn = g.TW >> 2;
+      int rq = wk / cbn, cbk = wk - rq * cbn;  // (wave-uniform, advanced with the step)
+      for (int step = wk; step < nsteps; step += WK) {
+        const unsigned offA = (unsigned)(step * 16 * PA), offB = (unsigned)((rq * 4 * HW2 + cbk * 4) * PB);
+        const unsigned char* arow = sDy + offA + a_lane;
+        const typename Mma<T>::Frag af = WFrag<T>::load(arow, arow + 4 * PA);
+        typename Mma<T>::Frag bf[NTAP];
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+          const int tap = TAP0 + t;
+          const int imm = ((tap / 3) * HW2 + (tap % 3)) * PB;
+          bf[t] = WFrag<T>::load(sIn + offB + b1c[tap % 3] + imm, sIn + offB + b2c[tap % 3] + imm);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) Mma<T>::mma(af, bf[t], acc[t]);
+        __builtin_amdgcn_s_setprio(0);
+        cbk += WK;
+        while (cbk >= cbn) cbk -= cbn, ++rq;
+      }
+    } else
     for (int step = wk; step < nsteps; step += WK) {
       const int k1 = step * 16 + 8 * h + q;
       // (k1 >> 1) & 1 == ((k1 + 4) >> 1) & 1: both dy rows share the swizzle term
@@ -151,7 +193,7 @@ __device__ __forceinline__ void wg12s_mfma_role(const WgradArgs& g, unsigned cha
 template <typename T, int WCO, int WCI>
 __device__ __forceinline__ void wg12s_dma_loader(const WgradArgs& g, unsigned char* smem, int lw, int lane, int TH,
                                                  int TW, int npix, int npix_pad, int co0, int ci0, int split,
-                                                 int nmine) {
+                                                 int nmine, bool blk_order) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using C = Wg12sCfg<WCO, WCI>;
   static_assert(C::PA == 128 && C::PB == 128, "128-byte pixels");
@@ -175,8 +217,15 @@ __device__ __forceinline__ void wg12s_dma_loader(const WgradArgs& g, unsigned ch
 #pragma unroll
   for (int i = 0; i < NDI; ++i) {
     const int k = (lw + 4 * i) * 8 + sub;
-    dty[i] = k / TW;
-    dtx[i] = k - dty[i] * TW;
+    if (blk_order) {  // k-step = a 4 x 4 patch (see wg12s_mfma_role): row k of the dy image holds that pixel
+      const int cbn = TW >> 2, st = k >> 4, l = k & 15;
+      const int rq = st / cbn, cbk = st - rq * cbn;
+      dty[i] = 4 * rq + (l >> 2);
+      dtx[i] = 4 * cbk + (l & 3);
+    } else {
+      dty[i] = k / TW;
+      dtx[i] = k - dty[i] * TW;
+    }
     if (k >= npix) dty[i] = -1;
   }
 #pragma unroll
@@ -249,21 +298,29 @@ __device__ __forceinline__ void wg12s_dma_loader(const WgradArgs& g, unsigned ch
       coef_seg = second ? 1 : 0;
     }
   };
-  // BN+ReLU prologue over this wave's own halo items, after they have landed (padding stays zero)
+  // BN+ReLU prologue over this wave's own halo items, after they have landed (padding stays zero).  All reads first,
+  // then the arithmetic, then the writes: item by item the pass was a chain of twelve LDS round trips (stamps: 3 500
+  // cycles per tile, which made the loaders the long pole again on the six layers with a prologue).
   auto transform = [&](unsigned char* sIn) {
     if (!pro) return;
+    u32x4 v[NHI];
 #pragma unroll
     for (int i = 0; i < NHI; ++i) {
       const int q = lw + 4 * i;
-      if (q >= nhq) continue;
-      if ((hok >> i) & 1u) {
-        unsigned char* p = sIn + q * 1024 + lane * 16;
-        float f[EPC];
-        Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(p), f);
+      v[i] = q < nhq ? *reinterpret_cast<const u32x4*>(sIn + q * 1024 + lane * 16) : u32x4{0u, 0u, 0u, 0u};
+    }
 #pragma unroll
-        for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(psc[j], f[j], psh[j]), 0.f);
-        st16(p, Chunk<T>::pack(f));
-      }
+    for (int i = 0; i < NHI; ++i) {
+      float f[EPC];
+      Chunk<T>::unpack(v[i], f);
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(psc[j], f[j], psh[j]), 0.f);
+      v[i] = Chunk<T>::pack(f);
+    }
+#pragma unroll
+    for (int i = 0; i < NHI; ++i) {
+      const int q = lw + 4 * i;
+      if (q < nhq && ((hok >> i) & 1u)) st16(sIn + q * 1024 + lane * 16, v[i]);
     }
   };
 
@@ -274,21 +331,35 @@ __device__ __forceinline__ void wg12s_dma_loader(const WgradArgs& g, unsigned ch
     transform(smem + C::A_BYTES);
   }
   __syncthreads();  // first tile staged
+#ifdef CY_WGRAD_STAMPS  // phases: 0 = DMA issue, 2 = wait for the data + prologue pass, 3 = barrier
+  const bool stamping = g.c.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+  unsigned long long ph_sum[4] = {0ull, 0ull, 0ull, 0ull}, t_last = stamping ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
   for (int j = 0; j < nmine; ++j) {
     if (j + 1 < nmine) {
       unsigned char* nb = smem + ((j + 1) & 1) * C::BUF;
       request(split + (j + 1) * g.S, nb, nb + C::A_BYTES);
+      W12_STAMP(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       transform(nb + C::A_BYTES);
+      W12_STAMP(2);
     }
     __syncthreads();  // tile j consumed by the MFMA waves, tile j + 1 staged
+    W12_STAMP(3);
   }
+#ifdef CY_WGRAD_STAMPS
+  if (stamping && lane == 0) {
+    for (int q = 0; q < 4; ++q) g.c.stamps[(8 + lw) * 8 + q] = ph_sum[q];
+    g.c.stamps[(8 + lw) * 8 + 4] = (unsigned long long)nmine;
+  }
+#endif
 #endif
 }
 
-template <typename T, int WCO, int WCI, bool DMA = false>
+template <typename T, int WCO, int WCI, bool DMA = false, bool BLK = false>
 __global__ void __launch_bounds__(768, 1)
     wgrad12s_kernel(const WgradArgs g) {
+  static_assert(!BLK || DMA, "patch order of the k-steps: DMA loaders only");
   using C = Wg12sCfg<WCO, WCI>;
   constexpr int PA = C::PA, PB = C::PB, CPA = C::CPA, CPB = C::CPB;
   constexpr int EPC = 8;
@@ -342,7 +413,7 @@ __global__ void __launch_bounds__(768, 1)
   if constexpr (DMA) {
     if (loader) {
       __builtin_amdgcn_s_setprio(3);
-      wg12s_dma_loader<T, WCO, WCI>(g, smem, wave - 8, lane, TH, TW, npix, npix_pad, co0, ci0, split, nmine);
+      wg12s_dma_loader<T, WCO, WCI>(g, smem, wave - 8, lane, TH, TW, npix, npix_pad, co0, ci0, split, nmine, BLK);
       return;
     }
   }
@@ -543,17 +614,17 @@ __global__ void __launch_bounds__(768, 1)
   // ---- MFMA waves: tap group = wave >> 2 (one of each per SIMD), block and pixel split from wave & 3 ----
   const int sub = wave & 3;
   if (wave < 4)
-    wg12s_mfma_role<T, WCO, WCI, 0, 5>(g, smem, s_ktab, sub % C::NBLK, sub / C::NBLK, lane, nsteps, nmine, co0, ci0,
-                                       split);
+    wg12s_mfma_role<T, WCO, WCI, 0, 5, BLK>(g, smem, s_ktab, sub % C::NBLK, sub / C::NBLK, lane, nsteps, nmine, co0, ci0,
+                                            split);
   else
-    wg12s_mfma_role<T, WCO, WCI, 5, 4>(g, smem, s_ktab, sub % C::NBLK, sub / C::NBLK, lane, nsteps, nmine, co0, ci0,
-                                       split);
+    wg12s_mfma_role<T, WCO, WCI, 5, 4, BLK>(g, smem, s_ktab, sub % C::NBLK, sub / C::NBLK, lane, nsteps, nmine, co0, ci0,
+                                            split);
 }
 
-template <typename T, int WCO, int WCI, bool DMA = false>
+template <typename T, int WCO, int WCI, bool DMA = false, bool BLK = false>
 int launch_wgrad12s(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
   using C = Wg12sCfg<WCO, WCI>;
-  auto kern = wgrad12s_kernel<T, WCO, WCI, DMA>;
+  auto kern = wgrad12s_kernel<T, WCO, WCI, DMA, BLK>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -571,6 +642,9 @@ int launch_wgrad12s(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
 
 template <typename T>
 int dispatch_wgrad12s(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
-  if (p.wco == 2 && p.wci == 2) return p.dma ? launch_wgrad12s<T, 2, 2, true>(g, p, st) : launch_wgrad12s<T, 2, 2>(g, p, st);
+  if (p.wco == 2 && p.wci == 2) {
+    if (p.dma && p.TH % 4 == 0 && p.TW % 4 == 0 && p.blk_order) return launch_wgrad12s<T, 2, 2, true, true>(g, p, st);
+    return p.dma ? launch_wgrad12s<T, 2, 2, true>(g, p, st) : launch_wgrad12s<T, 2, 2>(g, p, st);
+  }
   return CY_ERR_SHAPE;  // (<2,1>, <1,2>, <1,1> compile and pass the parity tests but are slower than wgrad12_kernel: not built)
 }
