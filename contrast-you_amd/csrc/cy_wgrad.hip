@@ -696,31 +696,6 @@ WgPlan plan_wgrad(const cy_conv_desc* d) {
   } else {
     p.wco = 1, p.wci = 1, p.wk = 4;
   }
-  static const bool spec_enabled = [] {
-    const char* e = getenv("CY_WGRAD_SPEC");
-    return !(e && e[0] == '0');
-  }();
-  // (measured per layer at N = 32: the pooled-on-load layers -- four synchronous loads per halo item in the loaders --
-  //  and the 14 x 14 layers -- 98-pixel tiles -- are faster in the unspecialised kernel)
-  // (the kernel is written for any block shape; on the 32- / 64-channel layers of the 224^2 and 112^2 levels, where a
-  //  tile's loads outweigh its MFMAs 4 : 1, four loader waves are too few: Conv1b 89 -> 109 us, Up_conv2b 80 -> 95 us)
-  p.spec = p.twelve && spec_enabled && p.wco == 2 && p.wci == 2 && d->mode1 != CY_SRC_POOL2 && d->W >= 28;
-  static const bool dma_enabled = [] {
-    const char* e = getenv("CY_WGRAD_DMA");
-    return !(e && e[0] == '0');
-  }();
-  {  // 32-bit buffer offsets: every tensor below 2 GiB (the caller's total batch is in d->N); a chunk reads one source
-    const long lim = (1L << 31) - 1, eb = 2;
-    const long opx = (long)d->N * d->H * d->W;
-    const long px1 = d->mode1 == CY_SRC_UP2 ? opx / 4 : opx;
-    const bool small = px1 * d->ld1 * eb <= lim && (!d->C2 || opx * d->ld2 * eb <= lim) && opx * d->ldo * eb <= lim;
-    p.dma = p.spec && dma_enabled && small && (d->C2 == 0 || d->C1 % 64 == 0);
-    static const bool blk_enabled = [] {
-      const char* e = getenv("CY_WGRAD_BLK");
-      return !(e && e[0] == '0');
-    }();
-    p.blk_order = p.dma && blk_enabled;
-  }
   p.co_pad = cy_roundup(d->Cout, 32 * p.wco);
   p.ci_pad = cy_roundup(Cin, 32 * p.wci);
   // spatial tile: TW <= 32 columns (halo row pitch is fixed at 36 pixels), TH <= 8 rows with
@@ -732,6 +707,37 @@ WgPlan plan_wgrad(const cy_conv_desc* d) {
   p.TH = best;
   p.tiles_h = (d->N * d->H) / p.TH;
   p.tiles_w = cy_cdiv(d->W, p.TW);
+  static const bool spec_enabled = [] {
+    const char* e = getenv("CY_WGRAD_SPEC");
+    return !(e && e[0] == '0');
+  }();
+  static const bool dma_enabled = [] {
+    const char* e = getenv("CY_WGRAD_DMA");
+    return !(e && e[0] == '0');
+  }();
+  static const bool blk_enabled = [] {
+    const char* e = getenv("CY_WGRAD_BLK");
+    return !(e && e[0] == '0');
+  }();
+  {
+    // the wave-specialised kernel (cy_wgrad_spec.h).  With register-staging loaders it pays on the 64 x 64 blocks
+    // only (measured per layer at N = 32: the pooled-on-load layers -- four synchronous loads per halo item -- and the
+    // 14 x 14 layers -- 98-pixel tiles -- are faster in the unspecialised kernel; on the 32-channel blocks of the
+    // 224^2 level four loader waves could not issue a tile's gathers fast enough: Conv1b 89 -> 109 us).  With the
+    // loaders on LDS-DMA and 4 x 4 patches as k-steps the 32-channel blocks take it too.
+    // DMA: 32-bit buffer offsets (every tensor below 2 GiB; the caller's total batch is in d->N), a ci block reads
+    // one source.
+    const long lim = (1L << 31) - 1, eb = 2;
+    const long opx = (long)d->N * d->H * d->W;
+    const long px1 = d->mode1 == CY_SRC_UP2 ? opx / 4 : opx;
+    const bool small = px1 * d->ld1 * eb <= lim && (!d->C2 || opx * d->ld2 * eb <= lim) && opx * d->ldo * eb <= lim;
+    const bool base = p.twelve && spec_enabled && d->mode1 != CY_SRC_POOL2 && d->W >= 28;
+    const bool dma_ok = dma_enabled && small && (d->C2 == 0 || d->C1 % (32 * p.wci) == 0);
+    const bool patches = dma_ok && blk_enabled && p.TH % 4 == 0 && p.TW % 4 == 0;
+    p.spec = base && ((p.wco == 2 && p.wci == 2) || (p.wco == 1 && patches));
+    p.dma = p.spec && dma_ok;
+    p.blk_order = p.dma && patches;
+  }
   const int out_tiles = (p.co_pad / (32 * p.wco)) * (p.ci_pad / (32 * p.wci));
   const int ntiles = p.tiles_h * p.tiles_w;
   // enough workgroups to fill 256 CUs twice (wgrad_kernel: two per CU) or once (twelve waves: one

@@ -196,27 +196,32 @@ __device__ __forceinline__ void wg12s_dma_loader(const WgradArgs& g, unsigned ch
                                                  int nmine, bool blk_order) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using C = Wg12sCfg<WCO, WCI>;
-  static_assert(C::PA == 128 && C::PB == 128, "128-byte pixels");
+  // 128-byte pixels (64 channels): 8 slots, 8 pixels per instruction, pair swizzle; 64-byte pixels (32 channels):
+  // 4 slots, 16 pixels per instruction, no swizzle
+  constexpr int PA = C::PA, PB = C::PB, SA = PA / 16, SB = PB / 16, PXA = 64 / SA, PXB = 64 / SB;
   constexpr int HW2 = C::HP, EPC = 8;
   constexpr unsigned OOB = 0x80000000u;  // (host: every tensor below 2 GiB)
-  constexpr int NDI = (C::MAXPIX / 8 + 3) / 4, NHI = (C::MAXHALO / 8 + 3) / 4;
+  constexpr int NDI = (C::MAXPIX / PXA + 3) / 4, NHI = (C::MAXHALO / PXB + 3) / 4;
   const ConvArgs& a = g.c;
-  const int sub = lane >> 3, slot = lane & 7;
-  const int chunk = slot ^ (((sub >> 1) & 1) << 2);  // logical 16-byte channel chunk of this lane's slot
-  const int ndq = npix_pad / 8, nhq = ((TH + 2) * HW2 + 7) / 8;
+  const int suba = lane / SA, slota = lane % SA, subb = lane / SB, slotb = lane % SB;
+  // logical 16-byte channel chunk of this lane's slot (the swizzle term of its pixel is a lane constant: an
+  // instruction's first pixel is a multiple of four)
+  const int chunka = PA == 128 ? slota ^ (((suba >> 1) & 1) << 2) : slota;
+  const int chunk = PB == 128 ? slotb ^ (((subb >> 1) & 1) << 2) : slotb;
+  const int ndq = npix_pad / PXA, nhq = ((TH + 2) * HW2 + PXB - 1) / PXB;
   const int cabs = ci0 + chunk * EPC;
-  const bool in2 = ci0 >= a.C1;  // (host: C1 % 64 == 0 when there is a second source)
-  const bool cvalid = cabs < a.C1 + a.C2, covalid = co0 + chunk * EPC < a.Cout;
+  const bool in2 = ci0 >= a.C1;  // (host: C1 % (ci block) == 0 when there is a second source)
+  const bool cvalid = cabs < a.C1 + a.C2, covalid = co0 + chunka * EPC < a.Cout;
   const bool up2 = !in2 && a.mode1 == CY_SRC_UP2;
   const int ldx = in2 ? a.ld2 : a.ld1;
   const unsigned xcol = (unsigned)((in2 ? cabs - a.C1 : cabs) * (int)sizeof(T));
-  const unsigned ycol = (unsigned)((co0 + chunk * EPC) * (int)sizeof(T));
+  const unsigned ycol = (unsigned)((co0 + chunka * EPC) * (int)sizeof(T));
   const int Hs = up2 ? a.H >> 1 : a.H, Ws = up2 ? a.W >> 1 : a.W;  // source geometry per image
   // item geometry
   int dty[NDI], dtx[NDI], hhr[NHI], hhc[NHI];
 #pragma unroll
   for (int i = 0; i < NDI; ++i) {
-    const int k = (lw + 4 * i) * 8 + sub;
+    const int k = (lw + 4 * i) * PXA + suba;
     if (blk_order) {  // k-step = a 4 x 4 patch (see wg12s_mfma_role): row k of the dy image holds that pixel
       const int cbn = TW >> 2, st = k >> 4, l = k & 15;
       const int rq = st / cbn, cbk = st - rq * cbn;
@@ -230,7 +235,7 @@ __device__ __forceinline__ void wg12s_dma_loader(const WgradArgs& g, unsigned ch
   }
 #pragma unroll
   for (int i = 0; i < NHI; ++i) {
-    const int P = (lw + 4 * i) * 8 + sub;
+    const int P = (lw + 4 * i) * PXB + subb;
     hhr[i] = P / HW2;
     hhc[i] = P - hhr[i] * HW2;
     if (hhr[i] >= TH + 2 || hhc[i] >= TW + 2) hhr[i] = -1000;
@@ -643,8 +648,11 @@ int launch_wgrad12s(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
 template <typename T>
 int dispatch_wgrad12s(const WgradArgs& g, const WgPlan& p, hipStream_t st) {
   if (p.wco == 2 && p.wci == 2) {
-    if (p.dma && p.TH % 4 == 0 && p.TW % 4 == 0 && p.blk_order) return launch_wgrad12s<T, 2, 2, true, true>(g, p, st);
+    if (p.blk_order) return launch_wgrad12s<T, 2, 2, true, true>(g, p, st);
     return p.dma ? launch_wgrad12s<T, 2, 2, true>(g, p, st) : launch_wgrad12s<T, 2, 2>(g, p, st);
   }
+  // 32-channel blocks: only with DMA loaders and patch-ordered k-steps (plan_wgrad)
+  if (p.blk_order && p.wco == 1 && p.wci == 2) return launch_wgrad12s<T, 1, 2, true, true>(g, p, st);
+  if (p.blk_order && p.wco == 1 && p.wci == 1) return launch_wgrad12s<T, 1, 1, true, true>(g, p, st);
   return CY_ERR_SHAPE;  // (<2,1>, <1,2>, <1,1> compile and pass the parity tests but are slower than wgrad12_kernel: not built)
 }
