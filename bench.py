@@ -68,8 +68,12 @@ class SyntheticLoader:
     def __len__(self):
         return 1 << 30
 
+    before_batch = None  # instrumented pass: called before a batch is handed out (= at the start of a step)
+
     def __iter__(self):
         while True:
+            if self.before_batch is not None:
+                self.before_batch()
             yield self.batch
 
 
@@ -154,16 +158,30 @@ def kernel_roofline(ctx, device, steps: int = 3):
     every launch on ONE stream (an overlapped kernel's begin-to-end time includes its neighbour's
     share of the CUs).  The committed rocprofv3 stats use the same setting
     (CY_ASYNC_WGRAD=0 CY_TWO_STREAM=0)."""
-    from cyhip import ops
+    from cyhip import _lib, ops
     ops.PROFILE = []
     was = (ops.ASYNC_WGRAD, ops.TWO_STREAM)
     ops.ASYNC_WGRAD = ops.TWO_STREAM = False
+    # An eager step is host-bound (the host needs longer to enqueue ~380 launches than the GPU to run them), and an
+    # event pair around a launch the GPU is waiting for brackets the host's enqueue latency, not the kernel: every
+    # step therefore starts with a one-lane spin kernel that holds the stream while the host enqueues the step
+    # behind it, so that the events see back-to-back GPU execution (they then agree with rocprofv3's durations).
+    loader = ctx["labeled"]
+    if os.environ.get("CY_BENCH_SPIN", "1") != "0" and ctx.get("workload") != "c5":  # (the c5 step is GPU-bound as it is)
+        loader.before_batch = lambda: _lib.call("cy_debug_spin", 12000, ops._stream())
+    settle = 3  # leading steps not counted: the single-stream mode's first steps allocate (hipMalloc synchronises)
     try:
-        run_epoch(ctx, device, steps, 99)
+        run_epoch(ctx, device, settle + steps, 99)
         torch.cuda.synchronize()
     finally:
         ops.ASYNC_WGRAD, ops.TWO_STREAM = was
+        loader.before_batch = None
     rec, ops.PROFILE = ops.PROFILE, None
+    assert len(rec) % (settle + steps) == 0, "every step makes the same launches"
+    rec = rec[len(rec) // (settle + steps) * settle:]
+    if os.environ.get("CY_BENCH_DUMP_EVENTS"):  # per-launch table of the counted steps, in launch order
+        for kind, flops, e0, e1, *rest in rec[:len(rec) // steps]:
+            print(f"[bench] {kind:18s} {flops / 1e9:9.2f} GFLOP {e0.elapsed_time(e1) * 1e3:8.1f} us", file=sys.stderr)
     fam, fam_bytes = {}, {}
     for kind, flops, e0, e1, *rest in rec:
         f = fam.setdefault(kind, [0.0, 0.0, 0])

@@ -247,4 +247,50 @@ int cy_debug_stamp(unsigned long long* buf, int slot, void* stream) {
   return CY_OK;
 }
 
+// Measurement aid (bench.py's instrumented pass): holds the stream for `micros` microseconds of the GPU's wall
+// clock, so that the host can enqueue a whole step behind it and the HIP events around each launch then bracket
+// back-to-back GPU execution instead of the host's enqueue latency.  One lane; bounded (<= 50 ms).
+static __global__ void spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+int cy_debug_spin(int micros, void* stream) {
+  if (micros < 0 || micros > 50000) return CY_ERR_ARG;
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long)micros * 100ull);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+// Timing-only HIP events for bench.py's per-launch durations: created with hipEventDisableSystemFence, i.e. WITHOUT
+// the system-scope release + L2 writeback / invalidate a default event performs when it is recorded -- around a
+// single launch that flush lands inside the measured interval (all of the launch's output is still dirty in the
+// L2s) and makes the following kernel re-read from HBM what it would have found there.
+int cy_debug_event_create(void** ev) {
+  if (!ev) return CY_ERR_ARG;
+  hipEvent_t e;
+  if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return CY_ERR_LAUNCH;
+  *ev = (void*)e;
+  return CY_OK;
+}
+
+int cy_debug_event_record(void* ev, void* stream) {
+  if (!ev) return CY_ERR_ARG;
+  return hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) == hipSuccess ? CY_OK : CY_ERR_LAUNCH;
+}
+
+int cy_debug_event_elapsed_us(void* e0, void* e1, float* us) {
+  if (!e0 || !e1 || !us) return CY_ERR_ARG;
+  if (hipEventSynchronize((hipEvent_t)e1) != hipSuccess) return CY_ERR_LAUNCH;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, (hipEvent_t)e0, (hipEvent_t)e1) != hipSuccess) return CY_ERR_LAUNCH;
+  *us = ms * 1000.f;
+  return CY_OK;
+}
+
+int cy_debug_event_destroy(void* ev) {
+  if (!ev) return CY_ERR_ARG;
+  return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? CY_OK : CY_ERR_LAUNCH;
+}
+
 }  // extern "C"

@@ -61,6 +61,11 @@ _SIGS = {
     "cy_build_arch": (c_char_p, []),
     "cy_stream_capture_id": (C.c_ulonglong, [_P]),
     "cy_debug_stamp": (c_int, [_P, c_int, _P]),
+    "cy_debug_spin": (c_int, [c_int, _P]),
+    "cy_debug_event_create": (c_int, [POINTER(_P)]),
+    "cy_debug_event_record": (c_int, [_P, _P]),
+    "cy_debug_event_elapsed_us": (c_int, [_P, _P, POINTER(C.c_float)]),
+    "cy_debug_event_destroy": (c_int, [_P]),
     "cy_conv3x3_packed_dims": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "cy_conv3x3_packed_elems": (C.c_longlong, [c_int, c_int, c_int]),
     "cy_conv3x3_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),

@@ -24,20 +24,45 @@ HALF_TYPES = (torch.bfloat16, torch.float16)
 PROFILE = None
 
 
+class TimingEvent:
+    """HIP event for measuring only (hipEventDisableSystemFence): torch.cuda.Event creates default events, whose
+    recording performs a system-scope release -- an L2 writeback + invalidate that, around a single launch, falls
+    inside the measured interval and slows the following kernel.  Recorded on torch's current stream."""
+
+    __slots__ = ("_h",)
+
+    def __init__(self):
+        h = C.c_void_p()
+        _lib.call("cy_debug_event_create", C.byref(h))
+        self._h = h
+
+    def record(self):
+        _lib.call("cy_debug_event_record", self._h, _stream())
+        return self
+
+    def elapsed_time(self, other: "TimingEvent") -> float:
+        """milliseconds from this event to `other` (waits for `other`) -- torch.cuda.Event's signature"""
+        us = C.c_float()
+        _lib.call("cy_debug_event_elapsed_us", self._h, other._h, C.byref(us))
+        return us.value * 1e-3
+
+    def __del__(self):
+        try:
+            _lib.call("cy_debug_event_destroy", self._h)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 def _prof_begin():
     if PROFILE is None:
         return None
-    e = torch.cuda.Event(enable_timing=True)
-    e.record()
-    return e
+    return TimingEvent().record()
 
 
 def _prof_end(e0, kind: str, flops: float, nbytes: float = 0.0):
     if e0 is None:
         return
-    e1 = torch.cuda.Event(enable_timing=True)
-    e1.record()
-    PROFILE.append((kind, flops, e0, e1, nbytes))
+    PROFILE.append((kind, flops, e0, TimingEvent().record(), nbytes))
 
 
 def dtype_code(dt: torch.dtype) -> int:

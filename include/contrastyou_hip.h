@@ -57,6 +57,16 @@ unsigned long long cy_stream_capture_id(void* stream);
 /* profiling aid: a one-thread kernel on `stream` stores the device wall clock (100 MHz ticks) into
  * buf[slot] (device memory); works inside a stream capture. */
 int cy_debug_stamp(unsigned long long* buf, int slot, void* stream);
+/* measurement aid: a one-lane kernel that holds `stream` for `micros` (<= 50000) microseconds of the device wall
+ * clock, so that a host can enqueue work behind it and time back-to-back GPU execution with events. */
+int cy_debug_spin(int micros, void* stream);
+/* measurement aid: timing-only HIP events (hipEventDisableSystemFence: recording one does not write back and
+ * invalidate the L2s, which a default event does -- inside the interval it measures).  elapsed_us synchronises on
+ * e1 first. */
+int cy_debug_event_create(void** ev);
+int cy_debug_event_record(void* ev, void* stream);
+int cy_debug_event_elapsed_us(void* e0, void* e1, float* us);
+int cy_debug_event_destroy(void* ev);
 
 /* ------------------------------------------------------------------------
  * 3x3 convolution, stride 1, pad 1, no bias  (nn.Conv2d at

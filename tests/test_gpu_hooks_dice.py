@@ -225,6 +225,16 @@ def test_dice_after_training_bf16_within_the_oracles_seed_spread():
     assert abs(d_32.mean().item() - d_or.mean().item()) < 2 * spread, (d_32.tolist(), d_or.tolist())
     assert abs(d_16.mean().item() - d_or.mean().item()) < 2 * spread, (d_16.tolist(), d_or.tolist())
     assert d_or.min().item() - 2 * spread <= d_16.mean().item() <= d_or.max().item() + 2 * spread
+    # PAIRED per seed: run i of every path starts from the same weights and sees the same batches
+    # in the same order, so the per-seed difference removes the initialisation's share of the spread; what is left
+    # is how far 120 chaotic steps carry two arithmetics apart.  No systematic shift: the mean paired difference is
+    # within three standard errors of zero (floor 0.002, BASELINE's figure).
+    for name, d in (("hip-f32", d_32), ("hip-bf16", d_16)):
+        delta = d - d_or
+        se = delta.std().item() / K ** 0.5
+        print(f"paired dDSC {name} - oracle: mean {delta.mean():+.4f} +- {se:.4f} (s.e., {K} seeds)  per seed "
+              f"{[round(x, 4) for x in delta.tolist()]}")
+        assert abs(delta.mean().item()) <= 3 * max(se, 0.002), (name, delta.tolist())
 
 
 def test_mean_teacher_hard_clip_and_update_bn_follow_the_reference():
