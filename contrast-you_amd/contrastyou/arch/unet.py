@@ -7,7 +7,7 @@ Same constructor, attribute names, parameter/buffer names (checkpoints interchan
 is ONE autograd Function (cyhip.functions.ConvChainFn) over HIP kernels, activations are
 NHWC (channels_last) bf16/f32, and
 
-  * nn.MaxPool2d(2)      -> CY_SRC_POOL2 load mode of the next block's first conv,
+  * nn.MaxPool2d(2)      -> second output of the block's last BN+ReLU launch (cy_bn_relu_apply_pool),
   * nn.Upsample(x2)      -> CY_SRC_UP2 load mode of the _UpConv conv,
   * torch.cat((skip,up)) -> two-source load of the decoder block's first conv,
   * BN+ReLU after conv 1 -> prologue of conv 2 (only raw conv outputs hit HBM inside a block).
@@ -51,20 +51,31 @@ class _ConvBlock(nn.Module):
         )
         self._first = in_ch <= 4
         self._cfgs = {}
+        self._pooled: Optional[Tensor] = None
         self.compute_dtype: Optional[torch.dtype] = None
 
-    def _cfg(self, mode: int) -> ChainCfg:
-        cfg = self._cfgs.get(mode)
+    def _cfg(self, mode: int, pool_out: bool = False) -> ChainCfg:
+        cfg = self._cfgs.get((mode, pool_out))
         if cfg is None:
-            cfg = self._cfgs[mode] = ChainCfg([self.conv[1], self.conv[4]], mode, self._first)
+            cfg = self._cfgs[(mode, pool_out)] = ChainCfg([self.conv[1], self.conv[4]], mode, self._first, pool_out)
         cfg.dtype = self.compute_dtype
         return cfg
 
-    def forward(self, x: Tensor, x2: Optional[Tensor] = None, *, pool: bool = False) -> Tensor:
+    def forward(self, x: Tensor, x2: Optional[Tensor] = None, *, pool: bool = False, pool_out: bool = False) -> Tensor:
+        """pool: the input is max-pooled 2x2 on load.  pool_out: the launch that writes the block output also
+        writes its 2x2 max (`take_pooled()`), so that the next block reads a plain tensor; the module's output
+        stays the one tensor forward hooks / feature extractors expect."""
         c = self.conv
         mode = ops.CY_SRC_POOL2 if pool else ops.CY_SRC_DIRECT
-        return ConvChainFn.apply(self._cfg(mode), x, x2, c[0].weight, c[1].weight, c[1].bias,
-                                 c[3].weight, c[4].weight, c[4].bias)
+        r = ConvChainFn.apply(self._cfg(mode, pool_out), x, x2, c[0].weight, c[1].weight, c[1].bias,
+                              c[3].weight, c[4].weight, c[4].bias)
+        if pool_out:
+            r, self._pooled = r
+        return r
+
+    def take_pooled(self) -> Tensor:
+        p, self._pooled = self._pooled, None
+        return p
 
 
 class _UpConv(nn.Module):
@@ -170,19 +181,21 @@ class UNet(nn.Module):
         return [w for w in ws if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()]
 
     def _forward(self, x: Tensor, until: Optional[str]):
-        e1 = self._Conv1(x)
+        # nn.MaxPool2d(2) between the encoder blocks (reference unet.py:108-121): the pooled tensor is a second
+        # output of the launch that writes the block output
+        e1 = self._Conv1(x, pool_out=until != "Conv1")
         if until == "Conv1":
             return e1
-        e2 = self._Conv2(e1, pool=True)
+        e2 = self._Conv2(self._Conv1.take_pooled(), pool_out=until != "Conv2")
         if until == "Conv2":
             return e2
-        e3 = self._Conv3(e2, pool=True)
+        e3 = self._Conv3(self._Conv2.take_pooled(), pool_out=until != "Conv3")
         if until == "Conv3":
             return e3
-        e4 = self._Conv4(e3, pool=True)
+        e4 = self._Conv4(self._Conv3.take_pooled(), pool_out=until != "Conv4")
         if until == "Conv4":
             return e4
-        e5 = self._Conv5(e4, pool=True)
+        e5 = self._Conv5(self._Conv4.take_pooled())
         if until == "Conv5":
             return e5
 

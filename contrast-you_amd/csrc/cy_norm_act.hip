@@ -110,6 +110,78 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// out = relu(scale*y + shift) AND its 2x2 max (nn.MaxPool2d(2) of the block output, reference unet.py:108-121) in one
+// pass: unit of work = 8 channels of one 2x2 quad (H, W are the POOLED dims).  The pooled copy costs a quarter of
+// the writes and lets the next block's first conv (and its weight gradient) read a plain tensor -- i.e. run on the
+// DMA-fed kernels, which cannot take a maximum on load.
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256)
+    bn_relu_apply_pool_kernel(const TI* __restrict__ y, const float* __restrict__ scale,
+                              const float* __restrict__ shift, TO* __restrict__ out, TO* __restrict__ pooled,
+                              int N, int H, int W, int C) {
+  const int G = C / 8;
+  const long total = (long)N * H * W * G;
+  const int W2 = 2 * W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int g = (int)(i % G);
+    long p = i / G;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const long n = p / H;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + g * 8);
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(scale + g * 8 + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + g * 8);
+    const f32x4 h1 = *reinterpret_cast<const f32x4*>(shift + g * 8 + 4);
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = 0.f;  // relu outputs are >= 0
+    float f[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long px = (n * 2 * H + 2 * h + (q >> 1)) * W2 + 2 * w + (q & 1);
+      const TI* yp = y + px * C + g * 8;
+      if constexpr (sizeof(TI) == 2) {
+        Chunk<TI>::unpack(ld16(yp), f[q]);
+      } else {
+        Chunk<float>::unpack(ld16(yp), f[q]);
+        Chunk<float>::unpack(ld16(yp + 4), f[q] + 4);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f[q][j] = fmaxf(fmaf(s0[j], f[q][j], h0[j]), 0.f);
+        f[q][4 + j] = fmaxf(fmaf(s1[j], f[q][4 + j], h1[j]), 0.f);
+      }
+      const long px = (n * 2 * H + 2 * h + (q >> 1)) * W2 + 2 * w + (q & 1);
+      TO* op = out + px * C + g * 8;
+      if constexpr (sizeof(TO) == 2) {
+        // the pooled value is the max of the STORED (rounded) values, like MaxPool2d of the stored tensor
+        const u32x4 pk = Chunk<TO>::pack(f[q]);
+        st16(op, pk);
+        float r[8];
+        Chunk<TO>::unpack(pk, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], r[j]);
+      } else {
+        st16(op, Chunk<float>::pack(f[q]));
+        st16(op + 4, Chunk<float>::pack(f[q] + 4));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], f[q][j]);
+      }
+    }
+    TO* pp = pooled + ((n * H + h) * W + w) * C + g * 8;
+    if constexpr (sizeof(TO) == 2) {
+      st16(pp, Chunk<TO>::pack(m));
+    } else {
+      st16(pp, Chunk<float>::pack(m));
+      st16(pp + 4, Chunk<float>::pack(m + 4));
+    }
+  }
+}
+
 // ------------------------------------------------------------------ backward
 template <typename T> __device__ __forceinline__ void load8(const T* p, float* f) {
   if constexpr (sizeof(T) == 2) {
@@ -408,6 +480,24 @@ int cy_bn_relu_apply(const void* y, const float* scale, const float* shift, void
                        (const f16*)y, scale, shift, (float*)out, npix, C);
   else
     return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_bn_relu_apply_pool(const void* y, const float* scale, const float* shift, void* out, void* pooled,
+                          int N, int H, int W, int C, int y_dtype, int out_dtype, void* stream) {
+  if (!y || !scale || !shift || !out || !pooled || N <= 0 || H <= 0 || W <= 0) return CY_ERR_ARG;
+  if (C % 8) return CY_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = stream_grid((long)N * H * W * (C / 8));
+#define CY_APPLY_POOL(TI, TO)                                                                              \
+  hipLaunchKernelGGL((bn_relu_apply_pool_kernel<TI, TO>), dim3(grid), dim3(256), 0, st, (const TI*)y, scale, \
+                     shift, (TO*)out, (TO*)pooled, N, H, W, C)
+  if (y_dtype == CY_BF16 && out_dtype == CY_BF16) CY_APPLY_POOL(bf16, bf16);
+  else if (y_dtype == CY_F32 && out_dtype == CY_F32) CY_APPLY_POOL(float, float);
+  else if (y_dtype == CY_F16 && out_dtype == CY_F16) CY_APPLY_POOL(f16, f16);
+  else return CY_ERR_DTYPE;
+#undef CY_APPLY_POOL
   CY_CHECK_LAUNCH();
   return CY_OK;
 }

@@ -90,6 +90,7 @@ _SIGS = {
     "cy_bn_finalize": (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, c_int,
                                c_int, _P, _P, _P, _P, _P]),
     "cy_bn_relu_apply": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, c_int, _P]),
+    "cy_bn_relu_apply_pool": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cy_bn_bwd_num_partials": (c_int, [c_long, c_int]),
     "cy_bn_relu_bwd_reduce": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_long, c_int, c_int, _P]),
     "cy_bn_bwd_finalize": (c_int, [_P, c_int, c_int, _P, _P, _P, c_double, c_int, _P, _P, c_int, _P, _P]),

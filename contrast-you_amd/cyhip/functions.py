@@ -208,10 +208,11 @@ def compute_dtype_for(x: Tensor, requested: Optional[torch.dtype]) -> torch.dtyp
 class ChainCfg:
     """Static description of one [conv3x3 -> BN -> ReLU] x {1,2} block."""
 
-    def __init__(self, bns: List[nn.BatchNorm2d], mode: int, first: bool):
+    def __init__(self, bns: List[nn.BatchNorm2d], mode: int, first: bool, pool_out: bool = False):
         self.bns = bns
         self.mode = mode  # ops.CY_SRC_* for the first conv's source 1
         self.first = first  # first conv reads the f32 image (Cin <= 4)
+        self.pool_out = pool_out  # second output: MaxPool2d(2) of the block output (written by the same launch)
         self.dtype: Optional[torch.dtype] = None  # forced compute dtype (None = infer)
 
 
@@ -268,7 +269,10 @@ class ConvChainFn(torch.autograd.Function):
             coefs.append((scale, shift, mean, invstd))
             batch_flags.append(use_batch)
             cur, cur2 = y, None
-        out = ops.bn_relu_apply(ys[-1], scale, shift)
+        if cfg.pool_out:
+            out, pooled = ops.bn_relu_apply_pool(ys[-1], scale, shift)
+        else:
+            out, pooled = ops.bn_relu_apply(ys[-1], scale, shift), None
         if RAW_TAP is not None:
             for i in range(nconv):
                 RAW_TAP(cfg.bns[i], ys[i], coefs[i][0], coefs[i][1], out if i == nconv - 1 else None)
@@ -281,14 +285,32 @@ class ConvChainFn(torch.autograd.Function):
         tensors = [x1s] + ([x2s] if x2 is not None else []) + list(params) + ys
         for c in coefs:
             tensors.extend(c)
+        if cfg.pool_out:
+            # backward of the pooled output routes through the arg-max of `out`; either output may go unused
+            # (a pass whose loss taps only the encoder leaves `out`'s skip branch without a gradient)
+            tensors.append(out)
+            ctx.set_materialize_grads(False)
+            ctx.save_for_backward(*tensors)
+            return out, pooled
         ctx.save_for_backward(*tensors)
         return out
 
     @staticmethod
-    def backward(ctx, dout: Tensor):
+    def backward(ctx, dout: Optional[Tensor], dpooled: Optional[Tensor] = None):
         ops.ensure_backward_join()
         cfg, nconv, dt = ctx.cfg, ctx.nconv, ctx.dt
         t = list(ctx.saved_tensors)
+        if cfg.pool_out:
+            out = t.pop()
+            if dout is None and dpooled is None:
+                return (None,) * (3 + 3 * nconv)
+            if dpooled is not None:
+                if dpooled.dtype != out.dtype:
+                    dpooled = dpooled.to(out.dtype)
+                add = None
+                if dout is not None:
+                    add = ops.to_nhwc(dout if dout.dtype == out.dtype else dout.to(out.dtype))
+                dout = ops.maxpool2_bwd(out, ops.to_nhwc(dpooled), add=add)  # (+ the skip branch's gradient)
         x1 = t.pop(0)
         x2 = t.pop(0) if ctx.has_x2 else None
         params = [t.pop(0) for _ in range(3 * nconv)]

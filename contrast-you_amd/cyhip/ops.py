@@ -626,6 +626,19 @@ def bn_relu_apply(y: Tensor, scale: Tensor, shift: Tensor, out_dtype: Optional[t
     return out
 
 
+def bn_relu_apply_pool(y: Tensor, scale: Tensor, shift: Tensor) -> Tuple[Tensor, Tensor]:
+    """(relu(scale*y + shift), its 2x2 max) in one pass -- the block output and what nn.MaxPool2d(2) makes of it"""
+    N, Cc, H2, W2 = y.shape
+    if H2 % 2 or W2 % 2:
+        raise ValueError(f"max-pool 2x2 needs even spatial dims, got {H2}x{W2}")
+    out = empty_nhwc(N, Cc, H2, W2, y.dtype, y.device)
+    pooled = empty_nhwc(N, Cc, H2 // 2, W2 // 2, y.dtype, y.device)
+    dt = dtype_code(y.dtype)
+    _lib.call("cy_bn_relu_apply_pool", y.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+              pooled.data_ptr(), N, H2 // 2, W2 // 2, Cc, dt, dt, _stream())
+    return out, pooled
+
+
 def bn_relu_bwd(da: Tensor, y: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor,
                 batch_stats: bool, dgamma_out: Optional[Tensor] = None, dbeta_out: Optional[Tensor] = None,
                 want_param_grads: bool = True):

@@ -219,6 +219,12 @@ int cy_bn_finalize(const float* partials, int num_partials, int C, double count,
 int cy_bn_relu_apply(const void* y, const float* scale, const float* shift, void* out,
                      long npix, int C, int y_dtype, int out_dtype, void* stream);
 
+/* The same, and the 2x2 max of the result (nn.MaxPool2d(2) of the block output, contrastyou/arch/unet.py:108-121)
+ * into `pooled` [N,H,W,C] in one pass; y / out are [N,2H,2W,C] (H, W: the POOLED dims).  out and pooled share
+ * out_dtype = y_dtype; the pooled values are maxima of the stored (rounded) outputs. */
+int cy_bn_relu_apply_pool(const void* y, const float* scale, const float* shift, void* out, void* pooled,
+                          int N, int H, int W, int C, int y_dtype, int out_dtype, void* stream);
+
 /* Backward of y -> relu(bn(y)).  Step 1: per-channel sums of
  * dz = da*(scale*y+shift > 0) and dz*xhat into partials
  * float[num_partials][2][C];  num_partials from cy_bn_bwd_num_partials. */

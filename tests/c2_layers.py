@@ -16,7 +16,7 @@ def unet_layers(hw: int = 224, max_channel: int = 512):
     s = [hw // (2 ** i) for i in range(5)]
     layers = [("Conv1b", s[0], c[0], 0, c[0], 0, 1)]
     for i in range(1, 5):
-        layers.append((f"Conv{i + 1}a", s[i], c[i - 1], 0, c[i], 1, 0))   # max-pool on load
+        layers.append((f"Conv{i + 1}a", s[i], c[i - 1], 0, c[i], 0, 0))   # reads the pooled tensor the previous block wrote
         layers.append((f"Conv{i + 1}b", s[i], c[i], 0, c[i], 0, 1))       # BN+ReLU prologue
     for i in range(3, -1, -1):
         layers.append((f"Up{i + 2}", s[i], c[i + 1], 0, c[i], 2, 0))      # nearest x2 on load

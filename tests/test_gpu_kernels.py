@@ -249,6 +249,11 @@ def test_bn_relu_fwd_bwd(C, hw, dtype):
     yg = nhwc(y.detach(), dtype)
     out = ops.bn_relu_apply(yg, scale, shift)
     assert_close(out, out_ref, ATOL[dtype], "bn relu apply")
+    # the pooled form: the same block output bit for bit, and MaxPool2d(2) of exactly those stored values
+    out_p, pooled = ops.bn_relu_apply_pool(yg, scale, shift)
+    assert torch.equal(out_p, out)
+    assert torch.equal(pooled.float().cpu(), F.max_pool2d(out.float().cpu(), 2, 2))
+    assert pooled.is_contiguous(memory_format=torch.channels_last) and pooled.dtype == out.dtype
     dy, dgamma, dbeta = ops.bn_relu_bwd(nhwc(da, dtype), yg, scale, shift, mean, invstd, True)
     assert_close(dgamma, gamma.grad, 1e-4, "dgamma")
     assert_close(dbeta, beta.grad, 1e-4, "dbeta")

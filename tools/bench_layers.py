@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", default="", help="comma list of layer names")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--pool-on-load", action="store_true",
+                    help="Conv(i)a with the 2x2 max on load (the U-Net reads the pooled tensor bn_relu_apply_pool writes)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda"
@@ -43,7 +45,7 @@ def main():
     # (name, H, C1, C2, Cout, mode, prologue)
     layers = [("Conv1b", hw[0], c[0], 0, c[0], 0, 1)]
     for i in range(1, 5):
-        layers.append((f"Conv{i+1}a", hw[i], c[i - 1], 0, c[i], 1, 0))
+        layers.append((f"Conv{i+1}a", hw[i], c[i - 1], 0, c[i], 1 if a.pool_on_load else 0, 0))
         layers.append((f"Conv{i+1}b", hw[i], c[i], 0, c[i], 0, 1))
     for i in range(3, -1, -1):
         layers.append((f"Up{i+2}", hw[i], c[i + 1], 0, c[i], 2, 0))
