@@ -7,13 +7,16 @@ the GroupNorm+SiLU kernels (cyhip.functions.Conv3x3Fn / GNSiLUFn).
 
 `UNet2` (contrastyou/arch/unet2.py:22-135), the second `get_arch` target: every ResnetBlock's two
 3x3 conv + GroupNorm + SiLU stages -- 18 of them, where the network's FLOPs are -- run on those HIP
-kernels; the glue around them (7x7 stem, 1x1 residual / qkv / output projections, 4x4 stride-2
-down / transposed up convolutions, channel LayerNorm, the linear- and softmax-attention contractions)
-is plain library work (MIOpen / rocBLAS through torch): it is not on the SemiSupervisedEpocher +
-InfoNCE hot path (UNet2 has no `until=` / `arch_elements`, semi_seg/hooks/infonce.py:98 cannot
-attach to it), so it gets no hand-written kernels.  Module and parameter names are the
-reference's (checkpoints interchange); time embeddings are not supported (the segmentation
-configs never enable them).
+kernels, and so does the glue around them (round 3): the 7x7 stem, the 1x1 residual / qkv / output
+projections, the 4x4 stride-2 down convolution and the 4x4 stride-2 transposed up convolution are
+im2col + strided f32-MFMA GEMM + col2im, the channel LayerNorm, the linear attention and the bottleneck's
+softmax attention are the kernels of csrc/cy_unet2.hip (cyhip.glue).  What torch still does here is
+memory, views, `cat`, the residual adds and dtype casts at the block borders.  UNet2 is not on the
+SemiSupervisedEpocher + InfoNCE hot path (it has no `until=` / `arch_elements`,
+semi_seg/hooks/infonce.py:98 cannot attach to it): these kernels are sized for correctness and
+full-chip launches, not tuned per shape.  Module and parameter names are the reference's
+(checkpoints interchange); time embeddings are not supported (the segmentation configs never enable
+them).
 """
 from __future__ import annotations
 
@@ -24,6 +27,7 @@ from torch import Tensor, nn
 
 from cyhip import ops
 from cyhip.functions import Conv3x3Fn, GNSiLUFn, compute_dtype_for
+from cyhip.glue import AttentionFn, ChanLayerNormFn, Conv2dFn, ConvTranspose2dFn, LinearAttentionFn
 
 __all__ = ["Block", "UNet2"]
 
@@ -55,14 +59,33 @@ class Block(nn.Module):
                               self.norm.eps)
 
 
-# ---- the rest of UNet2: library ops around the HIP blocks ---------------------------------------------
+# ---- the rest of UNet2: parameter holders with the reference's names, forward on cyhip.glue ------------------
+class _Conv2d(nn.Conv2d):
+    """nn.Conv2d (square kernel / stride / padding, dilation 1, groups 1) whose forward is im2col + HIP GEMM"""
+
+    def forward(self, x: Tensor) -> Tensor:  # noqa: D102
+        assert self.dilation == (1, 1) and self.groups == 1 and self.stride[0] == self.stride[1] \
+            and self.padding[0] == self.padding[1] and self.padding_mode == "zeros"
+        return Conv2dFn.apply(x, self.weight, self.bias, self.stride[0], self.padding[0])
+
+
+class _ConvTranspose2d(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d(C, C, 4, 2, 1) of the reference's Upsample (unet2.py:176-177): HIP GEMM + col2im"""
+
+    def forward(self, x: Tensor, output_size=None) -> Tensor:  # noqa: D102
+        assert output_size is None and self.dilation == (1, 1) and self.groups == 1 and self.output_padding == (0, 0) \
+            and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1]
+        return ConvTranspose2dFn.apply(x, self.weight, self.bias, self.stride[0], self.padding[0])
+
+
 class _Residual(nn.Module):
     def __init__(self, fn):
         super().__init__()
         self.fn = fn
 
     def forward(self, x):
-        return self.fn(x) + x
+        y = self.fn(x)
+        return y + x.to(y.dtype)
 
 
 class _ChanLayerNorm(nn.Module):
@@ -75,9 +98,7 @@ class _ChanLayerNorm(nn.Module):
         self.b = nn.Parameter(torch.zeros(1, dim, 1, 1))
 
     def forward(self, x):
-        mu = x.mean(dim=1, keepdim=True)
-        var = (x - mu).pow(2).mean(dim=1, keepdim=True)
-        return (x - mu) * torch.rsqrt(var + self.eps) * self.g + self.b
+        return ChanLayerNormFn.apply(x, self.g, self.b, self.eps)
 
 
 class _PreNorm(nn.Module):
@@ -90,29 +111,18 @@ class _PreNorm(nn.Module):
         return self.fn(self.norm(x))
 
 
-def _heads(t: Tensor, heads: int) -> Tensor:
-    b, c, h, w = t.shape
-    return t.reshape(b, heads, c // heads, h * w)  # "b (h c) x y -> b h c (x y)"
-
-
 class _LinearAttention(nn.Module):
     """softmax(q over channels), softmax(k over positions), out = (k v^T)^T q (unet2.py:245-271)"""
 
     def __init__(self, dim, heads=4, dim_head=32):
         super().__init__()
-        self.scale, self.heads = dim_head ** -0.5, heads
+        self.scale, self.heads, self.dim_head = dim_head ** -0.5, heads, dim_head
         hidden = dim_head * heads
-        self.to_qkv = nn.Conv2d(dim, hidden * 3, 1, bias=False)
-        self.to_out = nn.Sequential(nn.Conv2d(hidden, dim, 1), _ChanLayerNorm(dim))
+        self.to_qkv = _Conv2d(dim, hidden * 3, 1, bias=False)
+        self.to_out = nn.Sequential(_Conv2d(hidden, dim, 1), _ChanLayerNorm(dim))
 
     def forward(self, x):
-        b, _, h, w = x.shape
-        q, k, v = (_heads(t, self.heads) for t in self.to_qkv(x).chunk(3, dim=1))
-        q = q.softmax(dim=-2) * self.scale
-        k = k.softmax(dim=-1)
-        context = torch.matmul(k, v.transpose(-1, -2))         # [b,h,d,e]
-        out = torch.matmul(context.transpose(-1, -2), q)       # [b,h,e,n]
-        return self.to_out(out.reshape(b, -1, h, w))
+        return self.to_out(LinearAttentionFn.apply(self.to_qkv(x), self.heads, self.dim_head, self.scale))
 
 
 class _Attention(nn.Module):
@@ -120,18 +130,13 @@ class _Attention(nn.Module):
 
     def __init__(self, dim, heads=4, dim_head=32):
         super().__init__()
-        self.scale, self.heads = dim_head ** -0.5, heads
+        self.scale, self.heads, self.dim_head = dim_head ** -0.5, heads, dim_head
         hidden = dim_head * heads
-        self.to_qkv = nn.Conv2d(dim, hidden * 3, 1, bias=False)
-        self.to_out = nn.Conv2d(hidden, dim, 1)
+        self.to_qkv = _Conv2d(dim, hidden * 3, 1, bias=False)
+        self.to_out = _Conv2d(hidden, dim, 1)
 
     def forward(self, x):
-        b, _, h, w = x.shape
-        q, k, v = (_heads(t, self.heads) for t in self.to_qkv(x).chunk(3, dim=1))
-        sim = torch.matmul((q * self.scale).transpose(-1, -2), k)                 # [b,h,i,j]
-        attn = (sim - sim.amax(dim=-1, keepdim=True).detach()).softmax(dim=-1)
-        out = torch.matmul(attn, v.transpose(-1, -2))                             # [b,h,i,d]
-        return self.to_out(out.transpose(-1, -2).reshape(b, -1, h, w))            # "b h (x y) d -> b (h d) x y"
+        return self.to_out(AttentionFn.apply(self.to_qkv(x), self.heads, self.dim_head, self.scale))
 
 
 class ResnetBlock(nn.Module):
@@ -144,7 +149,7 @@ class ResnetBlock(nn.Module):
         self.mlp = None
         self.block1 = Block(dim, dim_out, groups=groups)
         self.block2 = Block(dim_out, dim_out, groups=groups)
-        self.res_conv = nn.Conv2d(dim, dim_out, 1) if dim != dim_out else nn.Identity()
+        self.res_conv = _Conv2d(dim, dim_out, 1) if dim != dim_out else nn.Identity()
 
     def forward(self, x, time_emb=None):
         h = self.block2(self.block1(x))
@@ -159,7 +164,7 @@ class UNet2(nn.Module):
             raise NotImplementedError("time embeddings are not used by the segmentation path")
         self.channels = input_dim
         init_dim = init_dim if init_dim is not None else dim // 3 * 2
-        self.init_conv = nn.Conv2d(input_dim, init_dim, 7, padding=3)
+        self.init_conv = _Conv2d(input_dim, init_dim, 7, padding=3)
         dims = [init_dim] + [dim * m for m in dim_mults]
         in_out = list(zip(dims[:-1], dims[1:]))
         self.time_mlp = None
@@ -171,7 +176,7 @@ class UNet2(nn.Module):
             self.downs.append(nn.ModuleList([
                 ResnetBlock(cin, cout, groups=g), ResnetBlock(cout, cout, groups=g),
                 _Residual(_PreNorm(cout, _LinearAttention(cout))),
-                nn.Identity() if last else nn.Conv2d(cout, cout, 4, 2, 1)]))
+                nn.Identity() if last else _Conv2d(cout, cout, 4, 2, 1)]))
         mid = dims[-1]
         self.mid_block1 = ResnetBlock(mid, mid, groups=g)
         self.mid_attn = _Residual(_PreNorm(mid, _Attention(mid)))
@@ -181,10 +186,10 @@ class UNet2(nn.Module):
             self.ups.append(nn.ModuleList([
                 ResnetBlock(cout * 2, cin, groups=g), ResnetBlock(cin, cin, groups=g),
                 _Residual(_PreNorm(cin, _LinearAttention(cin))),
-                nn.Identity() if last else nn.ConvTranspose2d(cin, cin, 4, 2, 1)]))
+                nn.Identity() if last else _ConvTranspose2d(cin, cin, 4, 2, 1)]))
         self.out_dim = num_classes if num_classes is not None else input_dim * (2 if learned_variance else 1)
         self.num_classes = num_classes
-        self.final_conv = nn.Sequential(ResnetBlock(dim, dim, groups=g), nn.Conv2d(dim, self.out_dim, 1))
+        self.final_conv = nn.Sequential(ResnetBlock(dim, dim, groups=g), _Conv2d(dim, self.out_dim, 1))
         self._compute_dtype: Optional[torch.dtype] = None
 
     @property
@@ -200,12 +205,7 @@ class UNet2(nn.Module):
 
     def forward(self, x, time=None):
         ops.require_gpu(x)
-        dt = self._compute_dtype
-        if dt in ops.HALF_TYPES and not torch.is_autocast_enabled():
-            # forced half-precision mode outside an autocast region: the library glue follows the blocks' dtype
-            with torch.autocast("cuda", dtype=dt):
-                return self._forward(x)
-        return self._forward(x)
+        return self._forward(x)  # (the glue computes in f32 whatever the blocks' storage type is)
 
     def _forward(self, x):
         x = self.init_conv(x)

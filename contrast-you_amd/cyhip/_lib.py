@@ -11,7 +11,7 @@ from pathlib import Path
 
 CY_F32, CY_BF16, CY_F16 = 0, 1, 2
 CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2 = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _ERRORS = {-1: "CY_ERR_ARG (bad/NULL argument)", -2: "CY_ERR_SHAPE (unsupported shape)",
            -3: "CY_ERR_DTYPE (unsupported dtype)", -4: "CY_ERR_LAUNCH (HIP launch failed)",
@@ -52,8 +52,14 @@ class WgradPlan(C.Structure):
     _fields_ = [(n, c_int32) for n in ("twelve", "wco", "wci", "wk", "th", "tw", "splits", "workgroups")]
 
 
+class MatLayout(C.Structure):
+    """mirror of cy_mat_layout: element (i, j) of batch (b1, b2) at b1*s1 + b2*s2 + i*rs + j*cs"""
+    _fields_ = [(n, c_long) for n in ("rs", "cs", "s1", "s2")]
+
+
 _P = c_void_p
 _PCD = POINTER(ConvDesc)
+_PML = POINTER(MatLayout)
 
 # name -> (restype, argtypes).  restype c_int functions are status-checked.
 _SIGS = {
@@ -155,6 +161,23 @@ _SIGS = {
     "cy_gn_silu_bwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int,
                                c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "cy_bilinear_fwd": (c_int, [_P, _P] + [c_int] * 7 + [_P]),
+    "cy_gemm_strided_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "cy_gemm_strided": (c_int, [_P, _PML, _P, _PML, _P, _PML, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                c_int, _P, c_size_t, _P]),
+    "cy_im2col": (c_int, [_P, _P] + [c_int] * 8 + [_P]),
+    "cy_col2im": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P]),
+    "cy_colsum_ws_bytes": (c_size_t, [c_long, c_int]),
+    "cy_colsum": (c_int, [_P, _P, c_long, c_int, c_int, _P, c_size_t, _P]),
+    "cy_chan_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_long, c_int, c_float, _P]),
+    "cy_chan_layernorm_bwd_ws_bytes": (c_size_t, [c_long, c_int]),
+    "cy_chan_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_int, c_float, _P, c_size_t, _P]),
+    "cy_head_softmax_fwd": (c_int, [_P, c_int, c_int, _P, c_long, c_int, c_int, c_float, _P]),
+    "cy_head_softmax_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_long, c_int, c_int, c_float, _P]),
+    "cy_col_softmax_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cy_col_softmax_fwd": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "cy_col_softmax_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cy_row_softmax_fwd": (c_int, [_P, c_long, c_int, _P]),
+    "cy_row_softmax_bwd": (c_int, [_P, _P, c_long, c_int, _P]),
 }
 
 # functions whose int return is a count / size, not a status

@@ -508,6 +508,63 @@ int cy_gn_silu_bwd(const void* y, int ldy, const void* dz, int ldd, const float*
 int cy_bilinear_fwd(const void* x, void* out, int N, int H, int W, int C, int h, int w, int dtype,
                     void* stream);
 
+/* ------------------------------------------------------------------------
+ * The glue of the reference's second backbone, `UNet2` (contrastyou/arch/unet2.py): everything that is not a
+ * 3x3 conv + GroupNorm + SiLU block.  f32, NHWC maps viewed as [pixels][channels] matrices.
+ *   7x7 stem (:45), Downsample = Conv2d(4, 2, 1) (:180-181), 1x1 projections      -> cy_im2col + cy_gemm_strided
+ *   Upsample = ConvTranspose2d(4, 2, 1) (:176-177) and every data gradient        -> cy_gemm_strided + cy_col2im
+ *   LayerNorm over channels (:183-194)                                            -> cy_chan_layernorm_*
+ *   LinearAttention (:245-271): q.softmax(-2) * scale, k.softmax(-1), two einsums  -> cy_head_softmax_*,
+ *                                                                                    cy_col_softmax_*, cy_gemm_strided
+ *   Attention (:274-304): softmax(q k^T) v over the positions of the bottleneck   -> cy_gemm_strided, cy_row_softmax_*
+ * ------------------------------------------------------------------------ */
+typedef struct {
+  long rs, cs; /* element (i, j) of a matrix at i*rs + j*cs (in elements) */
+  long s1, s2; /* batch (b1, b2) starts at b1*s1 + b2*s2 */
+} cy_mat_layout;
+/* C[b] = alpha * A[b] (M x K) * B[b] (K x N) (+ bias[n]) (+ C[b] when accumulate) for nb1 x nb2 batches, every
+ * operand addressed through its layout (so transposes, channel slices of a wider map and per-head blocks need no
+ * copies), on the f32 MFMA.  ksplit > 1 splits K into that many ranges whose partial products go through `ws`
+ * (cy_gemm_strided_ws_bytes) and are summed in a fixed order: run-to-run identical results. */
+size_t cy_gemm_strided_ws_bytes(int M, int N, int nbatch, int ksplit);
+int cy_gemm_strided(const float* A, const cy_mat_layout* la, const float* B, const cy_mat_layout* lb, float* C,
+                    const cy_mat_layout* lc, const float* bias, int M, int N, int K, int nb1, int nb2, float alpha,
+                    int accumulate, int ksplit, float* ws, size_t ws_bytes, void* stream);
+/* cols[(n, ho, wo)][(kh, kw, c)] = x[n, ho*stride - pad + kh, wo*stride - pad + kw, c] (zero outside);
+ * Ho = (H + 2 pad - KH) / stride + 1.  x [N,H,W,C], cols [N*Ho*Wo][KH*KW*C]. */
+int cy_im2col(const float* x, float* cols, int N, int H, int W, int C, int KH, int KW, int stride, int pad,
+              void* stream);
+/* the adjoint of cy_im2col as a gather: out[n,h,w,c] = bias[c] (or 0) + the sum of the cols entries that were read
+ * from (n,h,w,c).  H, W are those of `out`. */
+int cy_col2im(const float* cols, const float* bias, float* out, int N, int H, int W, int C, int KH, int KW, int stride,
+              int pad, void* stream);
+/* out[n] (+)= sum_m x[m][n], two ordered stages (bias gradients) */
+size_t cy_colsum_ws_bytes(long M, int N);
+int cy_colsum(const float* x, float* out, long M, int N, int accumulate, float* ws, size_t ws_bytes, void* stream);
+/* y[p][c] = (x[p][c] - mean_p) / sqrt(var_p + eps) * g[c] + b[c] over the C channels of each of M pixels */
+int cy_chan_layernorm_fwd(const float* x, const float* g, const float* b, float* y, long M, int C, float eps,
+                          void* stream);
+size_t cy_chan_layernorm_bwd_ws_bytes(long M, int C);
+/* dx, and dg / db (both or neither) */
+int cy_chan_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* dg, float* db, long M,
+                          int C, float eps, float* ws, size_t ws_bytes, void* stream);
+/* y[p][h][d] = scale * softmax_d(x[p][off + h*dh + d]) for rows of ld floats (q of the linear attention) */
+int cy_head_softmax_fwd(const float* x, int ld, int off, float* y, long M, int heads, int dh, float scale,
+                        void* stream);
+/* its backward, written into columns off.. of rows of ld_dx floats */
+int cy_head_softmax_bwd(const float* y, const float* dy, float* dx, int ld_dx, int off, long M, int heads, int dh,
+                        float scale, void* stream);
+/* y[b][p][c] = softmax over the n positions p of image b of x[(b*n + p)*ld + off + c] (k of the linear attention) */
+size_t cy_col_softmax_ws_bytes(int B, int n, int Ch);
+int cy_col_softmax_fwd(const float* x, int ld, int off, float* y, int B, int n, int Ch, float* ws, size_t ws_bytes,
+                       void* stream);
+/* dx[(b*n + p)*ld_dx + off + c] = y * (dy - t[b][c]) with t[b][c] = sum_p y * dy supplied by the caller */
+int cy_col_softmax_bwd(const float* y, const float* dy, const float* t, float* dx, int ld_dx, int off, int B, int n,
+                       int Ch, void* stream);
+/* softmax of every row of x [rows][n], in place; backward: dp <- p * (dp - sum_j p * dp) */
+int cy_row_softmax_fwd(float* x, long rows, int n, void* stream);
+int cy_row_softmax_bwd(const float* p, float* dp, long rows, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
