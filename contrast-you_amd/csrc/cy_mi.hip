@@ -178,6 +178,139 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Displaced joints (padding > 0) in ONE pass over the maps: the kernel above is launched per displacement and reads
+// both maps (2p+1)^2 times (9 displacements: 266 GB/s of algorithmic traffic).  Here a block stages R image rows of
+// x2 and the R + 2p rows of x1 around them, with p zero columns on both sides (so a displaced read is an address
+// shift, no bounds test), and every thread keeps one 4x4 tile of the joint per displacement: up to JM_D = 9 tiles,
+// 144 accumulators; (2p+1)^2 > 9 runs in groups of nine (blockIdx.y).  Same partial layout and fixed-order
+// reduction as above.
+constexpr int JM_D = 9;
+
+__global__ void __launch_bounds__(256, 2)
+    joint_fwd_multi_kernel(const float* __restrict__ x1, const float* __restrict__ x2, float* __restrict__ part,
+                           int N, int H, int W, int k, int pad, int R) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int kp = (k + 3) & ~3, k4 = kp >> 2;
+  const int tps = k4 * k4, nsl = 256 / tps;
+  const int Wp = W + 2 * pad, Rp = R + 2 * pad;
+  float* xs1 = sm;                       // [Rp][Wp][kp]
+  float* xs2 = xs1 + (size_t)Rp * Wp * kp;  // [R][W][kp]
+  float* red = sm;                          // [nsl][kp*kp]: over the tiles once they are done (72 KB at W = 224,
+                                            // k = 20: two workgroups per CU, one stages while the other computes)
+  const int tid = threadIdx.x;
+  const int T = 2 * pad + 1;
+  const int d0 = (int)blockIdx.y * JM_D;
+  const int nd = T * T - d0 < JM_D ? T * T - d0 : JM_D;
+  const int sl = tid / tps, tt = tid - sl * tps;
+  const int ti = tt / k4, tj = tt - ti * k4;
+  const bool active = sl < nsl;
+  float acc[JM_D][4][4];
+#pragma unroll
+  for (int d = 0; d < JM_D; ++d)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[d][a][b] = 0.f;
+  int doff[JM_D];  // LDS offset (floats) of displacement d relative to the undisplaced pixel
+#pragma unroll
+  for (int d = 0; d < JM_D; ++d) {
+    const int dd = d0 + (d < nd ? d : 0);
+    doff[d] = ((dd / T - pad) * Wp + (dd % T - pad)) * kp;
+  }
+  const int tiles_h = (H + R - 1) / R;
+  const int ntile = N * tiles_h;
+  if (kp == k)  // the zero columns left and right of every staged x1 row
+    for (int e = tid; e < Rp * 2 * pad * kp; e += 256) {
+      const int r = e / (2 * pad * kp), q = e - r * (2 * pad * kp);
+      const int col = q / kp < pad ? q / kp : W + q / kp;  // 0..pad-1 | W+pad..W+2pad-1
+      xs1[(r * Wp + col) * kp + q % kp] = 0.f;
+    }
+  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const int n = t / tiles_h, h0 = (t - n * tiles_h) * R;
+    const int rows = H - h0 < R ? H - h0 : R;
+    __syncthreads();
+    if (kp == k) {
+      // an image row is one contiguous span of W*k floats in memory and in the staged tile: 16-byte copies, no
+      // index arithmetic (the pad columns were zeroed once, rows outside the image are zeroed here)
+      const int row4 = W * k / 4;
+      for (int r = 0; r < Rp; ++r) {
+        const int hh = h0 - pad + r;
+        const bool ok = r < rows + 2 * pad && hh >= 0 && hh < H;
+        const float* src = x1 + ((long)n * H + (ok ? hh : 0)) * W * k;
+        float* dst = xs1 + (r * Wp + pad) * kp;
+        for (int e4 = tid; e4 < row4; e4 += 256) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (ok) v = *reinterpret_cast<const f32x4*>(src + 4 * e4);
+          *reinterpret_cast<f32x4*>(dst + 4 * e4) = v;
+        }
+      }
+      const float* src2 = x2 + ((long)n * H + h0) * W * k;
+      for (int e4 = tid; e4 < R * row4; e4 += 256) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (e4 < rows * row4) v = *reinterpret_cast<const f32x4*>(src2 + 4 * e4);
+        *reinterpret_cast<f32x4*>(xs2 + 4 * e4) = v;
+      }
+    } else {
+      for (int e = tid; e < Rp * Wp * kp; e += 256) {
+        const int c = e % kp;
+        const int q = e / kp;
+        const int cw = q % Wp, r = q / Wp;
+        const int hh = h0 - pad + r, ww = cw - pad;
+        float v = 0.f;
+        if (c < k && r < rows + 2 * pad && hh >= 0 && hh < H && ww >= 0 && ww < W)
+          v = x1[(((long)n * H + hh) * W + ww) * k + c];
+        xs1[e] = v;
+      }
+      for (int e = tid; e < R * W * kp; e += 256) {
+        const int c = e % kp;
+        const int q = e / kp;
+        const int w = q % W, r = q / W;
+        xs2[e] = (c < k && r < rows) ? x2[(((long)n * H + h0 + r) * W + w) * k + c] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (active) {
+      int r = 0, w = sl;
+      while (w >= W) w -= W, ++r;
+      for (; r < rows;) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(xs2 + (r * W + w) * kp + 4 * tj);
+        const float* a0 = xs1 + ((r + pad) * Wp + (w + pad)) * kp + 4 * ti;
+#pragma unroll
+        for (int d = 0; d < JM_D; ++d) {
+          if (d < nd) {  // wave-uniform
+            const f32x4 a = *reinterpret_cast<const f32x4*>(a0 + doff[d]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[d][i][j] = fmaf(a[i], b[j], acc[d][i][j]);
+          }
+        }
+        w += nsl;
+        while (w >= W) w -= W, ++r;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < JM_D; ++d) {  // (no early exit: the accumulators must stay statically indexed = in registers)
+    if (d >= nd) continue;          // block-uniform
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[sl * kp * kp + (4 * ti + i) * kp + 4 * tj + j] = acc[d][i][j];
+    }
+    __syncthreads();
+    float* dst = part + ((size_t)(d0 + d) * gridDim.x + blockIdx.x) * (k * k);
+    for (int e = tid; e < k * k; e += 256) {
+      const int i = e / k, j = e - i * k;
+      float s = 0.f;
+      for (int q = 0; q < nsl; ++q) s += red[q * kp * kp + i * kp + j];
+      dst[e] = s;
+    }
+  }
+}
+
 // J[e] = scale * sum_b part[d][b][r]: 4 elements per block, 64 slices of the block partials each,
 // fixed slice order (deterministic)
 __global__ void __launch_bounds__(256)
@@ -470,8 +603,25 @@ int cy_joint_fwd(const float* x1, const float* x2, float* J, int N, int H, int W
   const int nblk = joint_blocks(npix), T = 2 * pad + 1;
   const int kp = (k + 3) & ~3, k4 = kp / 4, nsl = 256 / (k4 * k4);
   const size_t smem = (size_t)(2 * J_P * kp + nsl * kp * kp) * sizeof(float);
-  hipLaunchKernelGGL(joint_fwd_kernel, dim3(nblk, T * T), dim3(256), smem, st, x1, x2, (float*)ws,
-                     N, H, W, k, pad);
+  // padding > 0: every displacement from one staged tile of R rows, if it fits the LDS
+  int R = 256 / W;
+  R = R < 1 ? 1 : (R > H ? H : R);
+  size_t smem_multi = ((size_t)(R + 2 * pad) * (W + 2 * pad) * kp + (size_t)R * W * kp) * sizeof(float);
+  if (smem_multi < (size_t)nsl * kp * kp * sizeof(float)) smem_multi = (size_t)nsl * kp * kp * sizeof(float);
+  if (pad > 0 && smem_multi <= 150 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(joint_fwd_multi_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+        return CY_ERR_LAUNCH;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(joint_fwd_multi_kernel, dim3(nblk, cy_cdiv(T * T, JM_D)), dim3(256), smem_multi, st, x1, x2,
+                       (float*)ws, N, H, W, k, pad, R);
+  } else {
+    hipLaunchKernelGGL(joint_fwd_kernel, dim3(nblk, T * T), dim3(256), smem, st, x1, x2, (float*)ws,
+                       N, H, W, k, pad);
+  }
   CY_CHECK_LAUNCH();
   hipLaunchKernelGGL(joint_reduce_kernel, dim3(cy_cdiv((long)T * T * k * k, 4)), dim3(256), 0, st,
                      (const float*)ws, J, T * T, nblk, k * k,

@@ -7,6 +7,8 @@
 // (deterministic) reductions through per-block partials.
 #include "cy_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 // ------------------------------------------------------------------ finalize
@@ -236,7 +238,28 @@ __global__ void __launch_bounds__(256)
         mu[j] = mean[g * 8 + j];
         is[j] = invstd[g * 8 + j];
       }
-      for (long p = p0 + prow; p < p1; p += rows) {
+      // four pixels per round, all eight loads requested before the first use: a thread walks up to a few dozen
+      // pixels and the dependent form paid one memory latency per pixel (14 us on a 3 MB map).  Same order of
+      // additions per thread as the one-pixel loop.
+      long p = p0 + prow;
+      for (; p + 3L * rows < p1; p += 4L * rows) {
+        float d[4][8], v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          load8<T>(da + (p + (long)u * rows) * ld_da + g * 8, d[u]);
+          load8<T>(y + (p + (long)u * rows) * C + g * 8, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float z = fmaf(sc[j], v[u][j], sh[j]);
+            const float dz = z > 0.f ? d[u][j] : 0.f;
+            a1[j] += dz;
+            a2[j] += dz * ((v[u][j] - mu[j]) * is[j]);
+          }
+      }
+      for (; p < p1; p += rows) {
         float d[8], v[8];
         load8<T>(da + p * ld_da + g * 8, d);
         load8<T>(y + p * C + g * 8, v);
@@ -504,6 +527,8 @@ int cy_bn_relu_apply_pool(const void* y, const float* scale, const float* shift,
 
 int cy_bn_bwd_num_partials(long npix, int C) {
   (void)C;
+  // (32 / 64 / 256 pixels per workgroup measured the same kernel time within 2 % and a slower finalize for the
+  //  finer splits: the kernel is at ~80 % of the HBM rate on every layer size of the C2 step, not latency-bound)
   long b = (npix + 127) / 128;
   if (b > 1024) b = 1024;
   if (b < 1) b = 1;
