@@ -60,7 +60,21 @@ __device__ __forceinline__ void channel_reduce(const T* __restrict__ y, int ldy,
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[v][j] = 0.f;
   if (active) {
-    for (int q = q0 + prow; q < q1; q += rows) {
+    // four pixels per round, every load requested before the first use (a thread walks a dozen pixels or more: the
+    // dependent form paid one memory latency per pixel); same order of additions
+    int q = q0 + prow;
+    for (; q + 3 * rows < q1; q += 4 * rows) {
+      float fy[4][8], fd[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long pix = (long)n * HW + q + u * rows;
+        load8<T>(y + pix * ldy + gg * 8, fy[u]);
+        if (d) load8<T>(d + pix * ldd + gg * 8, fd[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) f(fy[u], fd[u], n, gg * 8, acc);
+    }
+    for (; q < q1; q += rows) {
       const long pix = (long)n * HW + q;
       float fy[8], fd[8];
       load8<T>(y + pix * ldy + gg * 8, fy);
@@ -97,38 +111,55 @@ __global__ void __launch_bounds__(256)
                        });
 }
 
-// one thread per (n, group): mean / rstd
+// one block per (n, group): mean / rstd over the group's channels and the pixel splits (fixed-shape tree), then the
+// per-(n, channel) coefficients of  v = a * y + b  (a = gamma * rstd, b = beta + gamma * (bias - mean) * rstd) that the
+// apply kernel reads -- it used to divide, and to fetch five scalars, per ELEMENT (45 us for a 26 MB map), and this
+// kernel was one thread per (n, group) walking 512 dependent loads (37 us)
 __global__ void __launch_bounds__(256)
-    gn_stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean_rstd, int N,
-                             int C, int G, int HW, float eps) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= N * G) return;
-  const int n = e / G, g = e - n * G, cg = C / G;
+    gn_stats_finalize_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                             float* __restrict__ mean_rstd, float* __restrict__ xcoef, int N, int C, int G, int HW,
+                             float eps) {
+  __shared__ double s1s[256], s2s[256];
+  const int n = blockIdx.x / G, g = blockIdx.x - n * G, cg = C / G;
+  const int tid = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int sp = 0; sp < GN_SPLIT; ++sp) {
+  for (int e = tid; e < GN_SPLIT * cg; e += 256) {
+    const int sp = e / cg, c = g * cg + (e - sp * cg);
     const float* p = part + ((size_t)n * GN_SPLIT + sp) * 2 * C;
-    for (int c = g * cg; c < (g + 1) * cg; ++c) {
-      s1 += (double)p[c];
-      s2 += (double)p[C + c];
-    }
+    s1 += (double)p[c];
+    s2 += (double)p[C + c];
+  }
+  s1s[tid] = s1, s2s[tid] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) s1s[tid] += s1s[tid + o], s2s[tid] += s2s[tid + o];
+    __syncthreads();
   }
   const double m = (double)cg * HW;
-  const double mean = s1 / m;
-  double var = s2 / m - mean * mean;
+  const double mean = s1s[0] / m;
+  double var = s2s[0] / m - mean * mean;
   if (var < 0.0) var = 0.0;
-  mean_rstd[2 * e] = (float)mean;
-  mean_rstd[2 * e + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  const float fmean = (float)mean, frstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (tid == 0) {
+    mean_rstd[2 * (n * G + g)] = fmean;
+    mean_rstd[2 * (n * G + g) + 1] = frstd;
+  }
+  for (int cl = tid; cl < cg; cl += 256) {
+    const int c = g * cg + cl;
+    const float a = gamma[c] * frstd;
+    xcoef[((size_t)n * 2 + 0) * C + c] = a;
+    xcoef[((size_t)n * 2 + 1) * C + c] = fmaf((bias ? bias[c] : 0.f) - fmean, a, beta[c]);
+  }
 }
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-    gn_silu_apply_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ bias,
-                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                         const float* __restrict__ mean_rstd, T* __restrict__ out, int ldo, int N,
-                         int HW, int C, int G) {
-  const int G8 = C / 8, cg = C / G;
+    gn_silu_apply_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ xcoef, T* __restrict__ out,
+                         int ldo, int N, int HW, int C) {
+  const int G8 = C / 8;
   const long total = (long)N * HW * G8;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int g8 = (int)(i % G8);
@@ -136,35 +167,51 @@ __global__ void __launch_bounds__(256)
     const int n = (int)(pix / HW);
     float f[8];
     load8<T>(y + pix * ldy + g8 * 8, f);
+    const float* ca = xcoef + ((size_t)n * 2 + 0) * C + g8 * 8;
+    const float* cb = xcoef + ((size_t)n * 2 + 1) * C + g8 * 8;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(ca), a1 = *reinterpret_cast<const f32x4*>(ca + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(cb), b1 = *reinterpret_cast<const f32x4*>(cb + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = g8 * 8 + j;
-      const float* mr = mean_rstd + 2 * ((size_t)n * G + c / cg);
-      const float xh = (f[j] + (bias ? bias[c] : 0.f) - mr[0]) * mr[1];
-      const float v = fmaf(gamma[c], xh, beta[c]);
-      f[j] = v * sigmoidf_(v);
+    for (int j = 0; j < 4; ++j) {
+      const float v0 = fmaf(a0[j], f[j], b0[j]), v1 = fmaf(a1[j], f[4 + j], b1[j]);
+      f[j] = v0 * sigmoidf_(v0);
+      f[4 + j] = v1 * sigmoidf_(v1);
     }
     store8<T>(out + pix * ldo + g8 * 8, f);
   }
 }
 
 // ---------------------------------------------------------------- backward
+// xt[n][0..3][C] = (a, b, ah, bh) with  v = a*y + b  (the GroupNorm output before SiLU) and  x^ = ah*y + bh, from the
+// statistics the forward pass saved: the two big backward kernels read four coefficient rows instead of dividing and
+// fetching five scalars per element
+__global__ void __launch_bounds__(256)
+    gn_bwd_coef_kernel(const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                       const float* __restrict__ mean_rstd, float* __restrict__ xt, int N, int C, int G) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * C) return;
+  const int n = e / C, c = e - n * C;
+  const float* mr = mean_rstd + 2 * ((size_t)n * G + c / (C / G));
+  const float rstd = mr[1], bh = ((bias ? bias[c] : 0.f) - mr[0]) * rstd;
+  float* t = xt + (size_t)n * 4 * C + c;
+  t[0] = gamma[c] * rstd;
+  t[C] = fmaf(gamma[c], bh, beta[c]);
+  t[2 * C] = rstd;
+  t[3 * C] = bh;
+}
+
 // per (n, split, channel): A = sum dv, B = sum dv*x^, X = sum x^
 template <typename T>
 __global__ void __launch_bounds__(256)
     gn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dz, int ldd,
-                         const float* __restrict__ bias, const float* __restrict__ gamma,
-                         const float* __restrict__ beta, const float* __restrict__ mean_rstd,
-                         int HW, int C, int G, float* __restrict__ part) {
-  const int cg = C / G;
+                         const float* __restrict__ xt, int HW, int C, float* __restrict__ part) {
   channel_reduce<T, 3>(y, ldy, dz, ldd, HW, C, part,
                        [&](const float* fy, const float* fd, int n, int c0, float(*acc)[8]) {
+                         const float* t = xt + (size_t)n * 4 * C + c0;
 #pragma unroll
                          for (int j = 0; j < 8; ++j) {
-                           const int c = c0 + j;
-                           const float* mr = mean_rstd + 2 * ((size_t)n * G + c / cg);
-                           const float xh = (fy[j] + (bias ? bias[c] : 0.f) - mr[0]) * mr[1];
-                           const float v = fmaf(gamma[c], xh, beta[c]);
+                           const float xh = fmaf(t[2 * C + j], fy[j], t[3 * C + j]);
+                           const float v = fmaf(t[j], fy[j], t[C + j]);
                            const float sg = sigmoidf_(v);
                            const float dv = fd[j] * (sg + v * sg * (1.f - sg));
                            acc[0][j] += dv;
@@ -208,10 +255,10 @@ __global__ void __launch_bounds__(64)
   const double rstd = mean_rstd[2 * (n * G + g) + 1];
   for (int cl = tid; cl < cg; cl += 64) {
     const int c = g * cg + cl;
-    float* k = coef + ((size_t)n * C + c) * 3;
+    float* k = coef + (size_t)n * 3 * C + c;  // [n][k0 | k1 | k2][C]
     k[0] = (float)(-rstd * m1);
-    k[1] = (float)(rstd * (double)gamma[c]);
-    k[2] = (float)(-rstd * m2);
+    k[C] = (float)(rstd * (double)gamma[c]);
+    k[2 * C] = (float)(-rstd * m2);
     float* pg = pgrad + ((size_t)n * C + c) * 3;
     pg[0] = (float)sb[cl];                                                       // dgamma_n
     pg[1] = (float)sa[cl];                                                       // dbeta_n
@@ -236,11 +283,9 @@ __global__ void __launch_bounds__(256)
 template <typename T>
 __global__ void __launch_bounds__(256)
     gn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dz, int ldd,
-                        const float* __restrict__ bias, const float* __restrict__ gamma,
-                        const float* __restrict__ beta, const float* __restrict__ mean_rstd,
-                        const float* __restrict__ coef, T* __restrict__ du, int ldu, int N, int HW,
-                        int C, int G) {
-  const int G8 = C / 8, cg = C / G;
+                        const float* __restrict__ xt, const float* __restrict__ coef, T* __restrict__ du, int ldu,
+                        int N, int HW, int C) {
+  const int G8 = C / 8;
   const long total = (long)N * HW * G8;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int g8 = (int)(i % G8);
@@ -249,16 +294,15 @@ __global__ void __launch_bounds__(256)
     float fy[8], fd[8];
     load8<T>(y + pix * ldy + g8 * 8, fy);
     load8<T>(dz + pix * ldd + g8 * 8, fd);
+    const float* t = xt + (size_t)n * 4 * C + g8 * 8;
+    const float* k = coef + (size_t)n * 3 * C + g8 * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = g8 * 8 + j;
-      const float* mr = mean_rstd + 2 * ((size_t)n * G + c / cg);
-      const float xh = (fy[j] + (bias ? bias[c] : 0.f) - mr[0]) * mr[1];
-      const float v = fmaf(gamma[c], xh, beta[c]);
+      const float xh = fmaf(t[2 * C + j], fy[j], t[3 * C + j]);
+      const float v = fmaf(t[j], fy[j], t[C + j]);
       const float sg = sigmoidf_(v);
       const float dv = fd[j] * (sg + v * sg * (1.f - sg));
-      const float* k = coef + ((size_t)n * C + c) * 3;
-      fy[j] = fmaf(k[1], dv, fmaf(k[2], xh, k[0]));
+      fy[j] = fmaf(k[C + j], dv, fmaf(k[2 * C + j], xh, k[j]));
     }
     store8<T>(du + pix * ldu + g8 * 8, fy);
   }
@@ -301,7 +345,7 @@ extern "C" {
 
 size_t cy_gn_ws_bytes(int N, int C) {
   /* reduction partials [N][SPLIT][3][C] + coef [N][C][3] + pgrad [N][C][3] */
-  return ((size_t)N * GN_SPLIT * 3 * C + 6 * (size_t)N * C) * sizeof(float);
+  return ((size_t)N * GN_SPLIT * 3 * C + 10 * (size_t)N * C) * sizeof(float);
 }
 
 int cy_gn_silu_fwd(const void* y, int ldy, const float* bias, const float* gamma, const float* beta,
@@ -314,35 +358,36 @@ int cy_gn_silu_fwd(const void* y, int ldy, const float* bias, const float* gamma
   if (!ws || ws_bytes < cy_gn_ws_bytes(N, C)) return CY_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)ws;
+  float* xcoef = part + (size_t)N * GN_SPLIT * 3 * C;  // [N][2][C] behind the partial sums (cy_gn_ws_bytes has 6*N*C there)
   const size_t smem = reduce_smem(C, 2);
   const int grid = grid_for((long)N * HW * (C / 8));
   if (dtype == CY_BF16) {
     hipLaunchKernelGGL(gn_stats_kernel<bf16>, dim3(GN_SPLIT, N), dim3(256), smem, st, (const bf16*)y,
                        ldy, bias, HW, C, part);
     CY_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(cy_cdiv((long)N * G, 256)), dim3(256), 0, st,
-                       (const float*)part, mean_rstd, N, C, G, HW, eps);
+    hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(N * G), dim3(256), 0, st, (const float*)part, bias, gamma, beta,
+                       mean_rstd, xcoef, N, C, G, HW, eps);
     CY_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_silu_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, ldy,
-                       bias, gamma, beta, (const float*)mean_rstd, (bf16*)out, ldo, N, HW, C, G);
+                       (const float*)xcoef, (bf16*)out, ldo, N, HW, C);
   } else if (dtype == CY_F16) {
     hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(GN_SPLIT, N), dim3(256), smem, st, (const f16*)y,
                        ldy, bias, HW, C, part);
     CY_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(cy_cdiv((long)N * G, 256)), dim3(256), 0, st,
-                       (const float*)part, mean_rstd, N, C, G, HW, eps);
+    hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(N * G), dim3(256), 0, st, (const float*)part, bias, gamma, beta,
+                       mean_rstd, xcoef, N, C, G, HW, eps);
     CY_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_silu_apply_kernel<f16>, dim3(grid), dim3(256), 0, st, (const f16*)y, ldy,
-                       bias, gamma, beta, (const float*)mean_rstd, (f16*)out, ldo, N, HW, C, G);
+                       (const float*)xcoef, (f16*)out, ldo, N, HW, C);
   } else {
     hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(GN_SPLIT, N), dim3(256), smem, st,
                        (const float*)y, ldy, bias, HW, C, part);
     CY_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(cy_cdiv((long)N * G, 256)), dim3(256), 0, st,
-                       (const float*)part, mean_rstd, N, C, G, HW, eps);
+    hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(N * G), dim3(256), 0, st, (const float*)part, bias, gamma, beta,
+                       mean_rstd, xcoef, N, C, G, HW, eps);
     CY_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_silu_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y,
-                       ldy, bias, gamma, beta, (const float*)mean_rstd, (float*)out, ldo, N, HW, C, G);
+                       ldy, (const float*)xcoef, (float*)out, ldo, N, HW, C);
   }
   CY_CHECK_LAUNCH();
   return CY_OK;
@@ -362,20 +407,21 @@ int cy_gn_silu_bwd(const void* y, int ldy, const void* dz, int ldd, const float*
   float* part = (float*)ws;
   float* coef = part + (size_t)N * GN_SPLIT * 3 * C;
   float* pgrad = coef + 3 * (size_t)N * C;
+  float* xt = pgrad + 3 * (size_t)N * C;  // [N][4][C]
   const size_t smem = reduce_smem(C, 3);
   const int grid = grid_for((long)N * HW * (C / 8));
+  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(cy_cdiv((long)N * C, 256)), dim3(256), 0, st, bias, gamma, beta,
+                     mean_rstd, xt, N, C, G);
+  CY_CHECK_LAUNCH();
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16>, dim3(GN_SPLIT, N), dim3(256), smem, st,
-                       (const bf16*)y, ldy, (const bf16*)dz, ldd, bias, gamma, beta, mean_rstd, HW, C,
-                       G, part);
+                       (const bf16*)y, ldy, (const bf16*)dz, ldd, (const float*)xt, HW, C, part);
   else if (dtype == CY_F16)
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<f16>, dim3(GN_SPLIT, N), dim3(256), smem, st,
-                       (const f16*)y, ldy, (const f16*)dz, ldd, bias, gamma, beta, mean_rstd, HW, C,
-                       G, part);
+                       (const f16*)y, ldy, (const f16*)dz, ldd, (const float*)xt, HW, C, part);
   else
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(GN_SPLIT, N), dim3(256), smem, st,
-                       (const float*)y, ldy, (const float*)dz, ldd, bias, gamma, beta, mean_rstd, HW,
-                       C, G, part);
+                       (const float*)y, ldy, (const float*)dz, ldd, (const float*)xt, HW, C, part);
   CY_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N * G), dim3(64), 0, st, (const float*)part, gamma,
                      mean_rstd, coef, pgrad, N, C, G, HW);
@@ -387,16 +433,13 @@ int cy_gn_silu_bwd(const void* y, int ldy, const void* dz, int ldd, const float*
   }
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, ldy,
-                       (const bf16*)dz, ldd, bias, gamma, beta, mean_rstd, (const float*)coef,
-                       (bf16*)du, ldu, N, HW, C, G);
+                       (const bf16*)dz, ldd, (const float*)xt, (const float*)coef, (bf16*)du, ldu, N, HW, C);
   else if (dtype == CY_F16)
     hipLaunchKernelGGL(gn_bwd_apply_kernel<f16>, dim3(grid), dim3(256), 0, st, (const f16*)y, ldy,
-                       (const f16*)dz, ldd, bias, gamma, beta, mean_rstd, (const float*)coef,
-                       (f16*)du, ldu, N, HW, C, G);
+                       (const f16*)dz, ldd, (const float*)xt, (const float*)coef, (f16*)du, ldu, N, HW, C);
   else
     hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y, ldy,
-                       (const float*)dz, ldd, bias, gamma, beta, mean_rstd, (const float*)coef,
-                       (float*)du, ldu, N, HW, C, G);
+                       (const float*)dz, ldd, (const float*)xt, (const float*)coef, (float*)du, ldu, N, HW, C);
   CY_CHECK_LAUNCH();
   return CY_OK;
 }
