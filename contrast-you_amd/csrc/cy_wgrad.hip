@@ -724,14 +724,19 @@ WgPlan plan_wgrad(const cy_conv_desc* d) {
     // only (measured per layer at N = 32: the pooled-on-load layers -- four synchronous loads per halo item -- and the
     // 14 x 14 layers -- 98-pixel tiles -- are faster in the unspecialised kernel; on the 32-channel blocks of the
     // 224^2 level four loader waves could not issue a tile's gathers fast enough: Conv1b 89 -> 109 us).  With the
-    // loaders on LDS-DMA and 4 x 4 patches as k-steps the 32-channel blocks take it too.
+    // loaders on LDS-DMA and 4 x 4 patches as k-steps the 32-channel blocks take it too, and so do the 14 x 14
+    // layers (Conv5a / Conv5b, both passes paired: 74 -> 58 and 131 -> 116 us).
     // DMA: 32-bit buffer offsets (every tensor below 2 GiB; the caller's total batch is in d->N), a ci block reads
     // one source.
     const long lim = (1L << 31) - 1, eb = 2;
     const long opx = (long)d->N * d->H * d->W;
     const long px1 = d->mode1 == CY_SRC_UP2 ? opx / 4 : opx;
     const bool small = px1 * d->ld1 * eb <= lim && (!d->C2 || opx * d->ld2 * eb <= lim) && opx * d->ldo * eb <= lim;
-    const bool base = p.twelve && spec_enabled && d->mode1 != CY_SRC_POOL2 && d->W >= 28;
+    static const int min_w = [] {  // (CY_WGRAD_MINW: experiments)
+      const char* e = getenv("CY_WGRAD_MINW");
+      return e ? atoi(e) : 14;
+    }();
+    const bool base = p.twelve && spec_enabled && d->mode1 != CY_SRC_POOL2 && d->W >= min_w;
     const bool dma_ok = dma_enabled && small && (d->C2 == 0 || d->C1 % (32 * p.wci) == 0);
     const bool patches = dma_ok && blk_enabled && p.TH % 4 == 0 && p.TW % 4 == 0;
     p.spec = base && ((p.wco == 2 && p.wci == 2) || (p.wco == 1 && patches));
