@@ -33,6 +33,7 @@ __global__ void __launch_bounds__(1024)
   }
   double s1 = 0.0, s2 = 0.0;
   if (c < C && use_batch_stats) {
+#pragma unroll 8  // (the loads of eight rounds in flight; same order of additions)
     for (int p = sl; p < P; p += 256) {
       s1 += (double)partials[((size_t)p * 2 + 0) * C + c];
       s2 += (double)partials[((size_t)p * 2 + 1) * C + c];
@@ -203,7 +204,10 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const float* 
 }
 
 // partial sums of dz and dz*xhat.  thread = (pixel lane, group of 8 channels)
-template <typename T>
+// DEEP: four pixels per round with all eight loads requested first -- for the small maps, whose few workgroups
+// are latency-bound (14 x 14 x 16 images: 21 -> 14 us); on the large maps the 64 extra registers cost occupancy and
+// bandwidth (23 vs 20 us at 112 x 112 x 16), so the host picks per launch
+template <typename T, bool DEEP>
 __global__ void __launch_bounds__(256)
     bn_relu_bwd_reduce_kernel(const T* __restrict__ da, int ld_da, const T* __restrict__ y,
                               const float* __restrict__ scale, const float* __restrict__ shift,
@@ -242,6 +246,7 @@ __global__ void __launch_bounds__(256)
       // pixels and the dependent form paid one memory latency per pixel (14 us on a 3 MB map).  Same order of
       // additions per thread as the one-pixel loop.
       long p = p0 + prow;
+      if constexpr (DEEP)
       for (; p + 3L * rows < p1; p += 4L * rows) {
         float d[4][8], v[4][8];
 #pragma unroll
@@ -312,6 +317,7 @@ __global__ void __launch_bounds__(256)
   }
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
+#pragma unroll 8  // (the loads of eight rounds in flight; same order of additions)
     for (int p = sl; p < P; p += 64) {
       s1 += (double)partials[((size_t)p * 2 + 0) * C + c];
       s2 += (double)partials[((size_t)p * 2 + 1) * C + c];
@@ -527,9 +533,10 @@ int cy_bn_relu_apply_pool(const void* y, const float* scale, const float* shift,
 
 int cy_bn_bwd_num_partials(long npix, int C) {
   (void)C;
-  // (32 / 64 / 256 pixels per workgroup measured the same kernel time within 2 % and a slower finalize for the
-  //  finer splits: the kernel is at ~80 % of the HBM rate on every layer size of the C2 step, not latency-bound)
+  // 128 pixels per workgroup; small maps (fewer than 512 such workgroups) get 32 pixels per workgroup and the
+  // deep-prefetch form of the kernel
   long b = (npix + 127) / 128;
+  if (b < 512) b = (npix + 31) / 32 < 512 ? (npix + 31) / 32 : 511;
   if (b > 1024) b = 1024;
   if (b < 1) b = 1;
   return (int)b;
@@ -546,20 +553,20 @@ int cy_bn_relu_bwd_reduce(const void* da, int ld_da, const void* y, const float*
   const size_t smem = (size_t)2 * rows * gpp * 8 * sizeof(float);
   const int grid = cy_bn_bwd_num_partials(npix, C);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CY_BF16)
-    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), smem, st,
-                       (const bf16*)da, ld_da, (const bf16*)y, scale, shift, mean, invstd,
-                       partials, npix, C);
-  else if (dtype == CY_F16)
-    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<f16>, dim3(grid), dim3(256), smem, st,
-                       (const f16*)da, ld_da, (const f16*)y, scale, shift, mean, invstd,
-                       partials, npix, C);
-  else if (dtype == CY_F32)
-    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<float>, dim3(grid), dim3(256), smem, st,
-                       (const float*)da, ld_da, (const float*)y, scale, shift, mean, invstd,
-                       partials, npix, C);
-  else
+  const bool deep = grid < 512;
+#define CY_BN_RED(TT, DD)                                                                                          \
+  hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<TT, DD>), dim3(grid), dim3(256), smem, st, (const TT*)da, ld_da,   \
+                     (const TT*)y, scale, shift, mean, invstd, partials, npix, C)
+  if (dtype == CY_BF16) {
+    if (deep) CY_BN_RED(bf16, true); else CY_BN_RED(bf16, false);
+  } else if (dtype == CY_F16) {
+    if (deep) CY_BN_RED(f16, true); else CY_BN_RED(f16, false);
+  } else if (dtype == CY_F32) {
+    if (deep) CY_BN_RED(float, true); else CY_BN_RED(float, false);
+  } else {
     return CY_ERR_DTYPE;
+  }
+#undef CY_BN_RED
   CY_CHECK_LAUNCH();
   return CY_OK;
 }
