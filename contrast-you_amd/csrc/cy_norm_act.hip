@@ -384,15 +384,30 @@ __global__ void __launch_bounds__(256)
 }
 
 // ------------------------------------------------------------------ pool / upsample backward
-template <typename T>
+// STATS: the gradient this kernel writes is the dA of the block's last BatchNorm: its backward sums (sum dz, sum dz*xhat
+// with dz = dA where relu(bn(y)) is active) are taken from the values in registers -- one extra read of y instead of the
+// separate reduce pass over (dA, y).  One partial row per workgroup, lanes of a channel group combined in a fixed order;
+// the sums use the ROUNDED gradient, i.e. what bn_relu_bwd_reduce_kernel would read back.  Needs 256 % (C/8) == 0.
+template <typename T, bool STATS>
 __global__ void __launch_bounds__(256)
     maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dpool,
                         const T* __restrict__ add, int ld_add, T* __restrict__ dx, int N, int H,
-                        int W, int C) {
-  // (H,W) are the POOLED dims; x/dx/add are [N,2H,2W,C]
+                        int W, int C, const T* __restrict__ y, const float* __restrict__ scale,
+                        const float* __restrict__ shift, const float* __restrict__ mean,
+                        const float* __restrict__ invstd, float* __restrict__ partials) {
+  // (H,W) are the POOLED dims; x/dx/add/y are [N,2H,2W,C]
   const int G = C / 8;
   const long total = (long)N * H * W * G;
   const int W2 = 2 * W;
+  float a1[8], a2[8], sc[8], sh[8], mu[8], is[8];
+  if constexpr (STATS) {
+    const int g = threadIdx.x % G;  // (the grid stride is a multiple of G: a thread keeps its channel group)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a1[j] = a2[j] = 0.f;
+      sc[j] = scale[g * 8 + j], sh[j] = shift[g * 8 + j], mu[j] = mean[g * 8 + j], is[j] = invstd[g * 8 + j];
+    }
+  }
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int g = (int)(i % G);
     long p = i / G;
@@ -430,6 +445,40 @@ __global__ void __launch_bounds__(256)
         for (int j = 0; j < 8; ++j) o[k][j] += a8[j];
       }
       store8<T>(dx + q[k] * C + g * 8, o[k]);
+      if constexpr (STATS) {
+        float yv[8], d[8];
+        load8<T>(y + q[k] * C + g * 8, yv);
+        if constexpr (sizeof(T) == 2) {
+          Chunk<T>::unpack(Chunk<T>::pack(o[k]), d);  // the stored (rounded) gradient
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) d[j] = o[k][j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float z = fmaf(sc[j], yv[j], sh[j]);
+          const float dz = z > 0.f ? d[j] : 0.f;
+          a1[j] += dz;
+          a2[j] += dz * ((yv[j] - mu[j]) * is[j]);
+        }
+      }
+    }
+  }
+  if constexpr (STATS) {
+    __shared__ float sred[256 * 16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sred[threadIdx.x * 16 + j] = a1[j];
+      sred[threadIdx.x * 16 + 8 + j] = a2[j];
+    }
+    __syncthreads();
+    const int per_g = 256 / G;
+    for (int e = threadIdx.x; e < 2 * C; e += 256) {
+      const int which = e / C, c = e - which * C;
+      const int g = c >> 3, jj = c & 7;
+      float s = 0.f;
+      for (int k = 0; k < per_g; ++k) s += sred[(g + k * G) * 16 + which * 8 + jj];
+      partials[((size_t)blockIdx.x * 2 + which) * C + c] = s;
     }
   }
 }
@@ -614,17 +663,45 @@ int cy_maxpool2_bwd(const void* x, const void* dpool, const void* add, int ld_ad
   if (C % 8 || (add && (ld_add % 8 || ld_add < C))) return CY_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int grid = stream_grid((long)N * H * W * (C / 8));
-  if (dtype == CY_BF16)
-    hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x,
-                       (const bf16*)dpool, (const bf16*)add, ld_add, (bf16*)dx, N, H, W, C);
-  else if (dtype == CY_F16)
-    hipLaunchKernelGGL(maxpool2_bwd_kernel<f16>, dim3(grid), dim3(256), 0, st, (const f16*)x,
-                       (const f16*)dpool, (const f16*)add, ld_add, (f16*)dx, N, H, W, C);
-  else if (dtype == CY_F32)
-    hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x,
-                       (const float*)dpool, (const float*)add, ld_add, (float*)dx, N, H, W, C);
-  else
-    return CY_ERR_DTYPE;
+#define CY_POOL_BWD(TT)                                                                                          \
+  hipLaunchKernelGGL((maxpool2_bwd_kernel<TT, false>), dim3(grid), dim3(256), 0, st, (const TT*)x,              \
+                     (const TT*)dpool, (const TT*)add, ld_add, (TT*)dx, N, H, W, C, (const TT*)nullptr, nullptr, \
+                     nullptr, nullptr, nullptr, nullptr)
+  if (dtype == CY_BF16) CY_POOL_BWD(bf16);
+  else if (dtype == CY_F16) CY_POOL_BWD(f16);
+  else if (dtype == CY_F32) CY_POOL_BWD(float);
+  else return CY_ERR_DTYPE;
+#undef CY_POOL_BWD
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+/* partial rows cy_maxpool2_bwd_bn writes (a function of the geometry only), or CY_ERR_SHAPE when the fused form
+ * does not apply (the channel groups must divide a workgroup) */
+int cy_maxpool2_bwd_bn_num_partials(int N, int H, int W, int C) {
+  if (N <= 0 || H <= 0 || W <= 0 || C % 8 || C / 8 > 256 || 256 % (C / 8)) return CY_ERR_SHAPE;
+  long b = ((long)N * H * W * (C / 8) + 255) / 256;
+  if (b > 1024) b = 1024;
+  return (int)(b < 1 ? 1 : b);
+}
+
+int cy_maxpool2_bwd_bn(const void* x, const void* dpool, const void* add, int ld_add, void* dx, const void* y,
+                       const float* scale, const float* shift, const float* mean, const float* invstd,
+                       float* partials, int N, int H, int W, int C, int dtype, void* stream) {
+  if (!x || !dpool || !dx || !y || !scale || !shift || !mean || !invstd || !partials) return CY_ERR_ARG;
+  if (add && (ld_add % 8 || ld_add < C)) return CY_ERR_SHAPE;
+  const int grid = cy_maxpool2_bwd_bn_num_partials(N, H, W, C);
+  if (grid < 0) return grid;
+  hipStream_t st = (hipStream_t)stream;
+#define CY_POOL_BWD(TT)                                                                                      \
+  hipLaunchKernelGGL((maxpool2_bwd_kernel<TT, true>), dim3(grid), dim3(256), 0, st, (const TT*)x,           \
+                     (const TT*)dpool, (const TT*)add, ld_add, (TT*)dx, N, H, W, C, (const TT*)y, scale, shift, \
+                     mean, invstd, partials)
+  if (dtype == CY_BF16) CY_POOL_BWD(bf16);
+  else if (dtype == CY_F16) CY_POOL_BWD(f16);
+  else if (dtype == CY_F32) CY_POOL_BWD(float);
+  else return CY_ERR_DTYPE;
+#undef CY_POOL_BWD
   CY_CHECK_LAUNCH();
   return CY_OK;
 }

@@ -102,6 +102,8 @@ _SIGS = {
     "cy_bn_bwd_finalize": (c_int, [_P, c_int, c_int, _P, _P, _P, c_double, c_int, _P, _P, c_int, _P, _P]),
     "cy_bn_relu_bwd_apply": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_long, c_int, c_int, _P]),
     "cy_maxpool2_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cy_maxpool2_bwd_bn_num_partials": (c_int, [c_int, c_int, c_int, c_int]),
+    "cy_maxpool2_bwd_bn": (c_int, [_P, _P, _P, c_int] + [_P] * 7 + [c_int] * 5 + [_P]),
     "cy_upsample2_bwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cy_head1x1_fwd": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, c_int, _P]),
     "cy_head1x1_bwd_ws_bytes": (c_size_t, [c_long, c_int, c_int]),
@@ -183,6 +185,7 @@ _SIGS = {
 # functions whose int return is a count / size, not a status
 _COUNT_FUNCS = {"cy_abi_version", "cy_conv3x3_num_partials", "cy_conv3x3_first_num_partials",
                 "cy_bn_bwd_num_partials"}
+# (cy_maxpool2_bwd_bn_num_partials returns a count or a negative status: the caller tests the sign itself)
 
 _lib = None
 

@@ -300,22 +300,24 @@ class ConvChainFn(torch.autograd.Function):
         ops.ensure_backward_join()
         cfg, nconv, dt = ctx.cfg, ctx.nconv, ctx.dt
         t = list(ctx.saved_tensors)
-        if cfg.pool_out:
-            out = t.pop()
-            if dout is None and dpooled is None:
-                return (None,) * (3 + 3 * nconv)
-            if dpooled is not None:
-                if dpooled.dtype != out.dtype:
-                    dpooled = dpooled.to(out.dtype)
-                add = None
-                if dout is not None:
-                    add = ops.to_nhwc(dout if dout.dtype == out.dtype else dout.to(out.dtype))
-                dout = ops.maxpool2_bwd(out, ops.to_nhwc(dpooled), add=add)  # (+ the skip branch's gradient)
+        out = t.pop() if cfg.pool_out else None
+        if cfg.pool_out and dout is None and dpooled is None:
+            return (None,) * (3 + 3 * nconv)
         x1 = t.pop(0)
         x2 = t.pop(0) if ctx.has_x2 else None
         params = [t.pop(0) for _ in range(3 * nconv)]
         ys = [t.pop(0) for _ in range(nconv)]
         coefs = [tuple(t.pop(0) for _ in range(4)) for _ in range(nconv)]
+        pool_partials = None
+        if cfg.pool_out and dpooled is not None:
+            if dpooled.dtype != out.dtype:
+                dpooled = dpooled.to(out.dtype)
+            add = None
+            if dout is not None:
+                add = ops.to_nhwc(dout if dout.dtype == out.dtype else dout.to(out.dtype))
+            # the pooled branch's gradient through the arg-max, + the skip branch's gradient; the same launch takes
+            # the backward sums of the block's last BatchNorm (whose dA it is writing)
+            dout, pool_partials = ops.maxpool2_bwd_bn(out, ops.to_nhwc(dpooled), add, ys[-1], *coefs[-1])
         need = ctx.needs_input_grad  # (cfg, x1, x2, *params)
         grads_p: List[Optional[Tensor]] = [None] * (3 * nconv)
         da = dout
@@ -332,7 +334,8 @@ class ConvChainFn(torch.autograd.Function):
                 gsink = None
             dy, dgamma, dbeta = ops.bn_relu_bwd(da, ys[i], scale, shift, mean, invstd, ctx.batch_flags[i],
                                                 dgamma_out=gsink, dbeta_out=bsink,
-                                                want_param_grads=need_g or need_b)
+                                                want_param_grads=need_g or need_b,
+                                                partials=pool_partials if i == nconv - 1 else None)
             if need_g:
                 grads_p[3 * i + 1] = dgamma
             if need_b:

@@ -7,6 +7,7 @@ Activations are logical [N,C,H,W] tensors in channels_last memory (= NHWC).
 from __future__ import annotations
 
 import contextlib
+import os
 import ctypes as C
 from typing import Optional, Tuple
 
@@ -641,9 +642,10 @@ def bn_relu_apply_pool(y: Tensor, scale: Tensor, shift: Tensor) -> Tuple[Tensor,
 
 def bn_relu_bwd(da: Tensor, y: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor,
                 batch_stats: bool, dgamma_out: Optional[Tensor] = None, dbeta_out: Optional[Tensor] = None,
-                want_param_grads: bool = True):
+                want_param_grads: bool = True, partials: Optional[Tensor] = None):
     """Backward of a = relu(bn(y)): returns (dy, dgamma, dbeta).  With dgamma_out/dbeta_out the
-    parameter gradients are ADDED into those buffers (and returned as None)."""
+    parameter gradients are ADDED into those buffers (and returned as None).  `partials`: the reduction pass
+    was already done by the kernel that produced `da` (maxpool2_bwd_bn)."""
     N, Cc, H, W = y.shape
     npix = N * H * W
     dev = y.device
@@ -651,11 +653,14 @@ def bn_relu_bwd(da: Tensor, y: Tensor, scale: Tensor, shift: Tensor, mean: Tenso
     if da.dtype != y.dtype:
         da = da.to(y.dtype)
     da = to_nhwc(da)
-    npart = _lib.call("cy_bn_bwd_num_partials", npix, Cc)
-    part = _f32(npart * 2 * Cc, dev)
-    _lib.call("cy_bn_relu_bwd_reduce", da.data_ptr(), Cc, y.data_ptr(), scale.data_ptr(),
-              shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), part.data_ptr(), npix, Cc, dt,
-              _stream())
+    if partials is not None:
+        part, npart = partials, partials.shape[0]
+    else:
+        npart = _lib.call("cy_bn_bwd_num_partials", npix, Cc)
+        part = _f32(npart * 2 * Cc, dev)
+        _lib.call("cy_bn_relu_bwd_reduce", da.data_ptr(), Cc, y.data_ptr(), scale.data_ptr(),
+                  shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), part.data_ptr(), npix, Cc, dt,
+                  _stream())
     coef = _f32(2 * Cc, dev)
     acc = dgamma_out is not None
     dgamma = dbeta = None
@@ -689,6 +694,25 @@ def maxpool2_bwd(x: Tensor, dpool: Tensor, add: Optional[Tensor] = None) -> Tens
     _lib.call("cy_maxpool2_bwd", x.data_ptr(), dpool.data_ptr(), _ptr(add), Cc, dx.data_ptr(), N,
               H2 // 2, W2 // 2, Cc, dtype_code(x.dtype), _stream())
     return dx
+
+
+POOL_BN_FUSE = os.environ.get("CY_POOL_BN_FUSE", "1") != "0"  # (A/B switch)
+
+
+def maxpool2_bwd_bn(x: Tensor, dpool: Tensor, add: Optional[Tensor], y: Tensor, scale: Tensor, shift: Tensor,
+                    mean: Tensor, invstd: Tensor) -> Tuple[Tensor, Optional[Tensor]]:
+    """maxpool2_bwd whose result is the dA of relu(bn(y)): (dx, partial rows [P, 2, C] of that BatchNorm's backward
+    sums), or (dx, None) where the fused form does not apply (channel groups that do not divide a workgroup)"""
+    N, Cc, H2, W2 = x.shape
+    npart = _lib.load().cy_maxpool2_bwd_bn_num_partials(N, H2 // 2, W2 // 2, Cc) if POOL_BN_FUSE else 0
+    if npart <= 0:
+        return maxpool2_bwd(x, dpool, add), None
+    dx = empty_nhwc(N, Cc, H2, W2, x.dtype, x.device)
+    part = _f32(npart * 2 * Cc, x.device).view(npart, 2, Cc)
+    _lib.call("cy_maxpool2_bwd_bn", x.data_ptr(), dpool.data_ptr(), _ptr(add), Cc, dx.data_ptr(), y.data_ptr(),
+              scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), part.data_ptr(), N,
+              H2 // 2, W2 // 2, Cc, dtype_code(x.dtype), _stream())
+    return dx, part
 
 
 def upsample2_bwd(dup: Tensor) -> Tensor:

@@ -252,6 +252,13 @@ int cy_bn_relu_bwd_apply(const void* da, int ld_da, const void* y, const float* 
 int cy_maxpool2_bwd(const void* x, const void* dpool, const void* add, int ld_add, void* dx, int N,
                     int H, int W, int C, int dtype, void* stream);
 /* dx[N,H,W,C] = sum of the 2x2 block of dup[N,2H,2W,C] (pitch ld_dup). */
+/* cy_maxpool2_bwd whose output is the dA of a BatchNorm+ReLU (the block's last one, y = its raw conv output): also
+ * writes that layer's backward partial sums (what cy_bn_relu_bwd_reduce would compute from dx and y in a second
+ * pass), cy_maxpool2_bwd_bn_num_partials rows of [2][C]; feed them to cy_bn_bwd_finalize. */
+int cy_maxpool2_bwd_bn_num_partials(int N, int H, int W, int C);
+int cy_maxpool2_bwd_bn(const void* x, const void* dpool, const void* add, int ld_add, void* dx, const void* y,
+                       const float* scale, const float* shift, const float* mean, const float* invstd,
+                       float* partials, int N, int H, int W, int C, int dtype, void* stream);
 int cy_upsample2_bwd(const void* dup, int ld_dup, void* dx, int N, int H, int W, int C, int dtype,
                      void* stream);
 

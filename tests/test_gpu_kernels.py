@@ -287,6 +287,33 @@ def test_pool_upsample_bwd(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,hw,N", [(32, 24, 3), (64, 12, 2), (512, 4, 5), (40, 8, 2)])
+def test_pool_bwd_with_bn_backward_sums(C, hw, N, dtype):
+    """maxpool2_bwd_bn = maxpool2_bwd (+ addend) whose second output, fed to the BatchNorm backward instead of its own
+    reduction pass, gives the same dy / dgamma / dbeta (C = 40: five channel groups do not divide a workgroup, the
+    unfused form runs)"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    y = nhwc(rnd(N, C, hw, hw, gen=g) * 1.5, dtype)
+    gamma, beta = rnd(C, gen=g) + 1.2, rnd(C, gen=g) * 0.5
+    yd = cpu(y).double()
+    part = torch.stack([yd.sum(dim=(0, 2, 3)), (yd * yd).sum(dim=(0, 2, 3))]).float().view(1, 2, C).to(DEV)
+    scale, shift, mean, invstd = ops.bn_finalize(part, N * hw * hw, gamma.to(DEV), beta.to(DEV), torch.zeros(C, device=DEV),
+                                                 torch.ones(C, device=DEV), 0.1, 1e-5, True, True, C, DEV)
+    out, _ = ops.bn_relu_apply_pool(y, scale, shift)
+    dpool = nhwc(rnd(N, C, hw // 2, hw // 2, gen=g), dtype)
+    for add in (None, nhwc(rnd(N, C, hw, hw, gen=g), dtype)):
+        dx_ref = ops.maxpool2_bwd(out, dpool, add)
+        dx, partials = ops.maxpool2_bwd_bn(out, dpool, add, y, scale, shift, mean, invstd)
+        assert torch.equal(dx, dx_ref)
+        assert (partials is None) == (C == 40)
+        ref = ops.bn_relu_bwd(dx_ref, y, scale, shift, mean, invstd, True)
+        got = ops.bn_relu_bwd(dx, y, scale, shift, mean, invstd, True, partials=partials)
+        for a, b, what in zip(got, ref, ("dy", "dgamma", "dbeta")):
+            assert_close(a, cpu(b), 2e-5 if what != "dy" else (1e-5 if dtype == torch.float32 else TOL[dtype]), what)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("K", [4, 2, 5, 8])
 def test_head_and_losses(K, dtype):
     ops = _ops()
