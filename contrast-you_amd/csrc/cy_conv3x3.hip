@@ -970,10 +970,170 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Cin = 1, 16-bit storage, Cout <= 32: the nine taps are one k-step of the 32x32x16 MFMA (k = 9 taps + 7 zeros).
+// The VALU kernel above spends ~110 instructions and 18 LDS weight reads per (pixel, 8 couts) -- 36 / 56 us at
+// N = 16 / 32 against the 13 / 25 us the output write takes.  Here a wave computes 32 pixels x 32 couts per MFMA:
+// rows = couts (the weights, in registers for the whole kernel), columns = pixels (the patch, eight LDS reads per
+// lane), so that a lane owns one pixel and 16 couts and stores two 16-byte chunks straight from registers (the plane
+// kernel's epilogue).  Image and weights are rounded to the storage type first -- what the reference's autocast
+// convolution does with its inputs.  Same LDS image, block ranges and one statistics partial per block as above.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    conv3x3_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ out,
+                              float* __restrict__ stats, int N, int H, int W, int Cout) {
+  using M = Mma<T>;
+  __shared__ float sred[4 * 2 * 32];  // [wave][sum | sumsq][cout]
+  extern __shared__ float sx[];        // [rows of this block's pixel range + 2][W + 2], zero left / right columns
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  // A: weights of cout r, taps 8h .. 8h+7 (tap 8 is the only one of the upper half)
+  typename M::Frag fa;
+  {
+    T v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tap = 8 * h + j;
+      v[j] = from_f32<T>((r < Cout && tap < 9) ? w[r * 9 + tap] : 0.f);
+    }
+    fa.v = *reinterpret_cast<const decltype(fa.v)*>(v);
+  }
+  const long npix = (long)N * H * W;
+  const long per = ((npix + gridDim.x - 1) / gridDim.x + 127) / 128 * 128;
+  const long p0 = (long)blockIdx.x * per;
+  const long p1 = p0 + per < npix ? p0 + per : npix;
+  const int W2 = W + 2;
+  const int g0 = p0 < npix ? (int)(p0 / W) : 0;
+  const int g1 = p1 > p0 ? (int)((p1 - 1) / W) : g0;
+  const int nrows = g1 - g0 + 3;
+  for (int rr = tid / 64; rr < nrows; rr += 4) {  // a wave per row
+    const int g = g0 - 1 + rr;
+    const bool rok = g >= 0 && g < N * H;
+    const float* xr = x + (size_t)(rok ? g : 0) * W;  // (Cin = 1: image rows are consecutive)
+    float* dst = sx + (size_t)rr * W2;
+    for (int c = lane; c < W2; c += 64) dst[c] = (rok && c >= 1 && c <= W) ? xr[c - 1] : 0.f;
+  }
+  __syncthreads();
+  float s1[16], s2[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
+  long p = p0 + wave * 32 + r;
+  int wq, hq, n;
+  {
+    const unsigned pu = (unsigned)(p < npix ? p : 0);
+    const unsigned row = pu / (unsigned)W;
+    wq = (int)(pu - row * (unsigned)W);
+    n = (int)(row / (unsigned)H);
+    hq = (int)(row - (unsigned)n * (unsigned)H);
+  }
+  const int dq = 128 / W, dr = 128 - dq * W;  // 128 pixels = dq rows + dr pixels
+  for (long pb = p0 + wave * 32; pb < p1; pb += 128, p += 128) {  // (wave-uniform trip count)
+    const bool valid = p < p1;
+    const float* xc = sx + (size_t)(n * H + hq - g0 + 1) * W2 + wq + 1;
+    typename M::Frag fb;
+    {
+      T v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int dh0 = j / 3 - 1, dw0 = j % 3 - 1;  // tap j (lower half); the upper half has tap 8 = (+1, +1) at j = 0
+        const int dh = h ? 1 : dh0, dw = h ? 1 : dw0;
+        const bool ok = valid && (h ? j == 0 : true) && hq + dh >= 0 && hq + dh < H;
+        v[j] = from_f32<T>(ok ? xc[dh * W2 + dw] : 0.f);
+      }
+      fb.v = *reinterpret_cast<const decltype(fb.v)*>(v);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    M::mma(fa, fb, acc);  // rows = couts: lane (r = pixel, h) holds couts (i & 3) + 8 * (i >> 2) + 4 * h
+    u32x2 packed[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      T pk[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pk[j] = from_f32<T>(acc[4 * g + j]);
+        if (valid) {
+          const float qv = to_f32<T>(pk[j]);
+          s1[4 * g + j] += qv;
+          s2[4 * g + j] += qv * qv;
+        }
+      }
+      packed[g] = __builtin_bit_cast(u32x2, *reinterpret_cast<const s16x4*>(pk));
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+      u32x2 lo = packed[g], hi = packed[g + 1];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(lo[j], hi[j], false, false);
+        lo[j] = sw[0];
+        hi[j] = sw[1];
+      }
+      const int co = 8 * g + 8 * h;
+      if (valid && co < Cout) st16(out + (size_t)p * Cout + co, u32x4{lo[0], lo[1], hi[0], hi[1]});
+    }
+    wq += dr;
+    hq += dq;
+    if (wq >= W) wq -= W, ++hq;
+    while (hq >= H) hq -= H, ++n;
+  }
+  if (stats) {
+    // reduce-scatter over the 32 lanes of each half (the plane kernel's): even lanes end up with one channel each
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool up = (lane & 16) != 0;
+      const float snd1 = up ? s1[i] : s1[i + 8], snd2 = up ? s2[i] : s2[i + 8];
+      const float kp1 = up ? s1[i + 8] : s1[i], kp2 = up ? s2[i + 8] : s2[i];
+      s1[i] = kp1 + __shfl_xor(snd1, 16, 64);
+      s2[i] = kp2 + __shfl_xor(snd2, 16, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool up = (lane & 8) != 0;
+      const float snd1 = up ? s1[i] : s1[i + 4], snd2 = up ? s2[i] : s2[i + 4];
+      const float kp1 = up ? s1[i + 4] : s1[i], kp2 = up ? s2[i + 4] : s2[i];
+      s1[i] = kp1 + __shfl_xor(snd1, 8, 64);
+      s2[i] = kp2 + __shfl_xor(snd2, 8, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool up = (lane & 4) != 0;
+      const float snd1 = up ? s1[i] : s1[i + 2], snd2 = up ? s2[i] : s2[i + 2];
+      const float kp1 = up ? s1[i + 2] : s1[i], kp2 = up ? s2[i + 2] : s2[i];
+      s1[i] = kp1 + __shfl_xor(snd1, 4, 64);
+      s2[i] = kp2 + __shfl_xor(snd2, 4, 64);
+    }
+    {
+      const bool up = (lane & 2) != 0;
+      const float snd1 = up ? s1[0] : s1[1], snd2 = up ? s2[0] : s2[1];
+      const float kp1 = up ? s1[1] : s1[0], kp2 = up ? s2[1] : s2[0];
+      s1[0] = kp1 + __shfl_xor(snd1, 2, 64);
+      s2[0] = kp2 + __shfl_xor(snd2, 2, 64);
+    }
+    s1[0] += __shfl_xor(s1[0], 1, 64);
+    s2[0] += __shfl_xor(s2[0], 1, 64);
+    const int reg = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    const int col = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if ((lane & 1) == 0) {
+      sred[(wave * 2 + 0) * 32 + col] = s1[0];
+      sred[(wave * 2 + 1) * 32 + col] = s2[0];
+    }
+    __syncthreads();
+    if (tid < 2 * Cout) {
+      const int which = tid / Cout, co = tid % Cout;
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t += sred[(q * 2 + which) * 32 + co];
+      stats[((size_t)blockIdx.x * 2 + which) * Cout + co] = t;
+    }
+  }
+}
+
 int first_conv_blocks(long npix, int Cout, int W) {
   const int ppb = 256 / (Cout / 8);
   long b = (npix + ppb - 1) / ppb;
-  if (b > 2048) b = 2048;  // 8 blocks per CU: a few hundred pixels each at the U-Net's sizes
+  if (b > 2048) b = 2048;  // 8 blocks per CU: a few hundred pixels each at the U-Net's sizes (512 ... 4096: the same time)
   // ... but never more image rows per block than its LDS image holds (96 KB, up to four input channels)
   const long rows_max = (96 * 1024 / 4) / (4 * (W + 2)) - 4;
   const long need = (npix + rows_max * W - 1) / (rows_max > 0 ? rows_max * W : 1);
@@ -1179,6 +1339,29 @@ int cy_conv3x3_first_fwd(const float* x, const float* w, void* out, float* stats
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_first_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
       return CY_ERR_LAUNCH;
     attr_done = true;
+  }
+  static const int first_mfma = [] {  // (CY_FIRST_MFMA=0: the VALU kernel, for A/B runs)
+    const char* e = getenv("CY_FIRST_MFMA");
+    return e ? atoi(e) : 1;
+  }();
+  if (first_mfma && Cin == 1 && Cout <= 32 && (out_dtype == CY_BF16 || out_dtype == CY_F16)) {
+    const long per_m = ((npix + np - 1) / np + 127) / 128 * 128;
+    const size_t smem_m = (size_t)(per_m / W + 4) * (W + 2) * sizeof(float);
+    if (smem_m <= 96 * 1024) {
+      static bool attr_m = false;
+      if (!attr_m) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_first_mfma_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_first_mfma_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+          return CY_ERR_LAUNCH;
+        attr_m = true;
+      }
+      if (out_dtype == CY_BF16)
+        hipLaunchKernelGGL(conv3x3_first_mfma_kernel<bf16>, dim3(np), dim3(256), smem_m, st, x, w, (bf16*)out, stats, N, H, W, Cout);
+      else
+        hipLaunchKernelGGL(conv3x3_first_mfma_kernel<f16>, dim3(np), dim3(256), smem_m, st, x, w, (f16*)out, stats, N, H, W, Cout);
+      CY_CHECK_LAUNCH();
+      return CY_OK;
+    }
   }
   if (out_dtype == CY_BF16)
     hipLaunchKernelGGL(conv3x3_first_kernel<bf16>, dim3(np), dim3(256), smem, st, x, w, (bf16*)out,
