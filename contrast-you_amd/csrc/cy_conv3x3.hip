@@ -580,14 +580,27 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool 
       use = true;
     } else if (bn == 64) {
       use = blocks_big >= 160 && (blocks_big <= 256 || (nccf >= 8 && fills(blocks_big) >= 0.75));
+      // too few 64-row tiles for the chip (56 x 56, 128 -> 64: 56 of them at N = 16): four-wave workgroups on
+      // 16 rows x 64 couts, two per CU (Conv3a data gradient 18 -> 14 us)
+      const int n64 = cy_cdiv((long)N * H, 16) * (W / fc.tw) * (Cout / 64);
+      if (!use && blocks_big < 160 && n64 >= 192 && !(prologue && Cin > 256)) use = true, th = 16;
     } else {
       if (blocks_big >= 192 && (blocks_big <= 256 || (nccf >= 8 && fills(blocks_big) >= 0.85))) {
         use = true;
       } else if (fc.small_ok && blocks_big < 192) {
         th = 16;
         const int blocks_small = cy_cdiv((long)N * H, th) * (W / fc.tw) * (Cout / bn);
+        const int n64 = 2 * blocks_small;  // workgroups of the four-wave 16 x 64 tiling (two per CU)
         if (blocks_small >= 192) {
           use = blocks_small <= 256 || (nccf >= 8 && fills(blocks_small) >= 0.85);
+        } else if (!(prologue && Cin > 256) && (n64 >= 192 || (n64 >= 96 && nccf < 32))) {
+          // too few 16 x 128 tiles for the chip: the same wave tile (64 positions x 64 couts) in four-wave
+          // workgroups of 64 couts -- twice the workgroups, two per CU, each other's load / store phases covered
+          // (28 x 28 at N = 16: 256 -> 256 data gradient 28 -> 22 us, 128 -> 256 forward 20 -> 16; 14 x 14, 256 ->
+          // 512 forward 28 (split-K 4) -> 21); with a long K loop and still few workgroups split-K stays better
+          // (14 x 14, 512 -> 512 data gradient: 32 against 36)
+          bn = 64;
+          use = true;
         } else {
           // too few tiles for the chip: split-K over >= 4 chunks each only where the f32 partial slabs are shared
           // by many cout blocks and the K loop is long (28x28 at N=16, 256 -> 256: 112 workgroups without a
@@ -603,6 +616,7 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool 
       }
     }
     if (flow_cfg == 2 && fc.small_ok) use = true, th = 16, Z = 1;
+    if (flow_cfg == 3 && !(prologue && Cin > 256)) use = true, th = 16, bn = 64, Z = 1;  // (experiment: 4-wave 16 x 64 tiles)
     if (const char* ov = getenv("CY_KSPLIT")) {
       const int z = atoi(ov);
       if (z >= 1) Z = z > nccf ? nccf : z;

@@ -47,7 +47,7 @@ template <typename T, int TH_, int BN_, int WGM_, int WGN_, bool W16_> struct Fl
   static constexpr int NAI = (NGA + NW / 2 - 1) / (NW / 2);    // ... per wave (wave -> plane wave & 1), at most
   static constexpr int NBITEMS = 9 * CPP * (BN / 64);          // 1 KB weight pieces per chunk
   static constexpr int NBI = (NBITEMS + NW - 1) / NW;
-  static constexpr int COEF_MAX = 512;  // prologue channels held in LDS
+  static constexpr int COEF_MAX = NTHR < 512 ? NTHR : 512;  // prologue channels held in LDS (one pair per thread)
   static constexpr int COEF_BYTES = 2 * COEF_MAX * 4;
   static constexpr int TAB_BYTES = ((3 * TH + 4) * 4 + 15) & ~15;
   static constexpr int SMEM = 2 * STAGE + COEF_BYTES + TAB_BYTES;
@@ -588,6 +588,11 @@ int dispatch_conv_flow(const ConvArgs& a, int th, int bn, int tw, hipStream_t st
   if (th == 64 && bn == 64) {
     if (tw == 16) return launch_conv_flow<T, 64, 64, 8, 1, true>(a, st);
     return launch_conv_flow<T, 64, 64, 8, 1, false>(a, st);
+  }
+  if (th == 16 && bn == 64) {  // four waves of 64 positions x 64 couts, two workgroups per CU
+    if (a.scale && a.C1 > 256) return CY_ERR_SHAPE;
+    if (tw == 16) return launch_conv_flow<T, 16, 64, 4, 1, true>(a, st);
+    return launch_conv_flow<T, 16, 64, 4, 1, false>(a, st);
   }
   return CY_ERR_SHAPE;
 }

@@ -33,9 +33,11 @@ def test_every_profiled_conv_instantiation_has_a_parity_case():
 
 def test_plan_query_matches_partials_and_split():
     from cyhip import ops
-    p = ops.conv3x3_plan(16, 28, 28, 256, 0, 256, torch.bfloat16, 0, 1)  # Conv4b at N=16
-    assert p["kernel"] == "conv3x3_flow_kernel" and p["bn"] == 128 and p["th"] == 16 and p["ksplit"] == 1
-    assert p["workgroups"] == 112
+    p = ops.conv3x3_plan(16, 28, 28, 256, 0, 256, torch.bfloat16, 0, 1)  # Conv4b at N=16: four-wave 16 x 64 tiles
+    assert p["kernel"] == "conv3x3_flow_kernel" and p["bn"] == 64 and p["th"] == 16 and p["ksplit"] == 1
+    assert p["workgroups"] == 224
+    pd = ops.conv3x3_plan(16, 14, 14, 512, 0, 256, torch.bfloat16, 0, 0)  # Conv5a data gradient at N=16: 56 such
+    assert pd["kernel"] == "conv3x3_flow_kernel" and pd["bn"] == 128 and pd["ksplit"] == 8  # tiles: split-K stays
     p5 = ops.conv3x3_plan(16, 14, 14, 512, 0, 512, torch.bfloat16, 0, 1)  # Conv5b at N=16: split-K over 8-chunk ranges
     assert p5["kernel"] == "conv3x3_flow_kernel" and p5["ksplit"] == 4 and p5["workgroups"] == 224
     q = ops.conv3x3_plan(16, 28, 28, 128, 0, 256, torch.bfloat16, 1, 0)  # Conv4a: 2x2 max on load stays on the plane kernel
