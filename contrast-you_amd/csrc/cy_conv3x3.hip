@@ -576,7 +576,18 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool 
       return (double)blocks / (256.0 * rounds);
     };
     bool use = false;
-    if (flow_cfg == 1) {
+    // more than a round of four-wave workgroups of 128 positions x 64 couts per wave (32 rows x 64 couts, two per CU:
+    // the big tile's LDS traffic per MFMA, and each other's load / store phases covered): where a launch is several
+    // rounds of work anyway this beats the one-per-CU tiles (N = 32: 64 -> 64 at 112 x 112 65 (plane) -> 57 us,
+    // 128 -> 256 at 56 x 56 data gradient 66 -> 62) -- below that the one-per-CU tiles stay better (Conv3b 41 vs 45)
+    const long n3264 = cy_cdiv((long)N * H, 32) * (W / fc.tw) * (Cout / 64);
+    static const int th3264 = [] {
+      const char* e = getenv("CY_FLOW_3264_MIN");
+      return e ? atoi(e) : 512;
+    }();
+    if (flow_cfg == 0 && n3264 >= th3264 && !(prologue && Cin > 256)) {
+      use = true, th = 32, bn = 64;
+    } else if (flow_cfg == 1) {
       use = true;
     } else if (bn == 64) {
       use = blocks_big >= 160 && (blocks_big <= 256 || (nccf >= 8 && fills(blocks_big) >= 0.75));
@@ -617,6 +628,7 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool 
     }
     if (flow_cfg == 2 && fc.small_ok) use = true, th = 16, Z = 1;
     if (flow_cfg == 3 && !(prologue && Cin > 256)) use = true, th = 16, bn = 64, Z = 1;  // (experiment: 4-wave 16 x 64 tiles)
+    if (flow_cfg == 4 && !(prologue && Cin > 256)) use = true, th = 32, bn = 64, Z = 1;  // (experiment: 4-wave 32 x 64 tiles)
     if (const char* ov = getenv("CY_KSPLIT")) {
       const int z = atoi(ov);
       if (z >= 1) Z = z > nccf ? nccf : z;

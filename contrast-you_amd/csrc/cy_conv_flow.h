@@ -589,6 +589,11 @@ int dispatch_conv_flow(const ConvArgs& a, int th, int bn, int tw, hipStream_t st
     if (tw == 16) return launch_conv_flow<T, 64, 64, 8, 1, true>(a, st);
     return launch_conv_flow<T, 64, 64, 8, 1, false>(a, st);
   }
+  if (th == 32 && bn == 64) {  // four waves of 128 positions x 64 couts, two workgroups per CU
+    if (a.scale && a.C1 > 256) return CY_ERR_SHAPE;
+    if (tw == 16) return launch_conv_flow<T, 32, 64, 4, 1, true>(a, st);
+    return launch_conv_flow<T, 32, 64, 4, 1, false>(a, st);
+  }
   if (th == 16 && bn == 64) {  // four waves of 64 positions x 64 couts, two workgroups per CU
     if (a.scale && a.C1 > 256) return CY_ERR_SHAPE;
     if (tw == 16) return launch_conv_flow<T, 16, 64, 4, 1, true>(a, st);

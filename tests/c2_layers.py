@@ -38,7 +38,7 @@ def conv_kernel_name(plan: dict, dtype_tag: str = "DF16b", cin: int = 0, stats: 
         return ("conv3x3_plane_kernelI" + dtype_tag + i(plan["th"]) + i(plan["bn"]) + i(wgm) + i(wgn) + i(pitch)
                 + b(allt) + b(plan["one_per_cu"]) + "E")
     if plan["kernel"] == "conv3x3_flow_kernel":
-        wgm, wgn = (4, 2) if plan["bn"] == 128 else ((4, 1) if plan["th"] == 16 else (8, 1))
+        wgm, wgn = (4, 2) if plan["bn"] == 128 else ((4, 1) if plan["th"] in (16, 32) else (8, 1))
         return ("conv3x3_flow_kernelI" + dtype_tag + i(plan["th"]) + i(plan["bn"]) + i(wgm) + i(wgn) + b(plan["tw"] == 16) + "E")
     if plan["kernel"] == "conv3x3_stream_kernel":
         return ("conv3x3_stream_kernelI" + dtype_tag + i(cin // 32) + i(plan["bn"] // 32) + b(stats) + b(pro) + "E")
