@@ -341,7 +341,9 @@ def main():
     note(f"timed {a.steps} steps: {dt / a.steps * 1e3:.2f} ms/step")
 
     roof, detail = (None, {})
-    if rank == 0 and not a.no_roofline:
+    if not a.no_roofline:
+        # EVERY rank runs the instrumented steps: they contain the step's collectives (gradient all-reduce, the
+        # embedding all-gather of c5) -- rank 0 alone would wait for partners that have moved on to the barrier
         roof, detail = kernel_roofline(ctx, device)
         note(f"instrumented pass done: {detail}")
     cpu = None
