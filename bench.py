@@ -386,6 +386,10 @@ def main():
                          f"4 classes, UNet max_channel={a.max_channel}, RAdam")),
                        "global_batch": slices, "network_passes_per_step_per_gpu": passes,
                        "parallelism": f"dp{world}",
+                       # data parallel: gradient buckets per step whose all-reduce started on a "gradients final"
+                       # mark inside the backward pass instead of at its end (contrastyou/optim/fused_radam.py)
+                       "dp_early_buckets_per_step": (round(getattr(ctx["optimizer"], "early_buckets", 0) / max(
+                           1, getattr(ctx["optimizer"], "dp_steps", 1)), 2) if world > 1 else None),
                        "step_tflops_per_gpu": None if flops_step is None else round(flops_step / 1e12, 3),
                        "achieved_step_tflops_per_gpu": None if flops_step is None else round(
                            flops_step / per_step / 1e12, 1)},

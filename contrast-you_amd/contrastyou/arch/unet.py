@@ -52,6 +52,7 @@ class _ConvBlock(nn.Module):
         self._first = in_ch <= 4
         self._cfgs = {}
         self._pooled: Optional[Tensor] = None
+        self.ready_tag: Optional[str] = None  # (UNet: "the gradients up to this block are final" mark)
         self.compute_dtype: Optional[torch.dtype] = None
 
     def _cfg(self, mode: int, pool_out: bool = False) -> ChainCfg:
@@ -59,6 +60,7 @@ class _ConvBlock(nn.Module):
         if cfg is None:
             cfg = self._cfgs[(mode, pool_out)] = ChainCfg([self.conv[1], self.conv[4]], mode, self._first, pool_out)
         cfg.dtype = self.compute_dtype
+        cfg.ready_tag = self.ready_tag
         return cfg
 
     def forward(self, x: Tensor, x2: Optional[Tensor] = None, *, pool: bool = False, pool_out: bool = False) -> Tensor:
@@ -89,10 +91,12 @@ class _UpConv(nn.Module):
         )
         self._chain = ChainCfg([self.up[2]], ops.CY_SRC_UP2, False)
         self.compute_dtype: Optional[torch.dtype] = None
+        self.ready_tag: Optional[str] = None
 
     def forward(self, x: Tensor) -> Tensor:
         u = self.up
         self._chain.dtype = self.compute_dtype
+        self._chain.ready_tag = self.ready_tag
         return ConvChainFn.apply(self._chain, x, None, u[1].weight, u[2].weight, u[2].bias)
 
 
@@ -140,6 +144,15 @@ class UNet(nn.Module):
         self._Deconv_1x1 = _Head1x1(ch("Up_conv2"), num_classes, kernel_size=(1, 1), stride=(1, 1),
                                     padding=(0, 0))
         self._compute_dtype: Optional[torch.dtype] = None
+        # Data parallel (contrastyou.optim.FusedRAdam): the backward pass is done with the decoder when Up5's
+        # backward has run, with Conv5 / Conv4 after theirs -- 85 % of the parameters well before it ends.  Those
+        # blocks leave a mark, their parameters carry its name: gradient buckets made of marked parameters are
+        # all-reduced while the rest of the backward pass still runs.
+        for tag, names in (("decoder", self.decoder_names), ("conv5", ("Conv5",)), ("conv4", ("Conv4",))):
+            for n in names:
+                for p in getattr(self, f"_{n}").parameters():
+                    p.__dict__["_cy_ready_tag"] = tag
+        self._Up5.ready_tag, self._Conv5.ready_tag, self._Conv4.ready_tag = "decoder", "conv5", "conv4"
 
     # ---- precision control (None: bf16 under autocast, else f32 verification mode) ----
     @property

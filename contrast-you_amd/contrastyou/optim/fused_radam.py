@@ -88,6 +88,8 @@ class FusedRAdam(torch.optim.Optimizer):
         if data_parallel is None:
             data_parallel = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
         self._dp = data_parallel
+        if data_parallel:
+            ops.marks_wanted = True
         self._flat: List[Optional[FlatParams]] = [None] * len(self.param_groups)
         self._flat_state = {}
 
@@ -191,11 +193,29 @@ class FusedRAdam(torch.optim.Optimizer):
         world = dist.get_world_size(self._pg)
         avg = dist.get_backend(self._pg) == "nccl"  # (gloo has no AVG: sum, then scale)
         self._inflight = []
+        # Buckets whose parameters all carry a "gradients final" mark of this step (the decoder, Conv5, Conv4:
+        # contrastyou/arch/unet.py) are reduced on a communication stream that waits for those marks only -- the
+        # rest of the backward pass (eager or a replayed graph) is still running then.  Everything else waits for
+        # the whole pass, as before.
+        marks = ops.take_ready_marks() if torch.cuda.is_available() else {}
+        comm = None
+        self.dp_steps = getattr(self, "dp_steps", 0) + 1
         for gi, f in enumerate(self._flat):
             for a, b, i, j in self._buckets(f):
                 view = f.grad[a:b]
-                h = dist.all_reduce(view, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self._pg,
-                                    async_op=True)
+                tags = {p.__dict__.get("_cy_ready_tag") for p in f.params[i:j]}
+                early = bool(marks) and None not in tags and all(t in marks for t in tags)
+                if early:
+                    if comm is None:
+                        comm = ops.side_stream(view.device, "comm")
+                    ops.stream_wait_marks(comm, [marks[t] for t in tags], view.device)
+                    with torch.cuda.stream(comm):
+                        h = dist.all_reduce(view, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM,
+                                            group=self._pg, async_op=True)
+                    self.early_buckets = getattr(self, "early_buckets", 0) + 1
+                else:
+                    h = dist.all_reduce(view, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self._pg,
+                                        async_op=True)
                 self._inflight.append((gi, i, j, view, h, None if avg else world))
         if wait:
             self._wait_inflight()

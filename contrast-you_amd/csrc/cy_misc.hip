@@ -293,4 +293,17 @@ int cy_debug_event_destroy(void* ev) {
   return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? CY_OK : CY_ERR_LAUNCH;
 }
 
+// Cross-stream hand-over out of a captured HIP graph (data-parallel training: the gradient buckets whose layers
+// are done are all-reduced while the rest of the backward graph still runs).  An external event-record node is what
+// CUDA offers for this; hipEventRecordWithFlags(hipEventRecordExternal) returns hipErrorInvalidValue under capture on
+// this runtime, so the hand-over is a counter in device memory: a kernel of the graph increments it, a stream outside
+// the graph waits until it has reached the number of the current step (hipStreamWaitValue32, >=).
+int cy_stream_wait_value(void* stream, const int* counter, int at_least) {
+  if (!counter) return CY_ERR_ARG;
+  return hipStreamWaitValue32((hipStream_t)stream, (void*)counter, (uint32_t)at_least, hipStreamWaitValueGte,
+                              0xffffffffu) == hipSuccess
+             ? CY_OK
+             : CY_ERR_LAUNCH;
+}
+
 }  // extern "C"

@@ -72,6 +72,7 @@ _SIGS = {
     "cy_debug_event_record": (c_int, [_P, _P]),
     "cy_debug_event_elapsed_us": (c_int, [_P, _P, POINTER(C.c_float)]),
     "cy_debug_event_destroy": (c_int, [_P]),
+    "cy_stream_wait_value": (c_int, [_P, _P, c_int]),
     "cy_conv3x3_packed_dims": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "cy_conv3x3_packed_elems": (C.c_longlong, [c_int, c_int, c_int]),
     "cy_conv3x3_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),

@@ -122,6 +122,8 @@ def begin_pass() -> int:
     _pass_serial += 1
     if _step_first_pass is None and torch.is_grad_enabled():  # (evaluation passes are not differentiated)
         _step_first_pass = _pass_serial
+        if ops.marks_wanted and torch.cuda.is_available():
+            ops.begin_step_marks(torch.cuda.current_device())  # (data parallel: a new step's serial)
     return _pass_serial
 
 
@@ -213,6 +215,9 @@ class ChainCfg:
         self.mode = mode  # ops.CY_SRC_* for the first conv's source 1
         self.first = first  # first conv reads the f32 image (Cin <= 4)
         self.pool_out = pool_out  # second output: MaxPool2d(2) of the block output (written by the same launch)
+        # data parallel: when this block's backward has run for the last time in a step, the gradients of every
+        # parameter carrying this tag or an earlier one are final (ops.grad_ready_mark)
+        self.ready_tag: Optional[str] = None
         self.dtype: Optional[torch.dtype] = None  # forced compute dtype (None = infer)
 
 
@@ -393,6 +398,9 @@ class ConvChainFn(torch.autograd.Function):
                             dx1 = dl1
                         if dx1.dtype != ctx.x_dtype:
                             dx1 = dx1.to(ctx.x_dtype)
+        if cfg.ready_tag is not None and (_step_first_pass is None or ctx.pass_id == _step_first_pass):
+            # (the pass evaluated first is differentiated last: nothing of this block is parked or still to come)
+            ops.grad_ready_mark(cfg.ready_tag, da.device)
         return (None, dx1, dx2, *grads_p)
 
 

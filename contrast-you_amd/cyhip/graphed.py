@@ -150,6 +150,8 @@ class GraphedTwoPass:
             with ctx:
                 self._graphed = torch.cuda.make_graphed_callables(self._wrapper, (xa, xb), allow_unused_input=True)
             self._touched = [p for p in params if p.__dict__.get("_cy_touched")]
+            # the capture recorded the "gradients final" marks as external event nodes: every replay records them
+            self._marks = ops.take_ready_marks()
         finally:
             ops.CAPTURING = False
             ops.ASYNC_WGRAD = async_wgrad
@@ -166,11 +168,19 @@ class GraphedTwoPass:
 
     def __call__(self, xa: Tensor, xb: Tensor) -> Tuple[Tensor, Tensor]:
         ops.note_home_stream(xa.device)
+        ops.begin_step_marks(xa.device)  # (data parallel: the step's serial, read by the mark copies of the replay)
         out = self._graphed(xa, xb)
         out = tuple(o if k else _Canary.apply(o, self._anchor, self) for o, k in zip(out, self.need_grad))
         ya, yb, feats = out[0], out[1], out[2:]
         for p in self._touched:  # what ops.grad_sink does on the eager path
             p.__dict__["_cy_touched"] = True
+        marks = getattr(self, "_marks", None)
+        if marks:
+            # the backward graph leaves the marks of its capture again -- once it replays: they count from the moment
+            # a gradient arrives at the passes' outputs (a consumer waiting for a mark that never comes would hang)
+            for o in (ya, yb):
+                if o.requires_grad:
+                    o.register_hook(lambda g, m=marks: (ops.set_ready_marks(m), g)[1])
         _fire_taps(self.model, self.taps, feats)
         return ya, yb
 

@@ -346,7 +346,10 @@ def side_stream(device, role: str = "wgrad") -> "torch.cuda.Stream":
         idx = torch.cuda.current_device()
     st = _side_streams.get((idx, role))
     if st is None:
-        st = _side_streams[(idx, role)] = torch.cuda.Stream(device=idx)
+        # "comm" waits on a word in memory (stream_wait_marks): a waiting packet stalls every stream that shares its
+        # hardware queue, and streams of one priority are multiplexed onto a few queues -- a stream of another
+        # priority cannot share one with the streams that compute
+        st = _side_streams[(idx, role)] = torch.cuda.Stream(device=idx, priority=-1 if role == "comm" else 0)
     return st
 
 
@@ -449,6 +452,99 @@ def join_side_streams(onto: Optional["torch.cuda.Stream"] = None) -> None:
         if tgt is None:
             tgt = torch.cuda.current_stream(st.device)
         tgt.wait_stream(st)
+
+
+# ---- "these gradients are final" marks for the data-parallel optimizer ----------------------------------------------
+# The backward pass finishes the decoder's and the deep encoder blocks' gradients (85 % of the parameters) long before
+# it ends.  A block whose backward has run for the LAST time in a step leaves a mark; FusedRAdam starts the all-reduce
+# of the buckets whose parameters are all marked on a communication stream that waits for those marks only, while the
+# rest of the backward pass -- eager, or a replayed HIP graph -- still runs.
+# A mark must be visible from OUTSIDE a captured graph.  (CUDA's answer, an external event-record node, is refused by
+# this runtime: hipEventRecordWithFlags(hipEventRecordExternal) returns hipErrorInvalidValue under capture.)  So a mark
+# is a word in device memory: every step has a serial number, kept in a device scalar the host refreshes before the
+# step's first pass; the mark is a tiny copy "flag[tag] <- serial" on a helper stream that waits for every stream
+# carrying work of the step (an ordinary kernel + fork / join, capturable); the consumer stream waits until
+# flag[tag] >= serial (hipStreamWaitValue32).
+# OFF unless CY_DP_EARLY=1: correct in the two-rank rehearsals (tests/test_gpu_distributed.py, gloo, both ranks on one
+# card), but there a step with early buckets took 2.3 x as long as one without -- whether that is the two processes
+# time-slicing one GPU around a queue that sits in a wait packet, or something a one-process-per-GPU RCCL run would
+# also see, cannot be told on a one-GPU box.  Not something to switch on blind for the scaling run.
+DP_EARLY = _os.environ.get("CY_DP_EARLY", "0") == "1"
+marks_wanted = False   # set by a data-parallel FusedRAdam
+MARK_TAGS = ("decoder", "conv5", "conv4")
+_step_id = {}          # device index -> [int32 device scalar, host value]
+_mark_flags = {}       # (device index, tag) -> int32 device scalar
+_ready_marks = {}      # tag -> flag tensor, for the marks left in the current step
+
+
+def _dev_index(device) -> int:
+    idx = torch.device(device).index
+    return torch.cuda.current_device() if idx is None else idx
+
+
+def begin_step_marks(device) -> None:
+    """a new step (forward + backward) begins on `device`: bump its serial.  Outside graph capture only."""
+    if not (marks_wanted and DP_EARLY) or CAPTURING:
+        return
+    idx = _dev_index(device)
+    rec = _step_id.get(idx)
+    if rec is None:
+        rec = _step_id[idx] = [torch.zeros(1, dtype=torch.int32, device=f"cuda:{idx}"), 0]
+        for tag in MARK_TAGS:
+            _mark_flags[(idx, tag)] = torch.zeros(1, dtype=torch.int32, device=f"cuda:{idx}")
+    rec[1] += 1
+    rec[0].fill_(rec[1])
+    _ready_marks.clear()
+
+
+def grad_ready_mark(tag: str, device) -> None:
+    if not (marks_wanted and DP_EARLY):
+        return
+    idx = _dev_index(device)
+    rec = _step_id.get(idx)
+    if rec is None:
+        return
+    flag = _mark_flags[(idx, tag)]
+    cur = torch.cuda.current_stream(idx)
+    helper = side_stream(idx, "mark")
+    streams = {cur, _home_stream.get(idx, cur)} | {st for (d, role), st in _side_streams.items()
+                                                   if d == idx and role not in ("mark", "comm")}
+    capturing = torch.cuda.is_current_stream_capturing()
+    for st in streams:
+        if capturing and not int(_lib.load().cy_stream_capture_id(st.cuda_stream)):
+            continue  # (a stream outside the capture carries no work of this step)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        helper.wait_event(ev)
+    with torch.cuda.stream(helper):
+        flag.copy_(rec[0])
+    note_side_work(helper)  # joined when the backward pass ends (inside the capture, if there is one)
+    ensure_backward_join()
+    _ready_marks[tag] = flag
+
+
+def take_ready_marks() -> dict:
+    """the marks of the step (tag -> flag), handing them over: the next step starts without any"""
+    m = dict(_ready_marks)
+    _ready_marks.clear()
+    return m
+
+
+def set_ready_marks(marks: dict) -> None:
+    """a replayed backward graph leaves the marks of its capture"""
+    _ready_marks.clear()
+    _ready_marks.update(marks)
+
+
+def clear_ready_marks() -> None:
+    _ready_marks.clear()
+
+
+def stream_wait_marks(stream, flags, device) -> None:
+    """`stream` waits until every flag carries the serial of the current step"""
+    serial = _step_id[_dev_index(device)][1]
+    for flag in flags:
+        _lib.call("cy_stream_wait_value", stream.cuda_stream, flag.data_ptr(), serial)
 
 
 # ---- cross-stream ordering of read-modify-write kernels -----------------------------------------

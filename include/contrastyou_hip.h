@@ -67,6 +67,10 @@ int cy_debug_event_create(void** ev);
 int cy_debug_event_record(void* ev, void* stream);
 int cy_debug_event_elapsed_us(void* e0, void* e1, float* us);
 int cy_debug_event_destroy(void* ev);
+/* Hand-over from a captured HIP graph to a stream outside it (the data-parallel optimizer starts the all-reduce of
+ * the gradient buckets whose layers are done while the rest of the backward graph runs): `stream` waits until the
+ * int32 counter in device memory, which a kernel of the graph increments, is >= at_least. */
+int cy_stream_wait_value(void* stream, const int* counter, int at_least);
 
 /* ------------------------------------------------------------------------
  * 3x3 convolution, stride 1, pad 1, no bias  (nn.Conv2d at

@@ -85,7 +85,9 @@ def _worker(rank, world, port, q, mode):
     _setup_paths()
     graph = mode in ("graph", "bf16_buckets")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      CY_GRAPH_STEP="1" if graph else "0")
+                      CY_GRAPH_STEP="1" if graph else "0",
+                      # the opt-in early start of the marked buckets (cyhip.ops.grad_ready_mark) in one of the modes
+                      CY_DP_EARLY="1" if mode == "bf16_buckets" else "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
@@ -100,6 +102,9 @@ def _worker(rank, world, port, q, mode):
         _run(model, hook, opt, list(labs), list(unls), accumulate_iter=1, bf16=(mode == "bf16_buckets"))
         if mode == "bf16_buckets":
             assert sum(len(opt._buckets(f)) for f in opt._flat) > 4, "the test wants several buckets in flight"
+            # small buckets: some hold only decoder / Conv5 / Conv4 parameters and start on those blocks' marks,
+            # before the backward pass (here: the replayed graph) has ended
+            assert getattr(opt, "early_buckets", 0) >= steps, "no bucket was reduced ahead of the backward pass's end"
         q.put((rank, "ok", _flat(model, hook).numpy()))  # (by value: a tensor would travel as a shared-memory handle)
     except Exception as e:  # noqa: BLE001
         import traceback
