@@ -204,7 +204,14 @@ class FusedRAdam(torch.optim.Optimizer):
             for a, b, i, j in self._buckets(f):
                 view = f.grad[a:b]
                 tags = {p.__dict__.get("_cy_ready_tag") for p in f.params[i:j]}
-                early = bool(marks) and None not in tags and all(t in marks for t in tags)
+                early = bool(marks) and None not in tags
+                if early:
+                    # a mark covers the blocks that finish before it (ops.MARK_TAGS is in backward order): wait for
+                    # the first mark left at or after the latest block of the bucket
+                    last = max(ops.MARK_TAGS.index(t) for t in tags)
+                    cover = [t for t in ops.MARK_TAGS[last:] if t in marks]
+                    early = bool(cover)
+                    tags = {cover[0]} if cover else tags
                 if early:
                     if comm is None:
                         comm = ops.side_stream(view.device, "comm")

@@ -465,10 +465,9 @@ def join_side_streams(onto: Optional["torch.cuda.Stream"] = None) -> None:
 # step's first pass; the mark is a tiny copy "flag[tag] <- serial" on a helper stream that waits for every stream
 # carrying work of the step (an ordinary kernel + fork / join, capturable); the consumer stream waits until
 # flag[tag] >= serial (hipStreamWaitValue32).
-# OFF unless CY_DP_EARLY=1: correct in the two-rank rehearsals (tests/test_gpu_distributed.py, gloo, both ranks on one
-# card), but there a step with early buckets took 2.3 x as long as one without -- whether that is the two processes
-# time-slicing one GPU around a queue that sits in a wait packet, or something a one-process-per-GPU RCCL run would
-# also see, cannot be told on a one-GPU box.  Not something to switch on blind for the scaling run.
+# OFF unless CY_DP_EARLY=1: correct in the two-rank rehearsals (tests/test_gpu_distributed.py), but in one process on a
+# one-rank RCCL group (tools/dp_single_rank.py) the early start costs 0.24 ms of step time -- about what it could
+# hide at N = 8.  Not something to switch on without a multi-GPU measurement.
 DP_EARLY = _os.environ.get("CY_DP_EARLY", "0") == "1"
 marks_wanted = False   # set by a data-parallel FusedRAdam
 MARK_TAGS = ("decoder", "conv5", "conv4")
@@ -497,8 +496,11 @@ def begin_step_marks(device) -> None:
     _ready_marks.clear()
 
 
+_MARK_AT = tuple(t for t in _os.environ.get("CY_DP_MARK_AT", ",".join(MARK_TAGS)).split(",") if t)  # (experiments)
+
+
 def grad_ready_mark(tag: str, device) -> None:
-    if not (marks_wanted and DP_EARLY):
+    if not (marks_wanted and DP_EARLY) or tag not in _MARK_AT:
         return
     idx = _dev_index(device)
     rec = _step_id.get(idx)
@@ -506,6 +508,15 @@ def grad_ready_mark(tag: str, device) -> None:
         return
     flag = _mark_flags[(idx, tag)]
     cur = torch.cuda.current_stream(idx)
+    if torch.cuda.is_current_stream_capturing():
+        # Inside the captured step the weight gradients stay on their pass's stream, and this stream has already
+        # waited for whatever the other pass contributes to the block's parameters (the parked operands' events of the
+        # paired weight gradients, recorded after that pass's BatchNorm finalize; the `ordered` accumulations): the
+        # mark is one 4-byte copy in this stream's own order.  (Forked onto a helper stream it cost 0.35 ms of graph
+        # time per mark -- cross-stream edges are expensive in a replayed graph.)
+        flag.copy_(rec[0])
+        _ready_marks[tag] = flag
+        return
     helper = side_stream(idx, "mark")
     streams = {cur, _home_stream.get(idx, cur)} | {st for (d, role), st in _side_streams.items()
                                                    if d == idx and role not in ("mark", "comm")}
