@@ -162,7 +162,11 @@ class FusedRAdam(torch.optim.Optimizer):
         for f in self._flat:
             f.zero_grad()
 
-    BUCKET_ELEMS = 2 << 20  # ~8 MB of f32 gradients per collective
+    # One collective per parameter group at the U-Net's size (8.6 M parameters = 34.5 MB of f32): nothing overlaps the
+    # collectives but the 40 us of RAdam launches, so fewer, larger messages win (one-rank RCCL, tools/dp_single_rank.py:
+    # 6.72 ms/step with 8 MB buckets, 6.62 with one bucket -- launch overhead alone; larger messages also use the links
+    # better).  Models beyond 64 MB of gradients are cut into several.
+    BUCKET_ELEMS = 16 << 20
 
     def _buckets(self, f: "FlatParams"):
         """parameter-aligned slices [a, b) of a flat buffer, in REVERSE parameter order (the order the backward

@@ -23,6 +23,8 @@ def child():
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{os.environ.get('CY_PORT', '29611')}", world_size=1, rank=0, device_id=dev)
     ctx = bench.build_step(dev, 0, 16, 16, 224, 512)
     ctx["optimizer"]._dp = True
+    if os.environ.get("CY_BUCKET_ELEMS"):
+        type(ctx["optimizer"]).BUCKET_ELEMS = int(os.environ["CY_BUCKET_ELEMS"])
     ops.marks_wanted = True
     bench.run_epoch(ctx, dev, 15, 0)
     torch.cuda.synchronize()
