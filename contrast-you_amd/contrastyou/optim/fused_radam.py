@@ -171,11 +171,16 @@ class FusedRAdam(torch.optim.Optimizer):
     def _buckets(self, f: "FlatParams"):
         """parameter-aligned slices [a, b) of a flat buffer, in REVERSE parameter order (the order the backward
         pass completes gradients in: 1x1 head and decoder first, Conv1 last), ~BUCKET_ELEMS each"""
-        cuts, hi = [], f.numel
+        cuts = []
         j = len(f.params)
+        # With the early start on (ops.DP_EARLY) a bucket never mixes parameters of different "gradients final" marks
+        # (decoder / conv5 / conv4 / unmarked: contrastyou/arch/unet.py) -- one bucket over the whole group would hold the
+        # unmarked Conv1-3, head and projector parameters too and could never start early (ADVICE r03).
+        tag = (lambda q: f.params[q].__dict__.get("_cy_ready_tag")) if ops.DP_EARLY else (lambda q: None)
         while j > 0:
             i = j
-            while i > 0 and f.offsets[j] - f.offsets[i - 1] <= self.BUCKET_ELEMS:
+            while (i > 0 and f.offsets[j] - f.offsets[i - 1] <= self.BUCKET_ELEMS
+                   and tag(i - 1) == tag(j - 1)):
                 i -= 1
             if i == j:  # a single parameter larger than a bucket
                 i = j - 1

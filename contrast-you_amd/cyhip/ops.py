@@ -330,9 +330,8 @@ def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, 
 # 256 CUs on their own.  They are therefore enqueued on a second HIP stream and overlap with the
 # main stream's data-gradient / BN-backward kernels; the optimizer joins the stream before it reads
 # the gradients.  CY_ASYNC_WGRAD=0 keeps everything on one stream.
-import os as _os
 
-ASYNC_WGRAD = _os.environ.get("CY_ASYNC_WGRAD", "1") != "0"
+ASYNC_WGRAD = os.environ.get("CY_ASYNC_WGRAD", "1") != "0"
 CAPTURING = False  # True while a HIP graph of the step is being captured (cyhip.graphed)
 _side_streams = {}
 _side_pending = set()
@@ -468,7 +467,7 @@ def join_side_streams(onto: Optional["torch.cuda.Stream"] = None) -> None:
 # OFF unless CY_DP_EARLY=1: correct in the two-rank rehearsals (tests/test_gpu_distributed.py), but in one process on a
 # one-rank RCCL group (tools/dp_single_rank.py) the early start costs 0.24 ms of step time -- about what it could
 # hide at N = 8.  Not something to switch on without a multi-GPU measurement.
-DP_EARLY = _os.environ.get("CY_DP_EARLY", "0") == "1"
+DP_EARLY = os.environ.get("CY_DP_EARLY", "0") == "1"
 marks_wanted = False   # set by a data-parallel FusedRAdam
 MARK_TAGS = ("decoder", "conv5", "conv4")
 _step_id = {}          # device index -> [int32 device scalar, host value]
@@ -496,7 +495,7 @@ def begin_step_marks(device) -> None:
     _ready_marks.clear()
 
 
-_MARK_AT = tuple(t for t in _os.environ.get("CY_DP_MARK_AT", ",".join(MARK_TAGS)).split(",") if t)  # (experiments)
+_MARK_AT = tuple(t for t in os.environ.get("CY_DP_MARK_AT", ",".join(MARK_TAGS)).split(",") if t)  # (experiments)
 
 
 def grad_ready_mark(tag: str, device) -> None:
@@ -520,10 +519,7 @@ def grad_ready_mark(tag: str, device) -> None:
     helper = side_stream(idx, "mark")
     streams = {cur, _home_stream.get(idx, cur)} | {st for (d, role), st in _side_streams.items()
                                                    if d == idx and role not in ("mark", "comm")}
-    capturing = torch.cuda.is_current_stream_capturing()
-    for st in streams:
-        if capturing and not int(_lib.load().cy_stream_capture_id(st.cuda_stream)):
-            continue  # (a stream outside the capture carries no work of this step)
+    for st in streams:  # (eager mode only: the capturing case returned above)
         ev = torch.cuda.Event()
         ev.record(st)
         helper.wait_event(ev)
@@ -564,7 +560,7 @@ def stream_wait_marks(stream, flags, device) -> None:
 # gradients, batch counters -- must keep the reference's order: every such launch waits for the last
 # launch on the same buffer (if that was on another stream) and leaves an event behind.  The order is
 # the host's enqueue order, so results stay deterministic.
-TWO_STREAM = _os.environ.get("CY_TWO_STREAM", "1") != "0"
+TWO_STREAM = os.environ.get("CY_TWO_STREAM", "1") != "0"
 _order_events = {}
 _multi_stream_live = False  # set by the first fork onto a "pass2" stream; single-stream runs pay nothing
 
@@ -1047,7 +1043,7 @@ def supcon_bwd(P: Tensor, labels, pos_mask, S: Tensor, stats: Tensor, gscale: Te
     return dP
 
 
-SUPCON_FUSED = _os.environ.get("CY_SUPCON_FUSED", "1") != "0"
+SUPCON_FUSED = os.environ.get("CY_SUPCON_FUSED", "1") != "0"
 
 
 def supcon_fused_ok(P: Tensor) -> bool:

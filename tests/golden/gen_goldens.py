@@ -441,6 +441,7 @@ def main():
 
     gen_next_rows(scratch)
     gen_round2(scratch)
+    gen_round3(scratch)
     shutil.rmtree(scratch, ignore_errors=True)
     print("wrote", sorted(p.name for p in OUT.glob("*.npz")))
 

@@ -35,6 +35,9 @@ def child():
     opt = ctx["optimizer"]
     print(f"  CY_DP_EARLY={os.environ.get('CY_DP_EARLY')}: {dt * 1e3:.3f} ms/step, early buckets per step "
           f"{getattr(opt, 'early_buckets', 0) / max(1, getattr(opt, 'dp_steps', 1)):.1f}")
+    if os.environ.get("CY_DP_EARLY") == "1" and not os.environ.get("CY_BUCKET_ELEMS"):
+        # (default bucket size: the buckets are cut at the mark boundaries, so the marked ones do start early)
+        assert getattr(opt, "early_buckets", 0) > 0, "CY_DP_EARLY=1 started no bucket early at the default bucket size"
     dist.destroy_process_group()
 
 
