@@ -180,7 +180,7 @@ class UNet(nn.Module):
         # while the packed images are current, e.g. for the second pass of a step)
         begin_pass()
         prepack(self._packed_conv_weights(), compute_dtype_for(x, self._compute_dtype))
-        with defer_batch_counters():
+        with defer_batch_counters(x.device):
             return self._forward(x, until)
 
     def _packed_conv_weights(self):

@@ -1,0 +1,144 @@
+// BatchNorm sums across workgroups WITHOUT a finalize launch (reference: nn.BatchNorm2d in training mode,
+// contrastyou/arch/unet.py:22,25,40).
+//
+// The per-channel sums a training-mode BatchNorm needs (forward: sum y, sum y^2; backward: sum dz, sum dz*xhat) are
+// produced by hundreds of workgroups.  Rounds 1-3 wrote one f32 partial row per workgroup and reduced the rows with a
+// C/4-workgroup "finalize" launch per BatchNorm layer and direction: 76 launches x 5.4 us + a dependent-launch gap each,
+// all of it on the step's critical path (conv a -> finalize -> conv b).  Here the producers ADD their partials into a
+// small accumulator and the CONSUMER (the next conv's BN+ReLU prologue, the apply kernels, the backward apply kernel)
+// derives the coefficients itself; its first workgroup also leaves them in memory for the backward pass.
+//
+// The accumulation has to be independent of the order in which workgroups arrive (bitwise reproducible steps are a
+// tested property of this build), so it is done in INTEGERS: a partial s is split exactly into
+//     s = hi * 2^-12 + lo * 2^-44,     hi = rint(s * 2^12),  lo = rint((s - hi * 2^-12) * 2^44)
+// (exact for |s| >= 2^-21, otherwise rounded at 2^-44 absolute; |hi| < 2^51 for |s| < 5e11) and both limbs are added with
+// 64-bit integer atomics, which commute.  One fixed scale would have to trade range against resolution; two limbs give
+// 2^-44 resolution over +-2^50 whatever the layer's magnitude.
+//
+// Contention: a 64-byte line takes one atomic request per ~25 ns (MI355X_MICROARCH.md, global float atomics: 0.09 TB/s into
+// one 2304-byte row), so the accumulator has R replicas [R][4][C] and workgroup b adds into replica b & (R - 1); the host
+// picks R ~ workgroups / 32 (a tail of < 1 us), bounded by what a consumer workgroup is asked to read (R * C <= 2048:
+// 64 KB from L2).  Behind the replicas sit R flag words: a partial that is not finite (or beyond the hi limb's range)
+// sets its replica's flag instead of being added, and a consumer that finds a flag set reads every sum as NaN -- a
+// diverged step stays visibly diverged (GradScaler's inf check, the reference's NaN behaviour).
+#pragma once
+#include "cy_common.h"
+
+#include <math.h>
+
+struct BnFold {  // consumer side, forward statistics -> relu(scale * y + shift)
+  const unsigned long long* acc;  // [R][4][C]: sum hi, sum lo, sum of squares hi, lo; null: no fold (coefficients given)
+  int R, C;
+  const float* gamma;  // null: 1
+  const float* beta;   // null: 0
+  double inv_count;    // 1 / (N H W)
+  double unbias;       // count / (count - 1): running_var takes the unbiased estimate (torch)
+  float eps;
+  float* coef;         // [5][C]: scale, shift, mean, invstd, unbiased variance -- written by the leader workgroup; may be null
+};
+
+struct BnBwdFold {  // consumer side, backward sums -> dy = scale * dz + k1 * y + k0
+  const unsigned long long* acc;  // [R][4][C]: sum dz hi, lo, sum dz * xhat hi, lo
+  int R, C;
+  const float* coef;  // the forward pass's [5][C]
+  double inv_count;
+  int batch_stats;    // 0: the BatchNorm used running statistics (k1 = k0 = 0)
+  int accumulate;     // leader: dgamma / dbeta += (1) or = (0)
+  float* dgamma;      // may be null
+  float* dbeta;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ void bn_acc_add(unsigned long long* acc, int R, int C, int rep, int q, int c, float s) {
+  const double d = (double)s;
+  const double h = rint(d * 4096.0);
+  long long hi = (long long)h;
+  long long lo = (long long)rint((d - h * (1.0 / 4096.0)) * 17592186044416.0);
+  if (!(fabsf(s) < 2.0e11f)) {  // inf / nan / out of range: flag the replica (the consumer turns the sums into NaN)
+    atomicOr(acc + (size_t)R * 4 * C + rep, 1ull);
+    return;
+  }
+  unsigned long long* p = acc + ((size_t)(rep * 4 + 2 * q) * C + c);
+  atomicAdd(p, (unsigned long long)hi);  // (agent scope, no return value: executed at the memory side)
+  atomicAdd(p + C, (unsigned long long)lo);
+}
+
+__device__ __forceinline__ double bn_acc_read(const unsigned long long* acc, int R, int C, int q, int c) {
+  long long hi = 0, lo = 0;
+  const unsigned long long* p = acc + (size_t)(2 * q) * C + c;
+  const size_t rs = (size_t)4 * C;
+  int r = 0;
+  for (; r + 4 <= R; r += 4) {  // (four replicas' loads in flight)
+    const unsigned long long h0 = p[(r + 0) * rs], h1 = p[(r + 1) * rs], h2 = p[(r + 2) * rs], h3 = p[(r + 3) * rs];
+    const unsigned long long l0 = p[(r + 0) * rs + C], l1 = p[(r + 1) * rs + C], l2 = p[(r + 2) * rs + C], l3 = p[(r + 3) * rs + C];
+    hi += (long long)(h0 + h1 + h2 + h3);
+    lo += (long long)(l0 + l1 + l2 + l3);
+  }
+  for (; r < R; ++r) {
+    hi += (long long)p[r * rs];
+    lo += (long long)p[r * rs + C];
+  }
+  unsigned long long bad = 0;
+  for (r = 0; r < R; ++r) bad |= acc[(size_t)R * 4 * C + r];
+  if (bad) return __builtin_nan("");
+  return (double)hi * (1.0 / 4096.0) + (double)lo * (1.0 / 17592186044416.0);
+}
+
+// coefficients of channel c; the leader also leaves them (and the batch moments) in f.coef.  Same arithmetic as the
+// finalize kernel of rounds 1-3 (f64 throughout, variance clamped at 0).
+__device__ __forceinline__ void bn_fold_channel(const BnFold& f, int c, bool leader, float& sc, float& sh) {
+  const double s1 = bn_acc_read(f.acc, f.R, f.C, 0, c), s2 = bn_acc_read(f.acc, f.R, f.C, 1, c);
+  const double mean = s1 * f.inv_count;
+  double var = s2 * f.inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double istd = 1.0 / sqrt(var + (double)f.eps);
+  const double g = f.gamma ? (double)f.gamma[c] : 1.0, b = f.beta ? (double)f.beta[c] : 0.0;
+  sc = (float)(g * istd);
+  sh = (float)(b - mean * g * istd);
+  if (leader && f.coef) {
+    f.coef[c] = sc;
+    f.coef[f.C + c] = sh;
+    f.coef[2 * f.C + c] = (float)mean;
+    f.coef[3 * f.C + c] = (float)istd;
+    f.coef[4 * f.C + c] = (float)(var * f.unbias);
+  }
+}
+
+// backward coefficients of channel c: dy = scale * dz + k1 * y + k0; the leader adds the parameter gradients
+__device__ __forceinline__ void bn_bwd_fold_channel(const BnBwdFold& f, int c, bool leader, float& k1o, float& k0o) {
+  const double t1 = bn_acc_read(f.acc, f.R, f.C, 0, c), t2 = bn_acc_read(f.acc, f.R, f.C, 1, c);
+  double k1 = 0.0, k0 = 0.0;
+  if (f.batch_stats) {
+    const double sc = (double)f.coef[c], mu = (double)f.coef[2 * f.C + c], is = (double)f.coef[3 * f.C + c];
+    k1 = -sc * is * t2 * f.inv_count;
+    k0 = -sc * t1 * f.inv_count - k1 * mu;
+  }
+  k1o = (float)k1;
+  k0o = (float)k0;
+  if (leader) {
+    if (f.dbeta) f.dbeta[c] = f.accumulate ? f.dbeta[c] + (float)t1 : (float)t1;
+    if (f.dgamma) f.dgamma[c] = f.accumulate ? f.dgamma[c] + (float)t2 : (float)t2;
+  }
+}
+#endif
+
+static inline BnFold bn_fold_from_abi(const cy_bn_fold* f) {
+  BnFold b;
+  b.acc = (const unsigned long long*)f->acc;
+  b.R = f->R, b.C = f->C;
+  b.gamma = f->gamma, b.beta = f->beta;
+  b.inv_count = 1.0 / f->count;
+  b.unbias = f->count > 1.0 ? f->count / (f->count - 1.0) : 1.0;
+  b.eps = f->eps;
+  b.coef = f->coef;
+  return b;
+}
+
+static inline size_t bn_acc_elems(int C, int R) { return (size_t)R * 4 * C + R; }  // 64-bit words
+
+// replicas for an accumulator of C channels fed by `workgroups` producers (a power of two, 1..32)
+static inline int bn_acc_replicas(int C, int workgroups) {
+  int r = 1;
+  while (r < 32 && r * 32 < workgroups && 2 * r * C <= 2048) r *= 2;
+  return r;
+}

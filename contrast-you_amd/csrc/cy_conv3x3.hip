@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256, 2)
   constexpr int CPO = 32 / EPO;              // chunks per 32-cout row
   float* scratch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
   float* sstat = reinterpret_cast<float*>(smem) + 4 * (32 * 36);
-  const bool do_stats = a.stats != nullptr;
+  const bool do_stats = a.stats != nullptr || a.sacc != nullptr;
   TO* o1 = reinterpret_cast<TO*>(a.out);
   TO* o2 = reinterpret_cast<TO*>(a.out2);
 
@@ -369,8 +369,13 @@ __global__ void __launch_bounds__(256, 2)
         t1 += sstat[(q * 2 + 0) * BN + tid];
         t2 += sstat[(q * 2 + 1) * BN + tid];
       }
-      a.stats[((size_t)tile * 2 + 0) * a.Cout + n0 + tid] = t1;
-      a.stats[((size_t)tile * 2 + 1) * a.Cout + n0 + tid] = t2;
+      if (a.sacc) {
+        bn_acc_add(a.sacc, a.sR, a.Cout, tile & (a.sR - 1), 0, n0 + tid, t1);
+        bn_acc_add(a.sacc, a.sR, a.Cout, tile & (a.sR - 1), 1, n0 + tid, t2);
+      } else {
+        a.stats[((size_t)tile * 2 + 0) * a.Cout + n0 + tid] = t1;
+        a.stats[((size_t)tile * 2 + 1) * a.Cout + n0 + tid] = t2;
+      }
     }
   }
 }
@@ -381,7 +386,7 @@ template <typename TO>
 __global__ void __launch_bounds__(256)
     conv_splitk_finish_kernel(const float* __restrict__ ws, int Z, long npix, int Cout,
                               TO* __restrict__ out, int ldo, TO* __restrict__ out2, int ldo2,
-                              int split_c, float* __restrict__ stats) {
+                              int split_c, float* __restrict__ stats, unsigned long long* sacc, int sR) {
   extern __shared__ float sred[];  // [2][rows][gpp*8]
   const int G = Cout / 8;
   const int gpp = G < 256 ? G : 256;
@@ -430,7 +435,7 @@ __global__ void __launch_bounds__(256)
         }
       }
     }
-    if (stats) {
+    if (stats || sacc) {
       __syncthreads();
       if (active && gg < G) {
 #pragma unroll
@@ -446,7 +451,8 @@ __global__ void __launch_bounds__(256)
         if (c < Cout) {
           float s = 0.f;
           for (int q = 0; q < rows; ++q) s += sred[(which * rows + q) * (gpp * 8) + cl];
-          stats[((size_t)blockIdx.x * 2 + which) * Cout + c] = s;
+          if (sacc) bn_acc_add(sacc, sR, Cout, (int)blockIdx.x & (sR - 1), which, c, s);
+          else stats[((size_t)blockIdx.x * 2 + which) * Cout + c] = s;
         }
       }
     }
@@ -707,7 +713,7 @@ int launch_finish(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
   const size_t smem = (size_t)2 * rows * gpp * 8 * sizeof(float);
   hipLaunchKernelGGL(conv_splitk_finish_kernel<TO>, dim3(p.finish_blocks), dim3(256), smem, st, a.ws,
                      p.ksplit, (long)a.NH * a.W, a.Cout, (TO*)a.out, a.ldo, (TO*)a.out2, a.ldo2,
-                     a.split_c, a.stats);
+                     a.split_c, a.stats, a.sacc, a.sR);
   CY_CHECK_LAUNCH();
   return CY_OK;
 }
@@ -880,7 +886,7 @@ template <typename TO>
 __global__ void __launch_bounds__(256)
     conv3x3_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
                          TO* __restrict__ out, float* __restrict__ stats, int N, int Cin, int H,
-                         int W, int Cout) {
+                         int W, int Cout, unsigned long long* sacc, int sR) {
   // a block walks a contiguous pixel range, 256 / (Cout/8) pixels per iteration; the BN statistics
   // are accumulated in registers over the whole range and reduced ONCE per block (one partial per
   // block: fixed order => deterministic)
@@ -970,7 +976,7 @@ __global__ void __launch_bounds__(256)
     if (wq >= W) wq -= W, ++hq;
     while (hq >= H) hq -= H, ++n;
   }
-  if (stats) {
+  if (stats || sacc) {
     // lanes of a wave that share a cout group (xor-shuffles over the pixel bits), then the four waves
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -991,7 +997,8 @@ __global__ void __launch_bounds__(256)
       float t = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) t += sred[(q * 2 + which) * 64 + co];
-      stats[((size_t)blockIdx.x * 2 + which) * Cout + co] = t;
+      if (sacc) bn_acc_add(sacc, sR, Cout, (int)blockIdx.x & (sR - 1), which, co, t);
+      else stats[((size_t)blockIdx.x * 2 + which) * Cout + co] = t;
     }
   }
 }
@@ -1006,7 +1013,7 @@ __global__ void __launch_bounds__(256)
 template <typename T>
 __global__ void __launch_bounds__(256)
     conv3x3_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ out,
-                              float* __restrict__ stats, int N, int H, int W, int Cout) {
+                              float* __restrict__ stats, int N, int H, int W, int Cout, unsigned long long* sacc, int sR) {
   using M = Mma<T>;
   __shared__ float sred[4 * 2 * 32];  // [wave][sum | sumsq][cout]
   extern __shared__ float sx[];        // [rows of this block's pixel range + 2][W + 2], zero left / right columns
@@ -1104,7 +1111,7 @@ __global__ void __launch_bounds__(256)
     if (wq >= W) wq -= W, ++hq;
     while (hq >= H) hq -= H, ++n;
   }
-  if (stats) {
+  if (stats || sacc) {
     // reduce-scatter over the 32 lanes of each half (the plane kernel's): even lanes end up with one channel each
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1151,7 +1158,8 @@ __global__ void __launch_bounds__(256)
       float t = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) t += sred[(q * 2 + which) * 32 + co];
-      stats[((size_t)blockIdx.x * 2 + which) * Cout + co] = t;
+      if (sacc) bn_acc_add(sacc, sR, Cout, (int)blockIdx.x & (sR - 1), which, co, t);
+      else stats[((size_t)blockIdx.x * 2 + which) * Cout + co] = t;
     }
   }
 }
@@ -1173,7 +1181,7 @@ int first_conv_blocks(long npix, int Cout, int W) {
 // ---------------------------------------------------------------------------
 extern "C" {
 
-int cy_abi_version(void) { return 10; }
+int cy_abi_version(void) { return 11; }
 const char* cy_build_arch(void) { return "gfx950"; }
 
 unsigned long long cy_stream_capture_id(void* stream) {
@@ -1286,18 +1294,44 @@ size_t cy_conv3x3_fwd_ws_bytes(const cy_conv_desc* d) {
   return plan_of(d).ws_bytes;
 }
 
+// workgroups that add into one channel's sums (the streaming kernel sums its wave rows in LDS first)
+static int stat_workgroups_of(const cy_conv_desc* d, const ConvPlan& p) {
+  if (p.stream) return stream_grid(d->C1 + d->C2, d->Cout, cy_cdiv((long)d->N * d->H, kPlaneTH) * (d->W / kPlaneTW), d->prologue != 0);
+  return p.partials;
+}
+
+int cy_conv3x3_stat_workgroups(const cy_conv_desc* d) {
+  if (conv_check(d) != CY_OK) return CY_ERR_ARG;
+  return stat_workgroups_of(d, plan_of(d));
+}
+
+int cy_bn_acc_replicas(int C, int workgroups) { return (C <= 0 || workgroups <= 0) ? CY_ERR_ARG : bn_acc_replicas(C, workgroups); }
+size_t cy_bn_acc_bytes(int C, int R) { return (C <= 0 || R <= 0) ? 0 : bn_acc_elems(C, R) * 8; }
+
 int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, const float* scale,
                    const float* shift, const void* w_packed, void* out, void* out2, float* stats,
                    void* ws, size_t ws_bytes, void* stream) {
+  return cy_conv3x3_fwd_bn(d, src1, src2, nullptr, scale, shift, w_packed, out, out2, stats, nullptr, ws, ws_bytes, stream);
+}
+
+int cy_conv3x3_fwd_bn(const cy_conv_desc* d, const void* src1, const void* src2, const cy_bn_fold* in_fold,
+                      const float* scale, const float* shift, const void* w_packed, void* out, void* out2,
+                      float* stats, const cy_bn_acc* out_acc, void* ws, size_t ws_bytes, void* stream) {
   int rc = conv_check(d);
   if (rc != CY_OK) return rc;
   if (!src1 || !w_packed || !out) return CY_ERR_ARG;
   if (d->C2 && !src2) return CY_ERR_ARG;
-  if (d->prologue && (!scale || !shift)) return CY_ERR_ARG;
+  if (d->prologue && !in_fold && (!scale || !shift)) return CY_ERR_ARG;
+  if (in_fold && (!d->prologue || !in_fold->acc || !in_fold->coef || in_fold->C != d->C1 || in_fold->R < 1 ||
+                  (in_fold->R & (in_fold->R - 1)) || in_fold->count <= 0))
+    return CY_ERR_ARG;
+  if (out_acc && (stats || !out_acc->acc || out_acc->C != d->Cout || out_acc->R < 1 || (out_acc->R & (out_acc->R - 1))))
+    return CY_ERR_ARG;
   if (d->split_c > 0 && !out2) return CY_ERR_ARG;
   ConvArgs a = {};
   a.src1 = src1, a.src2 = src2, a.scale = scale, a.shift = shift, a.w = w_packed;
   a.out = out, a.out2 = out2, a.stats = stats;
+  if (out_acc) a.sacc = (unsigned long long*)out_acc->acc, a.sR = out_acc->R;
   a.N = d->N, a.H = d->H, a.W = d->W, a.NH = d->N * d->H;
   a.C1 = d->C1, a.C2 = d->C2, a.Cout = d->Cout;
   a.mode1 = d->mode1, a.prologue = d->prologue;
@@ -1325,6 +1359,21 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
   a.ws = (float*)ws;
   if (p.ksplit > 1 && (!ws || ws_bytes < p.ws_bytes)) return CY_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  if (in_fold) {
+    // the flow and streaming kernels derive the coefficients in place; the register-staged kernels (plane, igemm:
+    // every thread fetches its channels' pairs per chunk) take them from memory after a fold launch
+    static const int fold_in_kernel = [] {  // (CY_BN_FOLD_IN_KERNEL=0: always the separate launch, A/B runs)
+      const char* e = getenv("CY_BN_FOLD_IN_KERNEL");
+      return e ? atoi(e) : 1;
+    }();
+    if ((p.flow || p.stream) && fold_in_kernel) {
+      a.fold = bn_fold_from_abi(in_fold);
+    } else {
+      rc = cy_bn_fold_coef(in_fold, stream);
+      if (rc != CY_OK) return rc;
+      a.scale = in_fold->coef, a.shift = in_fold->coef + in_fold->C;
+    }
+  }
   rc = d->in_dtype == CY_BF16 ? dispatch_conv<bf16>(a, p, st)
        : d->in_dtype == CY_F16 ? dispatch_conv<f16>(a, p, st) : dispatch_conv<float>(a, p, st);
   if (rc != CY_OK || p.ksplit == 1) return rc;
@@ -1344,8 +1393,22 @@ int cy_conv3x3_first_num_partials(int N, int H, int W, int Cout) {
   return b < 0 ? CY_ERR_SHAPE : b;
 }
 
+static int first_fwd_impl(const float* x, const float* w, void* out, float* stats, unsigned long long* sacc, int sR, int N,
+                          int Cin, int H, int W, int Cout, int out_dtype, void* stream);
+
 int cy_conv3x3_first_fwd(const float* x, const float* w, void* out, float* stats, int N, int Cin,
                          int H, int W, int Cout, int out_dtype, void* stream) {
+  return first_fwd_impl(x, w, out, stats, nullptr, 0, N, Cin, H, W, Cout, out_dtype, stream);
+}
+
+int cy_conv3x3_first_fwd_acc(const float* x, const float* w, void* out, const cy_bn_acc* out_acc, int N, int Cin,
+                             int H, int W, int Cout, int out_dtype, void* stream) {
+  if (!out_acc || !out_acc->acc || out_acc->C != Cout || out_acc->R < 1 || (out_acc->R & (out_acc->R - 1))) return CY_ERR_ARG;
+  return first_fwd_impl(x, w, out, nullptr, (unsigned long long*)out_acc->acc, out_acc->R, N, Cin, H, W, Cout, out_dtype, stream);
+}
+
+static int first_fwd_impl(const float* x, const float* w, void* out, float* stats, unsigned long long* sacc, int sR, int N,
+                          int Cin, int H, int W, int Cout, int out_dtype, void* stream) {
   if (!x || !w || !out) return CY_ERR_ARG;
   if (Cin < 1 || Cin > 4) return CY_ERR_SHAPE;
   if ((long)N * H * W >= (1L << 31)) return CY_ERR_SHAPE;  // the kernel indexes pixels in 32 bits
@@ -1382,22 +1445,22 @@ int cy_conv3x3_first_fwd(const float* x, const float* w, void* out, float* stats
         attr_m = true;
       }
       if (out_dtype == CY_BF16)
-        hipLaunchKernelGGL(conv3x3_first_mfma_kernel<bf16>, dim3(np), dim3(256), smem_m, st, x, w, (bf16*)out, stats, N, H, W, Cout);
+        hipLaunchKernelGGL(conv3x3_first_mfma_kernel<bf16>, dim3(np), dim3(256), smem_m, st, x, w, (bf16*)out, stats, N, H, W, Cout, sacc, sR);
       else
-        hipLaunchKernelGGL(conv3x3_first_mfma_kernel<f16>, dim3(np), dim3(256), smem_m, st, x, w, (f16*)out, stats, N, H, W, Cout);
+        hipLaunchKernelGGL(conv3x3_first_mfma_kernel<f16>, dim3(np), dim3(256), smem_m, st, x, w, (f16*)out, stats, N, H, W, Cout, sacc, sR);
       CY_CHECK_LAUNCH();
       return CY_OK;
     }
   }
   if (out_dtype == CY_BF16)
     hipLaunchKernelGGL(conv3x3_first_kernel<bf16>, dim3(np), dim3(256), smem, st, x, w, (bf16*)out,
-                       stats, N, Cin, H, W, Cout);
+                       stats, N, Cin, H, W, Cout, sacc, sR);
   else if (out_dtype == CY_F16)
     hipLaunchKernelGGL(conv3x3_first_kernel<f16>, dim3(np), dim3(256), smem, st, x, w, (f16*)out,
-                       stats, N, Cin, H, W, Cout);
+                       stats, N, Cin, H, W, Cout, sacc, sR);
   else if (out_dtype == CY_F32)
     hipLaunchKernelGGL(conv3x3_first_kernel<float>, dim3(np), dim3(256), smem, st, x, w, (float*)out,
-                       stats, N, Cin, H, W, Cout);
+                       stats, N, Cin, H, W, Cout, sacc, sR);
   else
     return CY_ERR_DTYPE;
   CY_CHECK_LAUNCH();

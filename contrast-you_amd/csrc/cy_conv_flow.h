@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
   // BN+ReLU coefficients of the previous layer: requested BEFORE any DMA (vmcnt retires in order: a load behind the
   // DMAs would wait for all of them), written to LDS behind the halo requests
   float csc = 0.f, csh = 0.f;
-  if (a.prologue && tid < a.C1) {  // host: C1 <= COEF_MAX <= NTHR
+  if (a.prologue && !a.fold.acc && tid < a.C1) {  // host: C1 <= COEF_MAX <= NTHR
     csc = a.scale[tid];
     csh = a.shift[tid];
   }
@@ -266,6 +266,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
   // first chunk's halo tile
   plane_static_for<0, NAI>([&](auto I) { a_dma(cc0, I, 0); });
   if (a.prologue) {  // wave-uniform
+    // coefficients from the previous layer's sums (cy_bn_acc.h): behind the first chunk's DMA, whose flight time covers
+    // the accumulator reads; workgroup 0 leaves them in memory for the backward pass
+    if (a.fold.acc && tid < a.C1) bn_fold_channel(a.fold, tid, blockIdx.x == 0 && blockIdx.z == 0, csc, csh);
     if (tid < a.C1) {
       s_coef[tid] = csc;
       s_coef[C::COEF_MAX + tid] = csh;
@@ -380,7 +383,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
     return;
   }
   float* sstat = reinterpret_cast<float*>(smem);
-  const bool do_stats = a.stats != nullptr;
+  const bool do_stats = a.stats != nullptr || a.sacc != nullptr;
   T* o1 = reinterpret_cast<T*>(a.out);
   T* o2 = reinterpret_cast<T*>(a.out2);
   // Statistics of the ROUNDED outputs.  A lane's column is fixed, so when every row of the tile is inside the
@@ -514,8 +517,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
         t1 += sstat[(qq * 2 + 0) * BN + tid];
         t2 += sstat[(qq * 2 + 1) * BN + tid];
       }
-      a.stats[((size_t)tile * 2 + 0) * a.Cout + n0 + tid] = t1;
-      a.stats[((size_t)tile * 2 + 1) * a.Cout + n0 + tid] = t2;
+      if (a.sacc) {
+        bn_acc_add(a.sacc, a.sR, a.Cout, tile & (a.sR - 1), 0, n0 + tid, t1);
+        bn_acc_add(a.sacc, a.sR, a.Cout, tile & (a.sR - 1), 1, n0 + tid, t2);
+      } else {
+        a.stats[((size_t)tile * 2 + 0) * a.Cout + n0 + tid] = t1;
+        a.stats[((size_t)tile * 2 + 1) * a.Cout + n0 + tid] = t2;
+      }
     }
   }
   FLOW_STAMP(5, __builtin_amdgcn_s_memtime());

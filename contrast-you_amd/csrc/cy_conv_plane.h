@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(256, PREFA ? 1 : 2)
     return;
   }
   float* sstat = reinterpret_cast<float*>(smem);
-  const bool do_stats = a.stats != nullptr;
+  const bool do_stats = a.stats != nullptr || a.sacc != nullptr;
   T* o1 = reinterpret_cast<T*>(a.out);
   T* o2 = reinterpret_cast<T*>(a.out2);
 #pragma unroll
@@ -545,8 +545,13 @@ __global__ void __launch_bounds__(256, PREFA ? 1 : 2)
         t1 += sstat[(qq * 2 + 0) * BN + tid];
         t2 += sstat[(qq * 2 + 1) * BN + tid];
       }
-      a.stats[((size_t)tile * 2 + 0) * a.Cout + n0 + tid] = t1;
-      a.stats[((size_t)tile * 2 + 1) * a.Cout + n0 + tid] = t2;
+      if (a.sacc) {
+        bn_acc_add(a.sacc, a.sR, a.Cout, tile & (a.sR - 1), 0, n0 + tid, t1);
+        bn_acc_add(a.sacc, a.sR, a.Cout, tile & (a.sR - 1), 1, n0 + tid, t2);
+      } else {
+        a.stats[((size_t)tile * 2 + 0) * a.Cout + n0 + tid] = t1;
+        a.stats[((size_t)tile * 2 + 1) * a.Cout + n0 + tid] = t2;
+      }
     }
   }
 }

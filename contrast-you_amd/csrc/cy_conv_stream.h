@@ -230,10 +230,29 @@ __global__ void __launch_bounds__((256 * NB / stream_nbw<KCH, NB>()), (PRO ? 2 :
   };
   float psc[EPC], psh[EPC];
   if constexpr (PRO) {
+    if (a.fold.acc) {
+      // coefficients from the previous layer's sums (cy_bn_acc.h): one channel per thread, through LDS (a tile buffer:
+      // the first DMA is issued behind this); workgroup 0 leaves them in memory for the backward pass
+      float* scoef = reinterpret_cast<float*>(smem);
+      if (tid < a.C1) {  // host: C1 == 32
+        float c0, c1;
+        bn_fold_channel(a.fold, tid, blockIdx.x == 0, c0, c1);
+        scoef[tid] = c0;
+        scoef[64 + tid] = c1;
+      }
+      __syncthreads();
 #pragma unroll
-    for (int j = 0; j < EPC; ++j) {
-      psc[j] = a.scale[pl * EPC + j];
-      psh[j] = a.shift[pl * EPC + j];
+      for (int j = 0; j < EPC; ++j) {
+        psc[j] = scoef[pl * EPC + j];
+        psh[j] = scoef[64 + pl * EPC + j];
+      }
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) {
+        psc[j] = a.scale[pl * EPC + j];
+        psh[j] = a.shift[pl * EPC + j];
+      }
     }
   }
   auto transform_tile = [&](int t, int buf, int par) {  // PRO: after this wave's own vmcnt wait, before the barrier
@@ -475,11 +494,33 @@ __global__ void __launch_bounds__((256 * NB / stream_nbw<KCH, NB>()), (PRO ? 2 :
         const int reg = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
         const int col = nb0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         const bool sok = (lane & 1) == 0 && col < a.Cout;
+        if (a.sacc) {  // (accumulator form, cy_bn_acc.h: the four wave rows are summed in LDS below, one add per workgroup)
+          if (nb == 0) __syncthreads();  // every wave is done with the tile buffers
+          float* sred = reinterpret_cast<float*>(smem);
+          if (sok) {
+            sred[(wm * 2 + 0) * 64 + col] = S1[0];
+            sred[(wm * 2 + 1) * 64 + col] = S2[0];
+          }
+          continue;
+        }
         const unsigned prow = (unsigned)((int)blockIdx.x * WM + wm) * 2u;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, S1[0]), rst,
                                               sok ? ((prow + 0) * (unsigned)a.Cout + (unsigned)col) * 4u : OOB, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, S2[0]), rst,
                                               sok ? ((prow + 1) * (unsigned)a.Cout + (unsigned)col) * 4u : OOB, 0, 0);
+      }
+    }
+  }
+  if constexpr (STATS) {
+    if (a.sacc) {
+      __syncthreads();
+      const float* sred = reinterpret_cast<const float*>(smem);
+      if (tid < 2 * a.Cout) {  // host: Cout <= 64
+        const int q = tid / a.Cout, c = tid - q * a.Cout;
+        float t = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < WM; ++w4) t += sred[(w4 * 2 + q) * 64 + c];
+        bn_acc_add(a.sacc, a.sR, a.Cout, (int)blockIdx.x & (a.sR - 1), q, c, t);
       }
     }
   }
@@ -543,11 +584,11 @@ int launch_conv_stream(ConvArgs a, hipStream_t st) {
   int rc;
   if (a.prologue) {
     if constexpr (KCH == 1 && NB == 1)
-      rc = a.stats ? go(conv3x3_stream_kernel<T, 1, 1, true, true>) : go(conv3x3_stream_kernel<T, 1, 1, false, true>);
+      rc = (a.stats || a.sacc) ? go(conv3x3_stream_kernel<T, 1, 1, true, true>) : go(conv3x3_stream_kernel<T, 1, 1, false, true>);
     else
       return CY_ERR_SHAPE;
   } else {
-    rc = a.stats ? go(conv3x3_stream_kernel<T, KCH, NB, true>) : go(conv3x3_stream_kernel<T, KCH, NB, false>);
+    rc = (a.stats || a.sacc) ? go(conv3x3_stream_kernel<T, KCH, NB, true>) : go(conv3x3_stream_kernel<T, KCH, NB, false>);
   }
   if (rc != CY_OK) return rc;
   CY_CHECK_LAUNCH();

@@ -13,7 +13,7 @@
 //   index so that the 16 lanes a ds_read_b128 services together hit 16
 //   different 16-byte slots of the 256-byte bank row.
 #pragma once
-#include "cy_common.h"
+#include "cy_bn_acc.h"
 
 struct ConvArgs {
   const void* src1;
@@ -39,6 +39,10 @@ struct ConvArgs {
   long long bytes1, bytes2;    // sizes of the source tensors in bytes (buffer descriptors of the LDS-DMA kernels), or 0
   long long bytes_o1, bytes_o2, bytes_st;  // ... of the outputs and the statistics partials
   unsigned long long* stamps;  // development aid (cy_debug_conv_stamps): shader-clock stamps of workgroup 0, or null
+  // BatchNorm without finalize launches (cy_bn_acc.h):
+  BnFold fold;               // fold.acc != null: the prologue coefficients come from the previous layer's sums
+  unsigned long long* sacc;  // != null: the statistics are ADDED into this accumulator [sR][4][Cout] (no partial rows)
+  int sR;
 };
 
 // ---- MFMA fragment abstraction: one "k-step" is 16 input channels ----------

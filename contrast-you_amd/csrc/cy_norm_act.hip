@@ -5,7 +5,7 @@
 // :67-70 (MaxPool2d), :38 (Upsample).  All kernels are HBM-streaming: 16-byte
 // NHWC chunks per lane, per-channel coefficients from L1/L2, fixed-order
 // (deterministic) reductions through per-block partials.
-#include "cy_common.h"
+#include "cy_bn_acc.h"
 
 #include <cstdlib>
 
@@ -76,10 +76,28 @@ __global__ void __launch_bounds__(1024)
 }
 
 // ------------------------------------------------------------------ apply
-template <typename TI, typename TO>
+// FOLD (cy_bn_acc.h): the coefficients are derived from the producing conv's accumulator by every workgroup (one channel
+// per thread, through LDS); workgroup 0 leaves them in memory for the backward pass.  The host keeps the grid small
+// enough that the accumulator reads (R * C * 32 bytes per workgroup, from L2) stay a small share of the tensor traffic.
+template <bool FOLD>
+__device__ __forceinline__ void bn_fold_table(const BnFold& f, float* s_coef) {
+  if constexpr (FOLD) {
+    for (int c = threadIdx.x; c < f.C; c += 256) {
+      float a, b;
+      bn_fold_channel(f, c, blockIdx.x == 0, a, b);
+      s_coef[c] = a;
+      s_coef[f.C + c] = b;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename TI, typename TO, bool FOLD>
 __global__ void __launch_bounds__(256)
     bn_relu_apply_kernel(const TI* __restrict__ y, const float* __restrict__ scale,
-                         const float* __restrict__ shift, TO* __restrict__ out, long npix, int C) {
+                         const float* __restrict__ shift, TO* __restrict__ out, long npix, int C, const BnFold fold) {
+  extern __shared__ __attribute__((aligned(16))) float s_coef[];  // FOLD: [2][C]
+  bn_fold_table<FOLD>(fold, s_coef);
   // unit of work: 8 channels of one pixel (one 16-byte bf16 chunk / two f32 chunks)
   const int G = C / 8;
   const long total = npix * G;
@@ -94,10 +112,14 @@ __global__ void __launch_bounds__(256)
       Chunk<float>::unpack(ld16(yp), f);
       Chunk<float>::unpack(ld16(yp + 4), f + 4);
     }
-    const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + g * 8);
-    const f32x4 s1 = *reinterpret_cast<const f32x4*>(scale + g * 8 + 4);
-    const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + g * 8);
-    const f32x4 h1 = *reinterpret_cast<const f32x4*>(shift + g * 8 + 4);
+    f32x4 s0, s1, h0, h1;
+    if constexpr (FOLD) {
+      s0 = *reinterpret_cast<const f32x4*>(s_coef + g * 8), s1 = *reinterpret_cast<const f32x4*>(s_coef + g * 8 + 4);
+      h0 = *reinterpret_cast<const f32x4*>(s_coef + C + g * 8), h1 = *reinterpret_cast<const f32x4*>(s_coef + C + g * 8 + 4);
+    } else {
+      s0 = *reinterpret_cast<const f32x4*>(scale + g * 8), s1 = *reinterpret_cast<const f32x4*>(scale + g * 8 + 4);
+      h0 = *reinterpret_cast<const f32x4*>(shift + g * 8), h1 = *reinterpret_cast<const f32x4*>(shift + g * 8 + 4);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f[j] = fmaxf(fmaf(s0[j], f[j], h0[j]), 0.f);
@@ -117,11 +139,13 @@ __global__ void __launch_bounds__(256)
 // pass: unit of work = 8 channels of one 2x2 quad (H, W are the POOLED dims).  The pooled copy costs a quarter of
 // the writes and lets the next block's first conv (and its weight gradient) read a plain tensor -- i.e. run on the
 // DMA-fed kernels, which cannot take a maximum on load.
-template <typename TI, typename TO>
+template <typename TI, typename TO, bool FOLD>
 __global__ void __launch_bounds__(256)
     bn_relu_apply_pool_kernel(const TI* __restrict__ y, const float* __restrict__ scale,
                               const float* __restrict__ shift, TO* __restrict__ out, TO* __restrict__ pooled,
-                              int N, int H, int W, int C) {
+                              int N, int H, int W, int C, const BnFold fold) {
+  extern __shared__ __attribute__((aligned(16))) float s_coef[];  // FOLD: [2][C]
+  bn_fold_table<FOLD>(fold, s_coef);
   const int G = C / 8;
   const long total = (long)N * H * W * G;
   const int W2 = 2 * W;
@@ -132,10 +156,14 @@ __global__ void __launch_bounds__(256)
     p /= W;
     const int h = (int)(p % H);
     const long n = p / H;
-    const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + g * 8);
-    const f32x4 s1 = *reinterpret_cast<const f32x4*>(scale + g * 8 + 4);
-    const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + g * 8);
-    const f32x4 h1 = *reinterpret_cast<const f32x4*>(shift + g * 8 + 4);
+    f32x4 s0, s1, h0, h1;
+    if constexpr (FOLD) {
+      s0 = *reinterpret_cast<const f32x4*>(s_coef + g * 8), s1 = *reinterpret_cast<const f32x4*>(s_coef + g * 8 + 4);
+      h0 = *reinterpret_cast<const f32x4*>(s_coef + C + g * 8), h1 = *reinterpret_cast<const f32x4*>(s_coef + C + g * 8 + 4);
+    } else {
+      s0 = *reinterpret_cast<const f32x4*>(scale + g * 8), s1 = *reinterpret_cast<const f32x4*>(scale + g * 8 + 4);
+      h0 = *reinterpret_cast<const f32x4*>(shift + g * 8), h1 = *reinterpret_cast<const f32x4*>(shift + g * 8 + 4);
+    }
     float m[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) m[j] = 0.f;  // relu outputs are >= 0
@@ -212,7 +240,7 @@ __global__ void __launch_bounds__(256)
     bn_relu_bwd_reduce_kernel(const T* __restrict__ da, int ld_da, const T* __restrict__ y,
                               const float* __restrict__ scale, const float* __restrict__ shift,
                               const float* __restrict__ mean, const float* __restrict__ invstd,
-                              float* __restrict__ partials, long npix, int C) {
+                              float* __restrict__ partials, long npix, int C, unsigned long long* sacc, int sR) {
   extern __shared__ float sred[];  // [2][rows][C]
   const int G = C / 8;
   const int tid = threadIdx.x;
@@ -293,7 +321,8 @@ __global__ void __launch_bounds__(256)
       if (c < C) {
         float s = 0.f;
         for (int q = 0; q < rows; ++q) s += sred[(which * rows + q) * (gpp * 8) + cl];
-        partials[((size_t)blockIdx.x * 2 + which) * C + c] = s;
+        if (sacc) bn_acc_add(sacc, sR, C, (int)blockIdx.x & (sR - 1), which, c, s);
+        else partials[((size_t)blockIdx.x * 2 + which) * C + c] = s;
       }
     }
   }
@@ -349,11 +378,25 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-template <typename T>
+// FOLD (cy_bn_acc.h): (k1, k0) are derived from the backward sums' accumulator by every workgroup; workgroup 0 adds the
+// parameter gradients (what bn_bwd_finalize_kernel did in a launch of its own)
+template <typename T, bool FOLD>
 __global__ void __launch_bounds__(256)
     bn_relu_bwd_apply_kernel(const T* __restrict__ da, int ld_da, const T* __restrict__ y,
                              const float* __restrict__ scale, const float* __restrict__ shift,
-                             const float* __restrict__ coef, T* __restrict__ dy, long npix, int C) {
+                             const float* __restrict__ coef, T* __restrict__ dy, long npix, int C, const BnBwdFold fold) {
+  extern __shared__ __attribute__((aligned(16))) float s_coef[];  // FOLD: [4][C] = scale, shift, k1, k0
+  if constexpr (FOLD) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float k1v, k0v;
+      bn_bwd_fold_channel(fold, c, blockIdx.x == 0, k1v, k0v);
+      s_coef[c] = scale[c];
+      s_coef[C + c] = shift[c];
+      s_coef[2 * C + c] = k1v;
+      s_coef[3 * C + c] = k0v;
+    }
+    __syncthreads();
+  }
   const int G = C / 8;
   const bool pow2 = (G & (G - 1)) == 0;
   const int gshift = 31 - __clz(G);
@@ -364,13 +407,16 @@ __global__ void __launch_bounds__(256)
     float d[8], v[8], o[8];
     load8<T>(da + p * ld_da + g * 8, d);
     load8<T>(y + p * C + g * 8, v);
-    const f32x4* sc = reinterpret_cast<const f32x4*>(scale + g * 8);
-    const f32x4* sh = reinterpret_cast<const f32x4*>(shift + g * 8);
-    const f32x4* k1 = reinterpret_cast<const f32x4*>(coef + g * 8);
-    const f32x4* k0 = reinterpret_cast<const f32x4*>(coef + C + g * 8);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const f32x4 a = sc[h], b = sh[h], c1 = k1[h], c0 = k0[h];
+      f32x4 a, b, c1, c0;
+      if constexpr (FOLD) {
+        a = *reinterpret_cast<const f32x4*>(s_coef + g * 8 + 4 * h), b = *reinterpret_cast<const f32x4*>(s_coef + C + g * 8 + 4 * h);
+        c1 = *reinterpret_cast<const f32x4*>(s_coef + 2 * C + g * 8 + 4 * h), c0 = *reinterpret_cast<const f32x4*>(s_coef + 3 * C + g * 8 + 4 * h);
+      } else {
+        a = *reinterpret_cast<const f32x4*>(scale + g * 8 + 4 * h), b = *reinterpret_cast<const f32x4*>(shift + g * 8 + 4 * h);
+        c1 = *reinterpret_cast<const f32x4*>(coef + g * 8 + 4 * h), c0 = *reinterpret_cast<const f32x4*>(coef + C + g * 8 + 4 * h);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float yv = v[4 * h + j];
@@ -394,7 +440,7 @@ __global__ void __launch_bounds__(256)
                         const T* __restrict__ add, int ld_add, T* __restrict__ dx, int N, int H,
                         int W, int C, const T* __restrict__ y, const float* __restrict__ scale,
                         const float* __restrict__ shift, const float* __restrict__ mean,
-                        const float* __restrict__ invstd, float* __restrict__ partials) {
+                        const float* __restrict__ invstd, float* __restrict__ partials, unsigned long long* sacc, int sR) {
   // (H,W) are the POOLED dims; x/dx/add/y are [N,2H,2W,C]
   const int G = C / 8;
   const long total = (long)N * H * W * G;
@@ -478,7 +524,8 @@ __global__ void __launch_bounds__(256)
       const int g = c >> 3, jj = c & 7;
       float s = 0.f;
       for (int k = 0; k < per_g; ++k) s += sred[(g + k * G) * 16 + which * 8 + jj];
-      partials[((size_t)blockIdx.x * 2 + which) * C + c] = s;
+      if (sacc) bn_acc_add(sacc, sR, C, (int)blockIdx.x & (sR - 1), which, c, s);
+      else partials[((size_t)blockIdx.x * 2 + which) * C + c] = s;
     }
   }
 }
@@ -509,6 +556,36 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// accumulator -> coefficients as a launch of its own (for consumers that cannot fold in place)
+__global__ void __launch_bounds__(256) bn_fold_kernel(const BnFold f) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < f.C) {
+    float a, b;
+    bn_fold_channel(f, c, true, a, b);
+  }
+}
+
+// running statistics of several layers in one launch; the table travels as a kernel argument
+struct BnRunArgs {
+  cy_bn_run_item it[32];
+};
+__global__ void __launch_bounds__(256) bn_running_update_kernel(const BnRunArgs a) {
+  const cy_bn_run_item& it = a.it[blockIdx.x];
+  for (int c = threadIdx.x; c < it.C; c += 256) {
+    const double m = (double)it.momentum;
+    it.running_mean[c] = (float)((1.0 - m) * (double)it.running_mean[c] + m * (double)it.coef[2 * it.C + c]);
+    it.running_var[c] = (float)((1.0 - m) * (double)it.running_var[c] + m * (double)it.coef[4 * it.C + c]);
+  }
+}
+
+// grid of the folding elementwise kernels: every workgroup reads the accumulator, so few, long-running workgroups
+inline int fold_grid(long items) {
+  long b = (items + 1023) / 1024;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
 inline int stream_grid(long total_threads) {
   long b = (total_threads + 255) / 256;
   if (b > 2048 * 4) b = 2048 * 4;
@@ -535,48 +612,101 @@ int cy_bn_finalize(const float* partials, int num_partials, int C, double count,
   return CY_OK;
 }
 
-int cy_bn_relu_apply(const void* y, const float* scale, const float* shift, void* out, long npix,
-                     int C, int y_dtype, int out_dtype, void* stream) {
-  if (!y || !scale || !shift || !out || npix <= 0) return CY_ERR_ARG;
+static int bn_relu_apply_impl(const void* y, const float* scale, const float* shift, const cy_bn_fold* f, void* out,
+                              long npix, int C, int y_dtype, int out_dtype, void* stream) {
+  if (!y || !out || npix <= 0) return CY_ERR_ARG;
+  if (!f && (!scale || !shift)) return CY_ERR_ARG;
+  if (f && (!f->acc || !f->coef || f->C != C || f->R < 1 || (f->R & (f->R - 1)) || f->count <= 0)) return CY_ERR_ARG;
   if (C % 8) return CY_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = stream_grid(npix * (C / 8));
-  if (y_dtype == CY_BF16 && out_dtype == CY_BF16)
-    hipLaunchKernelGGL((bn_relu_apply_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, st,
-                       (const bf16*)y, scale, shift, (bf16*)out, npix, C);
-  else if (y_dtype == CY_F32 && out_dtype == CY_F32)
-    hipLaunchKernelGGL((bn_relu_apply_kernel<float, float>), dim3(grid), dim3(256), 0, st,
-                       (const float*)y, scale, shift, (float*)out, npix, C);
-  else if (y_dtype == CY_BF16 && out_dtype == CY_F32)
-    hipLaunchKernelGGL((bn_relu_apply_kernel<bf16, float>), dim3(grid), dim3(256), 0, st,
-                       (const bf16*)y, scale, shift, (float*)out, npix, C);
-  else if (y_dtype == CY_F16 && out_dtype == CY_F16)
-    hipLaunchKernelGGL((bn_relu_apply_kernel<f16, f16>), dim3(grid), dim3(256), 0, st,
-                       (const f16*)y, scale, shift, (f16*)out, npix, C);
-  else if (y_dtype == CY_F16 && out_dtype == CY_F32)
-    hipLaunchKernelGGL((bn_relu_apply_kernel<f16, float>), dim3(grid), dim3(256), 0, st,
-                       (const f16*)y, scale, shift, (float*)out, npix, C);
-  else
-    return CY_ERR_DTYPE;
+  const BnFold bf = f ? bn_fold_from_abi(f) : BnFold{};
+  const int grid = f ? fold_grid(npix * (C / 8)) : stream_grid(npix * (C / 8));
+  const size_t smem = f ? (size_t)2 * C * sizeof(float) : 0;
+#define CY_APPLY(TI, TO)                                                                                        \
+  do {                                                                                                          \
+    if (f) hipLaunchKernelGGL((bn_relu_apply_kernel<TI, TO, true>), dim3(grid), dim3(256), smem, st, (const TI*)y, \
+                              scale, shift, (TO*)out, npix, C, bf);                                             \
+    else hipLaunchKernelGGL((bn_relu_apply_kernel<TI, TO, false>), dim3(grid), dim3(256), 0, st, (const TI*)y,  \
+                            scale, shift, (TO*)out, npix, C, bf);                                               \
+  } while (0)
+  if (y_dtype == CY_BF16 && out_dtype == CY_BF16) CY_APPLY(bf16, bf16);
+  else if (y_dtype == CY_F32 && out_dtype == CY_F32) CY_APPLY(float, float);
+  else if (y_dtype == CY_BF16 && out_dtype == CY_F32) CY_APPLY(bf16, float);
+  else if (y_dtype == CY_F16 && out_dtype == CY_F16) CY_APPLY(f16, f16);
+  else if (y_dtype == CY_F16 && out_dtype == CY_F32) CY_APPLY(f16, float);
+  else return CY_ERR_DTYPE;
+#undef CY_APPLY
   CY_CHECK_LAUNCH();
   return CY_OK;
 }
 
-int cy_bn_relu_apply_pool(const void* y, const float* scale, const float* shift, void* out, void* pooled,
-                          int N, int H, int W, int C, int y_dtype, int out_dtype, void* stream) {
-  if (!y || !scale || !shift || !out || !pooled || N <= 0 || H <= 0 || W <= 0) return CY_ERR_ARG;
+int cy_bn_relu_apply(const void* y, const float* scale, const float* shift, void* out, long npix,
+                     int C, int y_dtype, int out_dtype, void* stream) {
+  return bn_relu_apply_impl(y, scale, shift, nullptr, out, npix, C, y_dtype, out_dtype, stream);
+}
+
+int cy_bn_relu_apply_fold(const void* y, const cy_bn_fold* f, void* out, long npix, int y_dtype, int out_dtype,
+                          void* stream) {
+  if (!f) return CY_ERR_ARG;
+  return bn_relu_apply_impl(y, nullptr, nullptr, f, out, npix, f->C, y_dtype, out_dtype, stream);
+}
+
+static int bn_relu_apply_pool_impl(const void* y, const float* scale, const float* shift, const cy_bn_fold* f, void* out,
+                                   void* pooled, int N, int H, int W, int C, int y_dtype, int out_dtype, void* stream) {
+  if (!y || !out || !pooled || N <= 0 || H <= 0 || W <= 0) return CY_ERR_ARG;
+  if (!f && (!scale || !shift)) return CY_ERR_ARG;
+  if (f && (!f->acc || !f->coef || f->C != C || f->R < 1 || (f->R & (f->R - 1)) || f->count <= 0)) return CY_ERR_ARG;
   if (C % 8) return CY_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = stream_grid((long)N * H * W * (C / 8));
-#define CY_APPLY_POOL(TI, TO)                                                                              \
-  hipLaunchKernelGGL((bn_relu_apply_pool_kernel<TI, TO>), dim3(grid), dim3(256), 0, st, (const TI*)y, scale, \
-                     shift, (TO*)out, (TO*)pooled, N, H, W, C)
+  const BnFold bf = f ? bn_fold_from_abi(f) : BnFold{};
+  const long items = (long)N * H * W * (C / 8);
+  const int grid = f ? fold_grid(items * 4) : stream_grid(items);
+  const size_t smem = f ? (size_t)2 * C * sizeof(float) : 0;
+#define CY_APPLY_POOL(TI, TO)                                                                                      \
+  do {                                                                                                             \
+    if (f) hipLaunchKernelGGL((bn_relu_apply_pool_kernel<TI, TO, true>), dim3(grid), dim3(256), smem, st,          \
+                              (const TI*)y, scale, shift, (TO*)out, (TO*)pooled, N, H, W, C, bf);                  \
+    else hipLaunchKernelGGL((bn_relu_apply_pool_kernel<TI, TO, false>), dim3(grid), dim3(256), 0, st, (const TI*)y, \
+                            scale, shift, (TO*)out, (TO*)pooled, N, H, W, C, bf);                                  \
+  } while (0)
   if (y_dtype == CY_BF16 && out_dtype == CY_BF16) CY_APPLY_POOL(bf16, bf16);
   else if (y_dtype == CY_F32 && out_dtype == CY_F32) CY_APPLY_POOL(float, float);
   else if (y_dtype == CY_F16 && out_dtype == CY_F16) CY_APPLY_POOL(f16, f16);
   else return CY_ERR_DTYPE;
 #undef CY_APPLY_POOL
   CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_bn_relu_apply_pool(const void* y, const float* scale, const float* shift, void* out, void* pooled,
+                          int N, int H, int W, int C, int y_dtype, int out_dtype, void* stream) {
+  return bn_relu_apply_pool_impl(y, scale, shift, nullptr, out, pooled, N, H, W, C, y_dtype, out_dtype, stream);
+}
+
+int cy_bn_relu_apply_pool_fold(const void* y, const cy_bn_fold* f, void* out, void* pooled, int N, int H, int W,
+                               int y_dtype, int out_dtype, void* stream) {
+  if (!f) return CY_ERR_ARG;
+  return bn_relu_apply_pool_impl(y, nullptr, nullptr, f, out, pooled, N, H, W, f->C, y_dtype, out_dtype, stream);
+}
+
+int cy_bn_fold_coef(const cy_bn_fold* f, void* stream) {
+  if (!f || !f->acc || !f->coef || f->C <= 0 || f->R < 1 || (f->R & (f->R - 1)) || f->count <= 0) return CY_ERR_ARG;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(cy_cdiv(f->C, 256)), dim3(256), 0, (hipStream_t)stream, bn_fold_from_abi(f));
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_bn_running_update(const cy_bn_run_item* h_items, int n, void* stream) {
+  if (!h_items || n <= 0) return CY_ERR_ARG;
+  for (int i = 0; i < n; ++i)
+    if (!h_items[i].coef || !h_items[i].running_mean || !h_items[i].running_var || h_items[i].C <= 0) return CY_ERR_ARG;
+  for (int i0 = 0; i0 < n; i0 += 32) {
+    BnRunArgs a;
+    const int m = n - i0 < 32 ? n - i0 : 32;
+    for (int i = 0; i < m; ++i) a.it[i] = h_items[i0 + i];
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, a);
+    CY_CHECK_LAUNCH();
+  }
   return CY_OK;
 }
 
@@ -591,10 +721,30 @@ int cy_bn_bwd_num_partials(long npix, int C) {
   return (int)b;
 }
 
+static int bn_relu_bwd_reduce_impl(const void* da, int ld_da, const void* y, const float* scale,
+                                   const float* shift, const float* mean, const float* invstd,
+                                   float* partials, unsigned long long* sacc, int sR, long npix, int C, int dtype, void* stream);
+
 int cy_bn_relu_bwd_reduce(const void* da, int ld_da, const void* y, const float* scale,
                           const float* shift, const float* mean, const float* invstd,
                           float* partials, long npix, int C, int dtype, void* stream) {
-  if (!da || !y || !scale || !shift || !mean || !invstd || !partials) return CY_ERR_ARG;
+  if (!partials) return CY_ERR_ARG;
+  return bn_relu_bwd_reduce_impl(da, ld_da, y, scale, shift, mean, invstd, partials, nullptr, 0, npix, C, dtype, stream);
+}
+
+int cy_bn_relu_bwd_workgroups(long npix, int C) { return cy_bn_bwd_num_partials(npix, C); }
+
+int cy_bn_relu_bwd_reduce_acc(const void* da, int ld_da, const void* y, const float* coef, const cy_bn_acc* acc,
+                              long npix, int C, int dtype, void* stream) {
+  if (!coef || !acc || !acc->acc || acc->C != C || acc->R < 1 || (acc->R & (acc->R - 1))) return CY_ERR_ARG;
+  return bn_relu_bwd_reduce_impl(da, ld_da, y, coef, coef + C, coef + 2 * C, coef + 3 * C, nullptr,
+                                 (unsigned long long*)acc->acc, acc->R, npix, C, dtype, stream);
+}
+
+static int bn_relu_bwd_reduce_impl(const void* da, int ld_da, const void* y, const float* scale,
+                                   const float* shift, const float* mean, const float* invstd,
+                                   float* partials, unsigned long long* sacc, int sR, long npix, int C, int dtype, void* stream) {
+  if (!da || !y || !scale || !shift || !mean || !invstd || (!partials && !sacc)) return CY_ERR_ARG;
   if (C % 8 || ld_da % 8 || ld_da < C) return CY_ERR_SHAPE;
   const int G = C / 8;
   const int gpp = G < 256 ? G : 256;
@@ -605,7 +755,7 @@ int cy_bn_relu_bwd_reduce(const void* da, int ld_da, const void* y, const float*
   const bool deep = grid < 512;
 #define CY_BN_RED(TT, DD)                                                                                          \
   hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<TT, DD>), dim3(grid), dim3(256), smem, st, (const TT*)da, ld_da,   \
-                     (const TT*)y, scale, shift, mean, invstd, partials, npix, C)
+                     (const TT*)y, scale, shift, mean, invstd, partials, npix, C, sacc, sR)
   if (dtype == CY_BF16) {
     if (deep) CY_BN_RED(bf16, true); else CY_BN_RED(bf16, false);
   } else if (dtype == CY_F16) {
@@ -639,20 +789,39 @@ int cy_bn_relu_bwd_apply(const void* da, int ld_da, const void* y, const float* 
   if (C % 8 || ld_da % 8 || ld_da < C) return CY_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int grid = stream_grid(npix * (C / 8));
-  if (dtype == CY_BF16)
-    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st,
-                       (const bf16*)da, ld_da, (const bf16*)y, scale, shift, coef, (bf16*)dy, npix,
-                       C);
-  else if (dtype == CY_F16)
-    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<f16>, dim3(grid), dim3(256), 0, st,
-                       (const f16*)da, ld_da, (const f16*)y, scale, shift, coef, (f16*)dy, npix,
-                       C);
-  else if (dtype == CY_F32)
-    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st,
-                       (const float*)da, ld_da, (const float*)y, scale, shift, coef, (float*)dy,
-                       npix, C);
-  else
-    return CY_ERR_DTYPE;
+  const BnBwdFold nf = {};
+#define CY_BWD_APPLY(TT)                                                                                          \
+  hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<TT, false>), dim3(grid), dim3(256), 0, st, (const TT*)da, ld_da,    \
+                     (const TT*)y, scale, shift, coef, (TT*)dy, npix, C, nf)
+  if (dtype == CY_BF16) CY_BWD_APPLY(bf16);
+  else if (dtype == CY_F16) CY_BWD_APPLY(f16);
+  else if (dtype == CY_F32) CY_BWD_APPLY(float);
+  else return CY_ERR_DTYPE;
+#undef CY_BWD_APPLY
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_bn_relu_bwd_apply_fold(const void* da, int ld_da, const void* y, const float* coef, const cy_bn_acc* acc,
+                              double count, int batch_stats, float* dgamma, float* dbeta, int accumulate, void* dy,
+                              long npix, int C, int dtype, void* stream) {
+  if (!da || !y || !coef || !dy || !acc || !acc->acc || acc->C != C || acc->R < 1 || (acc->R & (acc->R - 1)) || count <= 0)
+    return CY_ERR_ARG;
+  if (C % 8 || ld_da % 8 || ld_da < C) return CY_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  BnBwdFold f;
+  f.acc = (const unsigned long long*)acc->acc, f.R = acc->R, f.C = C, f.coef = coef;
+  f.inv_count = 1.0 / count, f.batch_stats = batch_stats, f.accumulate = accumulate, f.dgamma = dgamma, f.dbeta = dbeta;
+  const int grid = fold_grid(npix * (C / 8));
+  const size_t smem = (size_t)4 * C * sizeof(float);
+#define CY_BWD_APPLY(TT)                                                                                          \
+  hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<TT, true>), dim3(grid), dim3(256), smem, st, (const TT*)da, ld_da,  \
+                     (const TT*)y, coef, coef + C, (const float*)nullptr, (TT*)dy, npix, C, f)
+  if (dtype == CY_BF16) CY_BWD_APPLY(bf16);
+  else if (dtype == CY_F16) CY_BWD_APPLY(f16);
+  else if (dtype == CY_F32) CY_BWD_APPLY(float);
+  else return CY_ERR_DTYPE;
+#undef CY_BWD_APPLY
   CY_CHECK_LAUNCH();
   return CY_OK;
 }
@@ -666,7 +835,7 @@ int cy_maxpool2_bwd(const void* x, const void* dpool, const void* add, int ld_ad
 #define CY_POOL_BWD(TT)                                                                                          \
   hipLaunchKernelGGL((maxpool2_bwd_kernel<TT, false>), dim3(grid), dim3(256), 0, st, (const TT*)x,              \
                      (const TT*)dpool, (const TT*)add, ld_add, (TT*)dx, N, H, W, C, (const TT*)nullptr, nullptr, \
-                     nullptr, nullptr, nullptr, nullptr)
+                     nullptr, nullptr, nullptr, nullptr, nullptr, 0)
   if (dtype == CY_BF16) CY_POOL_BWD(bf16);
   else if (dtype == CY_F16) CY_POOL_BWD(f16);
   else if (dtype == CY_F32) CY_POOL_BWD(float);
@@ -685,10 +854,32 @@ int cy_maxpool2_bwd_bn_num_partials(int N, int H, int W, int C) {
   return (int)(b < 1 ? 1 : b);
 }
 
+static int maxpool2_bwd_bn_impl(const void* x, const void* dpool, const void* add, int ld_add, void* dx, const void* y,
+                                const float* scale, const float* shift, const float* mean, const float* invstd,
+                                float* partials, unsigned long long* sacc, int sR, int N, int H, int W, int C, int dtype,
+                                void* stream);
+
 int cy_maxpool2_bwd_bn(const void* x, const void* dpool, const void* add, int ld_add, void* dx, const void* y,
                        const float* scale, const float* shift, const float* mean, const float* invstd,
                        float* partials, int N, int H, int W, int C, int dtype, void* stream) {
-  if (!x || !dpool || !dx || !y || !scale || !shift || !mean || !invstd || !partials) return CY_ERR_ARG;
+  if (!partials) return CY_ERR_ARG;
+  return maxpool2_bwd_bn_impl(x, dpool, add, ld_add, dx, y, scale, shift, mean, invstd, partials, nullptr, 0, N, H, W, C,
+                              dtype, stream);
+}
+
+int cy_maxpool2_bwd_bn_acc(const void* x, const void* dpool, const void* add, int ld_add, void* dx, const void* y,
+                           const float* coef, const cy_bn_acc* acc, int N, int H, int W, int C, int dtype,
+                           void* stream) {
+  if (!coef || !acc || !acc->acc || acc->C != C || acc->R < 1 || (acc->R & (acc->R - 1))) return CY_ERR_ARG;
+  return maxpool2_bwd_bn_impl(x, dpool, add, ld_add, dx, y, coef, coef + C, coef + 2 * C, coef + 3 * C, nullptr,
+                              (unsigned long long*)acc->acc, acc->R, N, H, W, C, dtype, stream);
+}
+
+static int maxpool2_bwd_bn_impl(const void* x, const void* dpool, const void* add, int ld_add, void* dx, const void* y,
+                                const float* scale, const float* shift, const float* mean, const float* invstd,
+                                float* partials, unsigned long long* sacc, int sR, int N, int H, int W, int C, int dtype,
+                                void* stream) {
+  if (!x || !dpool || !dx || !y || !scale || !shift || !mean || !invstd || (!partials && !sacc)) return CY_ERR_ARG;
   if (add && (ld_add % 8 || ld_add < C)) return CY_ERR_SHAPE;
   const int grid = cy_maxpool2_bwd_bn_num_partials(N, H, W, C);
   if (grid < 0) return grid;
@@ -696,7 +887,7 @@ int cy_maxpool2_bwd_bn(const void* x, const void* dpool, const void* add, int ld
 #define CY_POOL_BWD(TT)                                                                                      \
   hipLaunchKernelGGL((maxpool2_bwd_kernel<TT, true>), dim3(grid), dim3(256), 0, st, (const TT*)x,           \
                      (const TT*)dpool, (const TT*)add, ld_add, (TT*)dx, N, H, W, C, (const TT*)y, scale, shift, \
-                     mean, invstd, partials)
+                     mean, invstd, partials, sacc, sR)
   if (dtype == CY_BF16) CY_POOL_BWD(bf16);
   else if (dtype == CY_F16) CY_POOL_BWD(f16);
   else if (dtype == CY_F32) CY_POOL_BWD(float);

@@ -11,7 +11,7 @@ from pathlib import Path
 
 CY_F32, CY_BF16, CY_F16 = 0, 1, 2
 CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2 = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _ERRORS = {-1: "CY_ERR_ARG (bad/NULL argument)", -2: "CY_ERR_SHAPE (unsupported shape)",
            -3: "CY_ERR_DTYPE (unsupported dtype)", -4: "CY_ERR_LAUNCH (HIP launch failed)",
@@ -52,6 +52,23 @@ class WgradPlan(C.Structure):
     _fields_ = [(n, c_int32) for n in ("twelve", "wco", "wci", "wk", "th", "tw", "splits", "workgroups")]
 
 
+class BnAcc(C.Structure):
+    """mirror of cy_bn_acc"""
+    _fields_ = [("acc", c_void_p), ("R", c_int32), ("C", c_int32)]
+
+
+class BnFold(C.Structure):
+    """mirror of cy_bn_fold"""
+    _fields_ = [("acc", c_void_p), ("R", c_int32), ("C", c_int32), ("gamma", c_void_p), ("beta", c_void_p),
+                ("count", c_double), ("eps", c_float), ("reserved", c_int32), ("coef", c_void_p)]
+
+
+class BnRunItem(C.Structure):
+    """mirror of cy_bn_run_item"""
+    _fields_ = [("coef", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p), ("C", c_int32),
+                ("momentum", c_float)]
+
+
 class MatLayout(C.Structure):
     """mirror of cy_mat_layout: element (i, j) of batch (b1, b2) at b1*s1 + b2*s2 + i*rs + j*cs"""
     _fields_ = [(n, c_long) for n in ("rs", "cs", "s1", "s2")]
@@ -60,6 +77,8 @@ class MatLayout(C.Structure):
 _P = c_void_p
 _PCD = POINTER(ConvDesc)
 _PML = POINTER(MatLayout)
+_PBA = POINTER(BnAcc)
+_PBF = POINTER(BnFold)
 
 # name -> (restype, argtypes).  restype c_int functions are status-checked.
 _SIGS = {
@@ -89,6 +108,20 @@ _SIGS = {
     "cy_conv3x3_wgrad_pair_ws_bytes": (c_size_t, [_PCD, c_int]),
     "cy_conv3x3_wgrad_pair": (c_int, [_PCD, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, _P,
                                       c_size_t, _P]),
+    "cy_bn_acc_replicas": (c_int, [c_int, c_int]),
+    "cy_bn_acc_bytes": (c_size_t, [c_int, c_int]),
+    "cy_conv3x3_stat_workgroups": (c_int, [_PCD]),
+    "cy_conv3x3_fwd_bn": (c_int, [_PCD, _P, _P, _PBF, _P, _P, _P, _P, _P, _P, _PBA, _P, c_size_t, _P]),
+    "cy_conv3x3_first_fwd_acc": (c_int, [_P, _P, _P, _PBA, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cy_bn_fold_coef": (c_int, [_PBF, _P]),
+    "cy_bn_relu_apply_fold": (c_int, [_P, _PBF, _P, c_long, c_int, c_int, _P]),
+    "cy_bn_relu_apply_pool_fold": (c_int, [_P, _PBF, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cy_bn_running_update": (c_int, [POINTER(BnRunItem), c_int, _P]),
+    "cy_bn_relu_bwd_reduce_acc": (c_int, [_P, c_int, _P, _P, _PBA, c_long, c_int, c_int, _P]),
+    "cy_bn_relu_bwd_workgroups": (c_int, [c_long, c_int]),
+    "cy_maxpool2_bwd_bn_acc": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _PBA, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cy_bn_relu_bwd_apply_fold": (c_int, [_P, c_int, _P, _P, _PBA, c_double, c_int, _P, _P, c_int, _P, c_long, c_int,
+                                          c_int, _P]),
     "cy_conv3x3_first_num_partials": (c_int, [c_int, c_int, c_int, c_int]),
     "cy_conv3x3_first_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cy_conv3x3_first_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -185,7 +218,8 @@ _SIGS = {
 
 # functions whose int return is a count / size, not a status
 _COUNT_FUNCS = {"cy_abi_version", "cy_conv3x3_num_partials", "cy_conv3x3_first_num_partials",
-                "cy_bn_bwd_num_partials"}
+                "cy_bn_bwd_num_partials", "cy_bn_acc_replicas", "cy_conv3x3_stat_workgroups",
+                "cy_bn_relu_bwd_workgroups"}
 # (cy_maxpool2_bwd_bn_num_partials returns a count or a negative status: the caller tests the sign itself)
 
 _lib = None

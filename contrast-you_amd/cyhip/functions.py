@@ -27,19 +27,36 @@ _weights_epoch = 0
 _nbt_pending: Optional[list] = None
 
 
+# running statistics of the BN layers touched by the current U-Net forward (accumulator path, csrc/cy_bn_acc.h): their
+# consumers leave the batch moments in memory, ONE launch at the end of the forward blends them into the running buffers
+_run_pending: Optional[list] = None
+
+
 class defer_batch_counters:
+    """scope of one network pass: the BatchNorm accumulators of the pass come from one zeroed arena (one fill launch),
+    the running statistics and batch counters of its layers are updated by one launch each when the pass ends"""
+
+    def __init__(self, device=None):
+        self._device = device
+
     def __enter__(self):
-        global _nbt_pending
-        self._outer = _nbt_pending
-        _nbt_pending = []
+        global _nbt_pending, _run_pending
+        self._outer = (_nbt_pending, _run_pending)
+        _nbt_pending, _run_pending = [], []
+        self._arena = ops.bn_arena_begin(self._device) if self._device is not None else None
         return self
 
     def __exit__(self, *exc):
-        global _nbt_pending
-        pending, _nbt_pending = _nbt_pending, self._outer
-        if pending and exc[0] is None:
-            with ops.ordered("bn_batch_counters"):
-                torch._foreach_add_(pending, 1)
+        global _nbt_pending, _run_pending
+        pending, running = _nbt_pending, _run_pending
+        _nbt_pending, _run_pending = self._outer
+        if self._device is not None:
+            ops.bn_arena_end(self._arena)
+        if exc[0] is None:
+            ops.bn_running_update(running)
+            if pending:
+                with ops.ordered("bn_batch_counters"):
+                    torch._foreach_add_(pending, 1)
         return False
 
 
@@ -247,37 +264,64 @@ class ConvChainFn(torch.autograd.Function):
                 cur2 = ops.to_nhwc(cur2.to(dt) if cur2.dtype != dt else cur2)
         x1s, x2s = cur, cur2
         scale = shift = None
-        ys, coefs = [], []
+        fold = None  # accumulator path: the BatchNorm evaluation whose coefficients the next kernel derives itself
+        ys, coefs, run_items = [], [], []
         for i in range(nconv):
             w, g, b = params[3 * i: 3 * i + 3]
             bn = cfg.bns[i]
             use_batch, update = _bn_flags(bn)
+            acc_i = ops.BN_ACC and use_batch
             Cout = w.shape[0]
             if i == 0 and cfg.first:
-                y, part = ops.conv_first_fwd(cur, w, dt, want_stats=use_batch)
+                y, part = ops.conv_first_fwd(cur, w, dt, want_stats=use_batch, stats_acc=acc_i)
             else:
                 note_forward_use(w, ctx.needs_input_grad[3 + 3 * i])
                 wf, _ = packed_weights(w, dt)
                 y, part = ops.conv3x3_fwd(cur, cur2 if i == 0 else None, wf, Cout,
-                                          mode=mode if i == 0 else 0, scale=scale, shift=shift,
-                                          want_stats=use_batch)
+                                          mode=mode if i == 0 else 0, scale=scale, shift=shift, fold=fold,
+                                          want_stats=use_batch, stats_acc=acc_i)
+                if fold is not None:
+                    fold.done = True
             count = y.shape[0] * y.shape[2] * y.shape[3]
-            scale, shift, mean, invstd = ops.bn_finalize(
-                part, count, g.detach(), b.detach(), bn.running_mean, bn.running_var,
-                bn.momentum if bn.momentum is not None else 0.1, bn.eps, use_batch, update, Cout, dev)
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            if acc_i:
+                # no finalize launch: the consumer of y (the next conv's prologue, or the apply launch below) derives
+                # the coefficients from the accumulator and leaves [scale, shift, mean, invstd, var] in fold.coef
+                fold = ops.BnState(part, g.detach(), b.detach(), count, bn.eps, dev)
+                scale = shift = None
+                coefs.append((fold.coef[0], fold.coef[1], fold.coef[2], fold.coef[3]))
+                if update:
+                    run_items.append((fold.coef, bn.running_mean, bn.running_var, mom))
+            else:
+                fold = None
+                scale, shift, mean, invstd = ops.bn_finalize(
+                    part, count, g.detach(), b.detach(), bn.running_mean, bn.running_var, mom, bn.eps, use_batch,
+                    update, Cout, dev)
+                coefs.append((scale, shift, mean, invstd))
             if update and bn.num_batches_tracked is not None:
                 if _nbt_pending is not None:
                     _nbt_pending.append(bn.num_batches_tracked)
                 else:
                     bn.num_batches_tracked.add_(1)
             ys.append(y)
-            coefs.append((scale, shift, mean, invstd))
             batch_flags.append(use_batch)
             cur, cur2 = y, None
-        if cfg.pool_out:
+        if fold is not None:
+            out, pooled = ops.bn_relu_apply_pool_fold(ys[-1], fold) if cfg.pool_out else (ops.bn_relu_apply_fold(ys[-1], fold), None)
+        elif cfg.pool_out:
             out, pooled = ops.bn_relu_apply_pool(ys[-1], scale, shift)
         else:
             out, pooled = ops.bn_relu_apply(ys[-1], scale, shift), None
+        if run_items:
+            if _run_pending is not None:
+                _run_pending.extend(run_items)
+            else:
+                ops.bn_running_update(run_items)
+        # accumulators of the backward sums, from the same zeroed arena (the backward pass allocates nothing to zero)
+        ctx.bwd_accs = None
+        if ops.BN_ACC and any(ctx.needs_input_grad):
+            ctx.bwd_accs = [ops.bn_bwd_acc_new(yy.shape[0], yy.shape[1], yy.shape[2], yy.shape[3],
+                                               cfg.pool_out and j == nconv - 1, dev) for j, yy in enumerate(ys)]
         if RAW_TAP is not None:
             for i in range(nconv):
                 RAW_TAP(cfg.bns[i], ys[i], coefs[i][0], coefs[i][1], out if i == nconv - 1 else None)
@@ -314,6 +358,11 @@ class ConvChainFn(torch.autograd.Function):
         ys = [t.pop(0) for _ in range(nconv)]
         coefs = [tuple(t.pop(0) for _ in range(4)) for _ in range(nconv)]
         pool_partials = None
+        accs = ctx.bwd_accs if ops.BN_ACC else None
+        ctx.bwd_accs = None  # (a second backward through the same node gets fresh accumulators)
+        if ops.BN_ACC and accs is None:
+            accs = [None] * nconv
+        pool_acc_filled = False
         if cfg.pool_out and dpooled is not None:
             if dpooled.dtype != out.dtype:
                 dpooled = dpooled.to(out.dtype)
@@ -322,7 +371,12 @@ class ConvChainFn(torch.autograd.Function):
                 add = ops.to_nhwc(dout if dout.dtype == out.dtype else dout.to(out.dtype))
             # the pooled branch's gradient through the arg-max, + the skip branch's gradient; the same launch takes
             # the backward sums of the block's last BatchNorm (whose dA it is writing)
-            dout, pool_partials = ops.maxpool2_bwd_bn(out, ops.to_nhwc(dpooled), add, ys[-1], *coefs[-1])
+            if accs is not None:
+                dout, acc_p = ops.maxpool2_bwd_bn_acc(out, ops.to_nhwc(dpooled), add, ys[-1], coefs[-1][0], accs[-1])
+                if acc_p is not None:
+                    accs[-1], pool_acc_filled = acc_p, True
+            else:
+                dout, pool_partials = ops.maxpool2_bwd_bn(out, ops.to_nhwc(dpooled), add, ys[-1], *coefs[-1])
         need = ctx.needs_input_grad  # (cfg, x1, x2, *params)
         grads_p: List[Optional[Tensor]] = [None] * (3 * nconv)
         da = dout
@@ -337,10 +391,16 @@ class ConvChainFn(torch.autograd.Function):
             bsink = ops.grad_sink(b) if gsink is not None else None
             if bsink is None:
                 gsink = None
-            dy, dgamma, dbeta = ops.bn_relu_bwd(da, ys[i], scale, shift, mean, invstd, ctx.batch_flags[i],
-                                                dgamma_out=gsink, dbeta_out=bsink,
-                                                want_param_grads=need_g or need_b,
-                                                partials=pool_partials if i == nconv - 1 else None)
+            if accs is not None:
+                # (scale is row 0 of the contiguous coefficient block [scale, shift, mean, invstd, ...] of either path)
+                dy, dgamma, dbeta = ops.bn_relu_bwd_acc(da, ys[i], scale, ctx.batch_flags[i], dgamma_out=gsink,
+                                                        dbeta_out=bsink, want_param_grads=need_g or need_b,
+                                                        acc=accs[i], acc_filled=pool_acc_filled and i == nconv - 1)
+            else:
+                dy, dgamma, dbeta = ops.bn_relu_bwd(da, ys[i], scale, shift, mean, invstd, ctx.batch_flags[i],
+                                                    dgamma_out=gsink, dbeta_out=bsink,
+                                                    want_param_grads=need_g or need_b,
+                                                    partials=pool_partials if i == nconv - 1 else None)
             if need_g:
                 grads_p[3 * i + 1] = dgamma
             if need_b:

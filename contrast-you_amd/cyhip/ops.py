@@ -230,11 +230,11 @@ _desc_cache = {}
 class _Plan:
     """a conv descriptor with the plan numbers the library derives from it (queried once per shape:
     the host issue path is the step's critical resource)"""
-    __slots__ = ("d", "ref", "npart", "fwd_ws", "wgrad_ws", "pair_ws")
+    __slots__ = ("d", "ref", "npart", "fwd_ws", "wgrad_ws", "pair_ws", "stat_wgs")
 
     def __init__(self, d: ConvDesc):
         self.d, self.ref = d, C.byref(d)
-        self.npart = self.fwd_ws = self.wgrad_ws = None
+        self.npart = self.fwd_ws = self.wgrad_ws = self.stat_wgs = None
         self.pair_ws = {}  # images of the second segment -> workspace bytes of the paired weight gradient
 
 
@@ -285,16 +285,19 @@ def _out_hw(src1: Tensor, mode: int) -> Tuple[int, int]:
 
 def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, mode: int = 0,
                 scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
-                want_stats: bool = True, split: Optional[int] = None):
+                want_stats: bool = True, split: Optional[int] = None, fold: Optional["BnState"] = None,
+                stats_acc: bool = False):
     """out = conv3x3(cat(src1', src2)).  Returns (out, partials|None) or, with `split`,
-    ((out[:, :split], out[:, split:]), None) as two separate NHWC tensors."""
+    ((out[:, :split], out[:, split:]), None) as two separate NHWC tensors.
+    `fold`: the BN+ReLU coefficients of source 1 come from the previous layer's accumulator (instead of scale / shift).
+    `stats_acc`: the statistics go into a new accumulator: the second return value is (acc, R) instead of partial rows."""
     require_gpu(src1, wf)
     N, C1 = src1.shape[0], src1.shape[1]
     C2 = 0 if src2 is None else src2.shape[1]
     H, W = _out_hw(src1, mode)
     dt = dtype_code(src1.dtype)
     dev = src1.device
-    prologue = 1 if scale is not None else 0
+    prologue = 1 if (scale is not None or fold is not None) else 0
     if split:
         out = empty_nhwc(N, split, H, W, src1.dtype, dev)
         out2 = empty_nhwc(N, Cout - split, H, W, src1.dtype, dev)
@@ -303,8 +306,12 @@ def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, 
         out = empty_nhwc(N, Cout, H, W, src1.dtype, dev)
         out2 = None
         d = _desc(N, H, W, C1, C2, Cout, mode, prologue, dt, C1, C2, Cout)
-    stats = None
-    if want_stats:
+    stats = acc = None
+    if want_stats and stats_acc:
+        if d.stat_wgs is None:
+            d.stat_wgs = _lib.call("cy_conv3x3_stat_workgroups", d.ref)
+        acc = bn_acc_new(Cout, d.stat_wgs, dev)
+    elif want_stats:
         if d.npart is None:
             d.npart = _lib.call("cy_conv3x3_num_partials", d.ref)
         stats = _f32(d.npart * 2 * Cout, dev).view(d.npart, 2, Cout)
@@ -313,8 +320,14 @@ def conv3x3_fwd(src1: Tensor, src2: Optional[Tensor], wf: Tensor, Cout: int, *, 
     nbytes = d.fwd_ws
     ws = _ws(nbytes, dev) if nbytes else None
     ev = _prof_begin()
-    _lib.call("cy_conv3x3_fwd", d.ref, src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
-              wf.data_ptr(), out.data_ptr(), _ptr(out2), _ptr(stats), _ptr(ws), nbytes, _stream())
+    if fold is not None or acc is not None:
+        _lib.call("cy_conv3x3_fwd_bn", d.ref, src1.data_ptr(), _ptr(src2), None if fold is None else fold.ref,
+                  _ptr(scale), _ptr(shift), wf.data_ptr(), out.data_ptr(), _ptr(out2), None,
+                  None if acc is None else acc.ref, _ptr(ws), nbytes, _stream())
+        stats = acc
+    else:
+        _lib.call("cy_conv3x3_fwd", d.ref, src1.data_ptr(), _ptr(src2), _ptr(scale), _ptr(shift),
+                  wf.data_ptr(), out.data_ptr(), _ptr(out2), _ptr(stats), _ptr(ws), nbytes, _stream())
     if ev is not None:  # algorithmic bytes: every input and output element once, packed weights once
         esz = src1.element_size()
         nb = esz * (src1.numel() + (0 if src2 is None else src2.numel()) + N * H * W * Cout + 9 * (C1 + C2) * Cout)
@@ -670,7 +683,7 @@ def conv3x3_wgrad_pair(src1: Tensor, src2: Optional[Tensor], dy: Tensor, scale: 
     return out
 
 
-def conv_first_fwd(x: Tensor, w: Tensor, out_dtype: torch.dtype, want_stats: bool = True):
+def conv_first_fwd(x: Tensor, w: Tensor, out_dtype: torch.dtype, want_stats: bool = True, stats_acc: bool = False):
     """x: f32 NCHW image [N,Cin<=4,H,W]; w: f32 [Cout,Cin,3,3]."""
     require_gpu(x, w)
     N, Cin, H, W = x.shape
@@ -679,6 +692,12 @@ def conv_first_fwd(x: Tensor, w: Tensor, out_dtype: torch.dtype, want_stats: boo
     w = w.detach().contiguous()
     out = empty_nhwc(N, Cout, H, W, out_dtype, x.device)
     stats = None
+    if want_stats and stats_acc:
+        npart = _lib.call("cy_conv3x3_first_num_partials", N, H, W, Cout)
+        acc = bn_acc_new(Cout, npart, x.device)
+        _lib.call("cy_conv3x3_first_fwd_acc", x.data_ptr(), w.data_ptr(), out.data_ptr(), acc.ref, N, Cin,
+                  H, W, Cout, dtype_code(out_dtype), _stream())
+        return out, acc
     if want_stats:
         npart = _lib.call("cy_conv3x3_first_num_partials", N, H, W, Cout)
         stats = _f32(npart * 2 * Cout, x.device).view(npart, 2, Cout)
@@ -702,6 +721,118 @@ def conv_first_wgrad(x: Tensor, dy: Tensor, out: Optional[Tensor] = None) -> Ten
 
 
 # --------------------------------------------------------------------------- BN + ReLU
+# BatchNorm sums without finalize launches (csrc/cy_bn_acc.h): producers add into a zeroed int64 accumulator, consumers
+# derive the coefficients themselves.  CY_BN_ACC=0 keeps the partial rows + finalize launches of rounds 1-3 (A/B runs).
+BN_ACC = os.environ.get("CY_BN_ACC", "1") != "0"
+
+
+class BnArena:
+    """zeroed int64 words for the accumulators of one network pass: ONE fill launch per pass instead of one per layer.
+    The size follows what earlier passes used; an allocation that does not fit gets its own zeroed tensor."""
+    high_water = 0
+
+    def __init__(self, device):
+        self.used = 0
+        n = BnArena.high_water
+        self.buf = torch.zeros(n, dtype=torch.int64, device=device) if n else None
+
+    def alloc(self, words: int, device) -> Tensor:
+        a = self.used
+        self.used += (words + 15) & ~15  # (128-byte granules: no line is shared by two accumulators)
+        if self.used > BnArena.high_water:
+            BnArena.high_water = self.used
+        if self.buf is not None and self.used <= self.buf.numel() and self.buf.device == torch.device(device):
+            return self.buf[a:a + words]
+        return torch.zeros(words, dtype=torch.int64, device=device)
+
+
+_bn_arena: Optional[BnArena] = None
+
+
+def bn_arena_begin(device) -> Optional[BnArena]:
+    """called when a network pass begins; returns the previous arena (restored by `bn_arena_end`)"""
+    global _bn_arena
+    prev, _bn_arena = _bn_arena, (BnArena(device) if BN_ACC else None)
+    return prev
+
+
+def bn_arena_end(prev: Optional[BnArena]) -> None:
+    global _bn_arena
+    _bn_arena = prev
+
+
+class BnAccBuf:
+    """an accumulator [R][4][C] (+ R flags) and its ctypes view"""
+    __slots__ = ("t", "R", "C", "s", "ref")
+
+    def __init__(self, t: Tensor, R: int, Cc: int):
+        self.t, self.R, self.C = t, R, Cc
+        self.s = _lib.BnAcc(t.data_ptr(), R, Cc)
+        self.ref = C.byref(self.s)
+
+
+def bn_acc_new(Cc: int, workgroups: int, device) -> BnAccBuf:
+    R = _lib.call("cy_bn_acc_replicas", Cc, max(1, workgroups))
+    words = R * 4 * Cc + R
+    t = _bn_arena.alloc(words, device) if _bn_arena is not None else torch.zeros(words, dtype=torch.int64, device=device)
+    return BnAccBuf(t, R, Cc)
+
+
+class BnState:
+    """one training-mode BatchNorm evaluation on an accumulator: what its consumer needs to derive relu(scale*y+shift)
+    (cy_bn_fold) and where it leaves [scale, shift, mean, invstd, unbiased var] for the backward pass"""
+    __slots__ = ("acc", "gamma", "beta", "count", "eps", "coef", "s", "ref", "done")
+
+    def __init__(self, acc: BnAccBuf, gamma: Optional[Tensor], beta: Optional[Tensor], count: int, eps: float, device):
+        self.acc, self.gamma, self.beta, self.count, self.eps = acc, gamma, beta, count, eps
+        self.coef = _f32(5 * acc.C, device).view(5, acc.C)
+        self.s = _lib.BnFold(acc.t.data_ptr(), acc.R, acc.C, _ptr(gamma), _ptr(beta), float(count), float(eps), 0,
+                             self.coef.data_ptr())
+        self.ref = C.byref(self.s)
+        self.done = False  # a consumer has written `coef`
+
+
+def bn_fold_coef(st: BnState) -> None:
+    """accumulator -> st.coef as its own launch (when no folding consumer follows)"""
+    _lib.call("cy_bn_fold_coef", st.ref, _stream())
+    st.done = True
+
+
+def bn_relu_apply_fold(y: Tensor, st: BnState, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    N, Cc, H, W = y.shape
+    out_dtype = out_dtype or y.dtype
+    out = empty_nhwc(N, Cc, H, W, out_dtype, y.device)
+    _lib.call("cy_bn_relu_apply_fold", y.data_ptr(), st.ref, out.data_ptr(), N * H * W, dtype_code(y.dtype),
+              dtype_code(out_dtype), _stream())
+    st.done = True
+    return out
+
+
+def bn_relu_apply_pool_fold(y: Tensor, st: BnState) -> Tuple[Tensor, Tensor]:
+    N, Cc, H2, W2 = y.shape
+    if H2 % 2 or W2 % 2:
+        raise ValueError(f"max-pool 2x2 needs even spatial dims, got {H2}x{W2}")
+    out = empty_nhwc(N, Cc, H2, W2, y.dtype, y.device)
+    pooled = empty_nhwc(N, Cc, H2 // 2, W2 // 2, y.dtype, y.device)
+    dt = dtype_code(y.dtype)
+    _lib.call("cy_bn_relu_apply_pool_fold", y.data_ptr(), st.ref, out.data_ptr(), pooled.data_ptr(), N, H2 // 2,
+              W2 // 2, dt, dt, _stream())
+    st.done = True
+    return out, pooled
+
+
+def bn_running_update(items) -> None:
+    """items: [(coef [5, C], running_mean, running_var, momentum)] -- the running statistics of all of them in one
+    launch per 32 layers, event-ordered against the other pass of a two-stream step like the per-layer updates were"""
+    if not items:
+        return
+    arr = (_lib.BnRunItem * len(items))()
+    for a, (coef, rm, rv, mom) in zip(arr, items):
+        a.coef, a.running_mean, a.running_var, a.C, a.momentum = coef.data_ptr(), rm.data_ptr(), rv.data_ptr(), coef.shape[1], mom
+    with ordered("bn_running_batch"):
+        _lib.call("cy_bn_running_update", arr, len(items), _stream())
+
+
 def bn_finalize(partials: Optional[Tensor], count: int, gamma: Optional[Tensor], beta: Optional[Tensor],
                 running_mean: Optional[Tensor], running_var: Optional[Tensor], momentum: float,
                 eps: float, use_batch_stats: bool, update_running: bool, Cc: int, device):
@@ -714,7 +845,8 @@ def bn_finalize(partials: Optional[Tensor], count: int, gamma: Optional[Tensor],
                   out[2].data_ptr(), out[3].data_ptr(), _stream())
 
     if running_mean is not None and (update_running or not use_batch_stats):
-        with ordered(("bn_running", running_mean.data_ptr())):  # reads or updates the running statistics
+        # reads or updates the running statistics (the batched updates of the accumulator path share the second key)
+        with ordered(("bn_running", running_mean.data_ptr())), ordered("bn_running_batch"):
             launch()
     else:
         launch()
@@ -791,15 +923,82 @@ def bn_relu_bwd(da: Tensor, y: Tensor, scale: Tensor, shift: Tensor, mean: Tenso
     return dy, dgamma, dbeta
 
 
+POOL_BN_FUSE = os.environ.get("CY_POOL_BN_FUSE", "1") != "0"  # (A/B switch)
+
+
+def bn_relu_bwd_acc(da: Tensor, y: Tensor, coef: Tensor, batch_stats: bool, dgamma_out: Optional[Tensor] = None,
+                    dbeta_out: Optional[Tensor] = None, want_param_grads: bool = True,
+                    acc: Optional[BnAccBuf] = None, acc_filled: bool = False):
+    """bn_relu_bwd on an accumulator: the reduce launch adds the sums of dz and dz*xhat into `acc` (skipped when the
+    kernel that produced `da` already did, `acc_filled`), the apply launch derives (k1, k0) from it and its first
+    workgroup adds the parameter gradients -- two launches instead of three.  coef: the forward pass's [5, C]."""
+    N, Cc, H, W = y.shape
+    npix = N * H * W
+    dev = y.device
+    dt = dtype_code(y.dtype)
+    if da.dtype != y.dtype:
+        da = da.to(y.dtype)
+    da = to_nhwc(da)
+    if acc is None:
+        acc = bn_acc_new(Cc, _lib.call("cy_bn_relu_bwd_workgroups", npix, Cc), dev)
+    if not acc_filled:
+        _lib.call("cy_bn_relu_bwd_reduce_acc", da.data_ptr(), Cc, y.data_ptr(), coef.data_ptr(), acc.ref, npix, Cc, dt,
+                  _stream())
+    accum = dgamma_out is not None
+    dgamma = dbeta = None
+    if accum:
+        pg, pb = dgamma_out, dbeta_out
+    elif want_param_grads:
+        gb = _f32(2 * Cc, dev).view(2, Cc)
+        dgamma, dbeta = gb[0], gb[1]
+        pg, pb = dgamma, dbeta
+    else:
+        pg = pb = None
+    dy = empty_nhwc(N, Cc, H, W, y.dtype, dev)
+
+    def apply():
+        _lib.call("cy_bn_relu_bwd_apply_fold", da.data_ptr(), Cc, y.data_ptr(), coef.data_ptr(), acc.ref, float(npix),
+                  int(batch_stats), _ptr(pg), _ptr(pb), int(accum), dy.data_ptr(), npix, Cc, dt, _stream())
+
+    if accum:
+        with ordered(("bn_grad", pg.data_ptr())):  # in-place accumulation into the parameters' .grad
+            apply()
+    else:
+        apply()
+    return dy, dgamma, dbeta
+
+
+def bn_bwd_acc_new(N: int, Cc: int, H: int, W: int, pooled: bool, device) -> BnAccBuf:
+    """a zeroed accumulator for the backward sums of a BatchNorm over [N, C, H, W], sized for whichever kernel will
+    fill it (the reduce launch, or the pool backward of the block's output)"""
+    wgs = _lib.call("cy_bn_relu_bwd_workgroups", N * H * W, Cc)
+    if pooled and POOL_BN_FUSE and H % 2 == 0 and W % 2 == 0:
+        wgs = max(wgs, _lib.load().cy_maxpool2_bwd_bn_num_partials(N, H // 2, W // 2, Cc))
+    return bn_acc_new(Cc, wgs, device)
+
+
+def maxpool2_bwd_bn_acc(x: Tensor, dpool: Tensor, add: Optional[Tensor], y: Tensor, coef: Tensor,
+                        acc: Optional[BnAccBuf] = None):
+    """maxpool2_bwd whose result is the dA of relu(bn(y)), with that BatchNorm's backward sums added into `acc` (a new
+    accumulator if None): (dx, acc), or (dx, None) where the fused form does not apply"""
+    N, Cc, H2, W2 = x.shape
+    npart = _lib.load().cy_maxpool2_bwd_bn_num_partials(N, H2 // 2, W2 // 2, Cc) if POOL_BN_FUSE else 0
+    if npart <= 0:
+        return maxpool2_bwd(x, dpool, add), None
+    dx = empty_nhwc(N, Cc, H2, W2, x.dtype, x.device)
+    if acc is None:
+        acc = bn_acc_new(Cc, npart, x.device)
+    _lib.call("cy_maxpool2_bwd_bn_acc", x.data_ptr(), dpool.data_ptr(), _ptr(add), Cc, dx.data_ptr(), y.data_ptr(),
+              coef.data_ptr(), acc.ref, N, H2 // 2, W2 // 2, Cc, dtype_code(x.dtype), _stream())
+    return dx, acc
+
+
 def maxpool2_bwd(x: Tensor, dpool: Tensor, add: Optional[Tensor] = None) -> Tensor:
     N, Cc, H2, W2 = x.shape
     dx = empty_nhwc(N, Cc, H2, W2, x.dtype, x.device)
     _lib.call("cy_maxpool2_bwd", x.data_ptr(), dpool.data_ptr(), _ptr(add), Cc, dx.data_ptr(), N,
               H2 // 2, W2 // 2, Cc, dtype_code(x.dtype), _stream())
     return dx
-
-
-POOL_BN_FUSE = os.environ.get("CY_POOL_BN_FUSE", "1") != "0"  # (A/B switch)
 
 
 def maxpool2_bwd_bn(x: Tensor, dpool: Tensor, add: Optional[Tensor], y: Tensor, scale: Tensor, shift: Tensor,

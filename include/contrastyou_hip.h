@@ -195,6 +195,72 @@ int cy_conv3x3_wgrad_pair(const cy_conv_desc* d, const void* src1, const void* s
                           const void* dy_b, float* dw, int accumulate, void* ws, size_t ws_bytes,
                           void* stream);
 
+/* ---- BatchNorm sums without finalize launches (ABI v11; csrc/cy_bn_acc.h) -------------------------------------
+ * A training-mode nn.BatchNorm2d (arch/unet.py:22,25,40) needs per-channel sums over the whole batch.  Instead of
+ * per-workgroup partial rows + a finalize launch per layer (cy_bn_finalize / cy_bn_bwd_finalize below, still there),
+ * the producing kernels ADD their partials into an accumulator -- 64-bit integer atomics on a two-limb fixed-point
+ * split, so the result does not depend on the order of arrival -- and the consuming kernels derive the coefficients
+ * themselves; the consumer's first workgroup leaves them in memory (`coef`) for the backward pass.
+ * Accumulator: int64 words [R][4][C] ({sum hi, lo, sum of squares hi, lo} per replica) + R flag words; the caller
+ * zeroes it before the producing launch.  R = cy_bn_acc_replicas(C, workgroups adding into a channel). */
+typedef struct cy_bn_acc {
+  void* acc;
+  int32_t R, C;
+} cy_bn_acc;
+typedef struct cy_bn_fold {
+  const void* acc;     /* the accumulator the previous conv filled */
+  int32_t R, C;
+  const float* gamma;  /* [C] or NULL (1) */
+  const float* beta;   /* [C] or NULL (0) */
+  double count;        /* N*H*W */
+  float eps;
+  int32_t reserved;
+  float* coef;         /* [5][C] f32: scale, shift, mean, invstd, unbiased variance (for cy_bn_running_update) */
+} cy_bn_fold;
+int cy_bn_acc_replicas(int C, int workgroups);
+size_t cy_bn_acc_bytes(int C, int R);
+/* workgroups of cy_conv3x3_fwd(d) / cy_conv3x3_first_fwd that add into one channel's sums (for cy_bn_acc_replicas) */
+int cy_conv3x3_stat_workgroups(const cy_conv_desc* d);
+/* cy_conv3x3_fwd with either side of the convolution on accumulators: `in_fold` != NULL (and d->prologue): the
+ * BN+ReLU coefficients of source 1 come from the previous layer's accumulator (kernels that cannot fold in place
+ * run cy_bn_fold first); `out_acc` != NULL: the statistics of the output are added into it. */
+int cy_conv3x3_fwd_bn(const cy_conv_desc* d, const void* src1, const void* src2, const cy_bn_fold* in_fold,
+                      const float* scale, const float* shift, const void* w_packed, void* out, void* out2,
+                      float* stats, const cy_bn_acc* out_acc, void* ws, size_t ws_bytes, void* stream);
+int cy_conv3x3_first_fwd_acc(const float* x, const float* w, void* out, const cy_bn_acc* out_acc, int N, int Cin,
+                             int H, int W, int Cout, int out_dtype, void* stream);
+/* accumulator -> f->coef as its own launch (what a folding consumer does in its first workgroup) */
+int cy_bn_fold_coef(const cy_bn_fold* f, void* stream);
+/* out = relu(scale*y + shift) (+ 2x2 max) with the coefficients taken from the accumulator */
+int cy_bn_relu_apply_fold(const void* y, const cy_bn_fold* f, void* out, long npix, int y_dtype, int out_dtype,
+                          void* stream);
+int cy_bn_relu_apply_pool_fold(const void* y, const cy_bn_fold* f, void* out, void* pooled, int N, int H, int W,
+                               int y_dtype, int out_dtype, void* stream);
+/* running statistics of up to 32 BatchNorm layers in ONE launch: running = (1 - momentum) * running + momentum *
+ * batch moment, from the `coef` arrays their consumers left (rows 2 and 4).  `h_items` is a HOST array: the
+ * pointers travel as kernel arguments (capturable, no device table). */
+typedef struct cy_bn_run_item {
+  const float* coef;
+  float* running_mean;
+  float* running_var;
+  int32_t C;
+  float momentum;
+} cy_bn_run_item;
+int cy_bn_running_update(const cy_bn_run_item* h_items, int n, void* stream);
+/* backward: the sums of dz and dz*xhat into an accumulator (as cy_bn_relu_bwd_reduce / cy_maxpool2_bwd_bn write
+ * partial rows); coef = the forward pass's [5][C] */
+int cy_bn_relu_bwd_reduce_acc(const void* da, int ld_da, const void* y, const float* coef, const cy_bn_acc* acc,
+                              long npix, int C, int dtype, void* stream);
+int cy_bn_relu_bwd_workgroups(long npix, int C);
+int cy_maxpool2_bwd_bn_acc(const void* x, const void* dpool, const void* add, int ld_add, void* dx, const void* y,
+                           const float* coef, const cy_bn_acc* acc, int N, int H, int W, int C, int dtype,
+                           void* stream);
+/* dy = scale*dz + k1*y + k0 with (k1, k0) derived from the accumulator; the first workgroup adds (accumulate != 0) or
+ * stores dgamma / dbeta (either may be NULL) */
+int cy_bn_relu_bwd_apply_fold(const void* da, int ld_da, const void* y, const float* coef, const cy_bn_acc* acc,
+                              double count, int batch_stats, float* dgamma, float* dbeta, int accumulate, void* dy,
+                              long npix, int C, int dtype, void* stream);
+
 /* First layer (input_dim 1..4, arch/unet.py:72): x is the f32 NCHW image
  * [N,Cin,H,W]; w is the reference-layout f32 weight [Cout][Cin][3][3]. */
 int cy_conv3x3_first_num_partials(int N, int H, int W, int Cout);
