@@ -84,10 +84,42 @@ __device__ __forceinline__ double bn_acc_read(const unsigned long long* acc, int
   return (double)hi * (1.0 / 4096.0) + (double)lo * (1.0 / 17592186044416.0);
 }
 
-// coefficients of channel c; the leader also leaves them (and the batch moments) in f.coef.  Same arithmetic as the
-// finalize kernel of rounds 1-3 (f64 throughout, variance clamped at 0).
+// The replicas of an accumulator summed into LDS by ALL threads of a workgroup: s_sum[4 * C + 1] (64-bit words: the four
+// limb rows, then the flag).  One thread per channel walking the replicas (the first version) is a chain of dependent
+// round trips -- R / 4 of them, 4-8 us on the 32-channel layers with R = 32; here every thread has its R * 4 * C / nthr
+// loads in flight at once and adds them with LDS atomics (integer adds: any order gives the same words).
+__device__ __forceinline__ void bn_acc_gather(const unsigned long long* acc, int R, int C, unsigned long long* s_sum,
+                                              int tid, int nthr) {
+  const int row = 4 * C;
+  for (int i = tid; i <= row; i += nthr) s_sum[i] = 0ull;
+  __syncthreads();
+  const int n = R * row;
+#pragma unroll 4
+  for (int i = tid; i < n; i += nthr) {
+    const unsigned long long v = acc[i];
+    atomicAdd(&s_sum[i % row], v);
+  }
+  if (tid < R && acc[n + tid]) atomicOr(&s_sum[row], 1ull);
+  __syncthreads();
+}
+__device__ __forceinline__ double bn_sum_read(const unsigned long long* s_sum, int C, int q, int c) {
+  if (s_sum[4 * C]) return __builtin_nan("");
+  return (double)(long long)s_sum[(2 * q) * C + c] * (1.0 / 4096.0) +
+         (double)(long long)s_sum[(2 * q + 1) * C + c] * (1.0 / 17592186044416.0);
+}
+
+// coefficients of channel c from the two sums; the leader also leaves them (and the batch moments) in f.coef.  Same
+// arithmetic as the finalize kernel of rounds 1-3 (f64 throughout, variance clamped at 0).
+__device__ __forceinline__ void bn_fold_finish(const BnFold& f, int c, bool leader, double s1, double s2, float& sc, float& sh);
 __device__ __forceinline__ void bn_fold_channel(const BnFold& f, int c, bool leader, float& sc, float& sh) {
-  const double s1 = bn_acc_read(f.acc, f.R, f.C, 0, c), s2 = bn_acc_read(f.acc, f.R, f.C, 1, c);
+  bn_fold_finish(f, c, leader, bn_acc_read(f.acc, f.R, f.C, 0, c), bn_acc_read(f.acc, f.R, f.C, 1, c), sc, sh);
+}
+// (after bn_acc_gather(f.acc, f.R, f.C, s_sum, ...))
+__device__ __forceinline__ void bn_fold_channel_lds(const BnFold& f, const unsigned long long* s_sum, int c, bool leader,
+                                                    float& sc, float& sh) {
+  bn_fold_finish(f, c, leader, bn_sum_read(s_sum, f.C, 0, c), bn_sum_read(s_sum, f.C, 1, c), sc, sh);
+}
+__device__ __forceinline__ void bn_fold_finish(const BnFold& f, int c, bool leader, double s1, double s2, float& sc, float& sh) {
   const double mean = s1 * f.inv_count;
   double var = s2 * f.inv_count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -105,8 +137,10 @@ __device__ __forceinline__ void bn_fold_channel(const BnFold& f, int c, bool lea
 }
 
 // backward coefficients of channel c: dy = scale * dz + k1 * y + k0; the leader adds the parameter gradients
-__device__ __forceinline__ void bn_bwd_fold_channel(const BnBwdFold& f, int c, bool leader, float& k1o, float& k0o) {
-  const double t1 = bn_acc_read(f.acc, f.R, f.C, 0, c), t2 = bn_acc_read(f.acc, f.R, f.C, 1, c);
+// (after bn_acc_gather(f.acc, f.R, f.C, s_sum, ...))
+__device__ __forceinline__ void bn_bwd_fold_channel(const BnBwdFold& f, const unsigned long long* s_sum, int c, bool leader,
+                                                    float& k1o, float& k0o) {
+  const double t1 = bn_sum_read(s_sum, f.C, 0, c), t2 = bn_sum_read(s_sum, f.C, 1, c);
   double k1 = 0.0, k0 = 0.0;
   if (f.batch_stats) {
     const double sc = (double)f.coef[c], mu = (double)f.coef[2 * f.C + c], is = (double)f.coef[3 * f.C + c];

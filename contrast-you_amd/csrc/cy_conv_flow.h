@@ -57,6 +57,7 @@ template <typename T, int TH_, int BN_, int WGM_, int WGN_, bool W16_> struct Fl
   static_assert(WGM * 2 * BN * 4 <= STAGE, "statistics scratch");
   static_assert(SMEM <= 160 * 1024, "LDS");
   static_assert(COEF_MAX <= NTHR, "one prologue coefficient pair per thread");
+  static_assert((4 * COEF_MAX + 1) * 8 <= B_BYTES, "the accumulator sums of the fold fit the second stage's weight region");
 };
 
 // elements of the stage-contiguous weight image of a (Cout, Cin) kernel (0: this geometry has none)
@@ -268,7 +269,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
   if (a.prologue) {  // wave-uniform
     // coefficients from the previous layer's sums (cy_bn_acc.h): behind the first chunk's DMA, whose flight time covers
     // the accumulator reads; workgroup 0 leaves them in memory for the backward pass
-    if (a.fold.acc && tid < a.C1) bn_fold_channel(a.fold, tid, blockIdx.x == 0 && blockIdx.z == 0, csc, csh);
+    if (a.fold.acc) {  // (the sums of the replicas through LDS: the weight region of the second stage is idle until chunk 1)
+      unsigned long long* s_sum = reinterpret_cast<unsigned long long*>(smem + C::STAGE + C::A_BYTES);
+      bn_acc_gather(a.fold.acc, a.fold.R, a.C1, s_sum, tid, C::NTHR);
+      if (tid < a.C1) bn_fold_channel_lds(a.fold, s_sum, tid, blockIdx.x == 0 && blockIdx.z == 0, csc, csh);
+    }
     if (tid < a.C1) {
       s_coef[tid] = csc;
       s_coef[C::COEF_MAX + tid] = csh;

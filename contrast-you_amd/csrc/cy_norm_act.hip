@@ -82,9 +82,11 @@ __global__ void __launch_bounds__(1024)
 template <bool FOLD>
 __device__ __forceinline__ void bn_fold_table(const BnFold& f, float* s_coef) {
   if constexpr (FOLD) {
+    unsigned long long* s_sum = reinterpret_cast<unsigned long long*>(s_coef + 2 * f.C);  // [4 C + 1] (host: C % 8 == 0)
+    bn_acc_gather(f.acc, f.R, f.C, s_sum, threadIdx.x, 256);
     for (int c = threadIdx.x; c < f.C; c += 256) {
       float a, b;
-      bn_fold_channel(f, c, blockIdx.x == 0, a, b);
+      bn_fold_channel_lds(f, s_sum, c, blockIdx.x == 0, a, b);
       s_coef[c] = a;
       s_coef[f.C + c] = b;
     }
@@ -96,22 +98,35 @@ template <typename TI, typename TO, bool FOLD>
 __global__ void __launch_bounds__(256)
     bn_relu_apply_kernel(const TI* __restrict__ y, const float* __restrict__ scale,
                          const float* __restrict__ shift, TO* __restrict__ out, long npix, int C, const BnFold fold) {
-  extern __shared__ __attribute__((aligned(16))) float s_coef[];  // FOLD: [2][C]
-  bn_fold_table<FOLD>(fold, s_coef);
-  // unit of work: 8 channels of one pixel (one 16-byte bf16 chunk / two f32 chunks)
+  extern __shared__ __attribute__((aligned(16))) float s_coef[];  // FOLD: [2][C] floats, then [4 C + 1] 64-bit sums
+  // unit of work: 8 channels of one pixel (one 16-byte bf16 chunk / two f32 chunks).  The item after the current one
+  // is always in flight; the FIRST one is requested before the coefficients are derived (FOLD: the accumulator's round
+  // trip and the data's overlap -- on the small maps the kernel is nothing but that chain of latencies).
   const int G = C / 8;
   const long total = npix * G;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+  const long stride = (long)gridDim.x * 256L;
+  long i = blockIdx.x * 256L + threadIdx.x;
+  u32x4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
+  auto request = [&](long idx) {
+    const int g = (int)(idx % G);
+    const TI* yp = y + (idx / G) * C + g * 8;
+    r0 = ld16(yp);
+    if constexpr (sizeof(TI) == 4) r1 = ld16(yp + 4);
+  };
+  if (i < total) request(i);
+  bn_fold_table<FOLD>(fold, s_coef);
+  while (i < total) {
     const int g = (int)(i % G);
     const long p = i / G;
     float f[8];
-    const TI* yp = y + p * C + g * 8;
     if constexpr (sizeof(TI) == 2) {
-      Chunk<TI>::unpack(ld16(yp), f);
+      Chunk<TI>::unpack(r0, f);
     } else {
-      Chunk<float>::unpack(ld16(yp), f);
-      Chunk<float>::unpack(ld16(yp + 4), f + 4);
+      Chunk<float>::unpack(r0, f);
+      Chunk<float>::unpack(r1, f + 4);
     }
+    const long nxt = i + stride;
+    if (nxt < total) request(nxt);
     f32x4 s0, s1, h0, h1;
     if constexpr (FOLD) {
       s0 = *reinterpret_cast<const f32x4*>(s_coef + g * 8), s1 = *reinterpret_cast<const f32x4*>(s_coef + g * 8 + 4);
@@ -132,6 +147,7 @@ __global__ void __launch_bounds__(256)
       st16(op, Chunk<float>::pack(f));
       st16(op + 4, Chunk<float>::pack(f + 4));
     }
+    i = nxt;
   }
 }
 
@@ -144,7 +160,7 @@ __global__ void __launch_bounds__(256)
     bn_relu_apply_pool_kernel(const TI* __restrict__ y, const float* __restrict__ scale,
                               const float* __restrict__ shift, TO* __restrict__ out, TO* __restrict__ pooled,
                               int N, int H, int W, int C, const BnFold fold) {
-  extern __shared__ __attribute__((aligned(16))) float s_coef[];  // FOLD: [2][C]
+  extern __shared__ __attribute__((aligned(16))) float s_coef[];  // FOLD: [2][C] floats, then [4 C + 1] 64-bit sums
   bn_fold_table<FOLD>(fold, s_coef);
   const int G = C / 8;
   const long total = (long)N * H * W * G;
@@ -385,28 +401,53 @@ __global__ void __launch_bounds__(256)
     bn_relu_bwd_apply_kernel(const T* __restrict__ da, int ld_da, const T* __restrict__ y,
                              const float* __restrict__ scale, const float* __restrict__ shift,
                              const float* __restrict__ coef, T* __restrict__ dy, long npix, int C, const BnBwdFold fold) {
-  extern __shared__ __attribute__((aligned(16))) float s_coef[];  // FOLD: [4][C] = scale, shift, k1, k0
+  extern __shared__ __attribute__((aligned(16))) float s_coef[];  // FOLD: [4][C] = scale, shift, k1, k0, then [4 C + 1] 64-bit sums
+  const int G = C / 8;
+  const bool pow2 = (G & (G - 1)) == 0;
+  const int gshift = 31 - __clz(G);
+  const long total = npix * G;
+  const long stride = (long)gridDim.x * 256L;
+  long i = blockIdx.x * 256L + threadIdx.x;
+  // the next item's (da, y) are always in flight; the first one's before the coefficients are derived (see
+  // bn_relu_apply_kernel)
+  u32x4 rd0 = {0u, 0u, 0u, 0u}, rd1 = {0u, 0u, 0u, 0u}, rv0 = {0u, 0u, 0u, 0u}, rv1 = {0u, 0u, 0u, 0u};
+  auto request = [&](long idx) {
+    const int g = pow2 ? (int)(idx & (G - 1)) : (int)(idx % G);
+    const long p = pow2 ? (idx >> gshift) : (idx / G);
+    const T* dp = da + p * ld_da + g * 8;
+    const T* vp = y + p * C + g * 8;
+    rd0 = ld16(dp), rv0 = ld16(vp);
+    if constexpr (sizeof(T) == 4) rd1 = ld16(dp + 4), rv1 = ld16(vp + 4);
+  };
+  if (i < total) request(i);
   if constexpr (FOLD) {
-    for (int c = threadIdx.x; c < C; c += 256) {
-      float k1v, k0v;
-      bn_bwd_fold_channel(fold, c, blockIdx.x == 0, k1v, k0v);
+    unsigned long long* s_sum = reinterpret_cast<unsigned long long*>(s_coef + 4 * C);
+    for (int c = threadIdx.x; c < C; c += 256) {  // (the forward coefficients: requested before the accumulator)
       s_coef[c] = scale[c];
       s_coef[C + c] = shift[c];
+    }
+    bn_acc_gather(fold.acc, fold.R, C, s_sum, threadIdx.x, 256);
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float k1v, k0v;
+      bn_bwd_fold_channel(fold, s_sum, c, blockIdx.x == 0, k1v, k0v);
       s_coef[2 * C + c] = k1v;
       s_coef[3 * C + c] = k0v;
     }
     __syncthreads();
   }
-  const int G = C / 8;
-  const bool pow2 = (G & (G - 1)) == 0;
-  const int gshift = 31 - __clz(G);
-  const long total = npix * G;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+  while (i < total) {
     const int g = pow2 ? (int)(i & (G - 1)) : (int)(i % G);
     const long p = pow2 ? (i >> gshift) : (i / G);
     float d[8], v[8], o[8];
-    load8<T>(da + p * ld_da + g * 8, d);
-    load8<T>(y + p * C + g * 8, v);
+    if constexpr (sizeof(T) == 2) {
+      Chunk<T>::unpack(rd0, d);
+      Chunk<T>::unpack(rv0, v);
+    } else {
+      Chunk<float>::unpack(rd0, d), Chunk<float>::unpack(rd1, d + 4);
+      Chunk<float>::unpack(rv0, v), Chunk<float>::unpack(rv1, v + 4);
+    }
+    const long nxt = i + stride;
+    if (nxt < total) request(nxt);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       f32x4 a, b, c1, c0;
@@ -426,6 +467,7 @@ __global__ void __launch_bounds__(256)
       }
     }
     store8<T>(dy + p * C + g * 8, o);
+    i = nxt;
   }
 }
 
@@ -558,10 +600,11 @@ __global__ void __launch_bounds__(256)
 
 // accumulator -> coefficients as a launch of its own (for consumers that cannot fold in place)
 __global__ void __launch_bounds__(256) bn_fold_kernel(const BnFold f) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c < f.C) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_sum_k[];  // [4 C + 1]
+  bn_acc_gather(f.acc, f.R, f.C, s_sum_k, threadIdx.x, 256);
+  for (int c = threadIdx.x; c < f.C; c += 256) {
     float a, b;
-    bn_fold_channel(f, c, true, a, b);
+    bn_fold_channel_lds(f, s_sum_k, c, true, a, b);
   }
 }
 
@@ -580,8 +623,10 @@ __global__ void __launch_bounds__(256) bn_running_update_kernel(const BnRunArgs 
 
 // grid of the folding elementwise kernels: every workgroup reads the accumulator, so few, long-running workgroups
 inline int fold_grid(long items) {
-  long b = (items + 1023) / 1024;
-  if (b > 1024) b = 1024;
+  static const int div = [] { const char* e = getenv("CY_FOLD_GRID_DIV"); return e ? atoi(e) : 1024; }();
+  static const int cap = [] { const char* e = getenv("CY_FOLD_GRID_MAX"); return e ? atoi(e) : 1024; }();
+  long b = (items + div - 1) / div;
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -617,11 +662,11 @@ static int bn_relu_apply_impl(const void* y, const float* scale, const float* sh
   if (!y || !out || npix <= 0) return CY_ERR_ARG;
   if (!f && (!scale || !shift)) return CY_ERR_ARG;
   if (f && (!f->acc || !f->coef || f->C != C || f->R < 1 || (f->R & (f->R - 1)) || f->count <= 0)) return CY_ERR_ARG;
-  if (C % 8) return CY_ERR_SHAPE;
+  if (C % 8 || (f && C > 1024)) return CY_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const BnFold bf = f ? bn_fold_from_abi(f) : BnFold{};
   const int grid = f ? fold_grid(npix * (C / 8)) : stream_grid(npix * (C / 8));
-  const size_t smem = f ? (size_t)2 * C * sizeof(float) : 0;
+  const size_t smem = f ? (size_t)2 * C * sizeof(float) + ((size_t)4 * C + 2) * 8 : 0;
 #define CY_APPLY(TI, TO)                                                                                        \
   do {                                                                                                          \
     if (f) hipLaunchKernelGGL((bn_relu_apply_kernel<TI, TO, true>), dim3(grid), dim3(256), smem, st, (const TI*)y, \
@@ -656,12 +701,12 @@ static int bn_relu_apply_pool_impl(const void* y, const float* scale, const floa
   if (!y || !out || !pooled || N <= 0 || H <= 0 || W <= 0) return CY_ERR_ARG;
   if (!f && (!scale || !shift)) return CY_ERR_ARG;
   if (f && (!f->acc || !f->coef || f->C != C || f->R < 1 || (f->R & (f->R - 1)) || f->count <= 0)) return CY_ERR_ARG;
-  if (C % 8) return CY_ERR_SHAPE;
+  if (C % 8 || (f && C > 1024)) return CY_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const BnFold bf = f ? bn_fold_from_abi(f) : BnFold{};
   const long items = (long)N * H * W * (C / 8);
   const int grid = f ? fold_grid(items * 4) : stream_grid(items);
-  const size_t smem = f ? (size_t)2 * C * sizeof(float) : 0;
+  const size_t smem = f ? (size_t)2 * C * sizeof(float) + ((size_t)4 * C + 2) * 8 : 0;
 #define CY_APPLY_POOL(TI, TO)                                                                                      \
   do {                                                                                                             \
     if (f) hipLaunchKernelGGL((bn_relu_apply_pool_kernel<TI, TO, true>), dim3(grid), dim3(256), smem, st,          \
@@ -691,7 +736,8 @@ int cy_bn_relu_apply_pool_fold(const void* y, const cy_bn_fold* f, void* out, vo
 
 int cy_bn_fold_coef(const cy_bn_fold* f, void* stream) {
   if (!f || !f->acc || !f->coef || f->C <= 0 || f->R < 1 || (f->R & (f->R - 1)) || f->count <= 0) return CY_ERR_ARG;
-  hipLaunchKernelGGL(bn_fold_kernel, dim3(cy_cdiv(f->C, 256)), dim3(256), 0, (hipStream_t)stream, bn_fold_from_abi(f));
+  if (f->C > 2048) return CY_ERR_SHAPE;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(1), dim3(256), ((size_t)4 * f->C + 2) * 8, (hipStream_t)stream, bn_fold_from_abi(f));
   CY_CHECK_LAUNCH();
   return CY_OK;
 }
@@ -807,13 +853,13 @@ int cy_bn_relu_bwd_apply_fold(const void* da, int ld_da, const void* y, const fl
                               long npix, int C, int dtype, void* stream) {
   if (!da || !y || !coef || !dy || !acc || !acc->acc || acc->C != C || acc->R < 1 || (acc->R & (acc->R - 1)) || count <= 0)
     return CY_ERR_ARG;
-  if (C % 8 || ld_da % 8 || ld_da < C) return CY_ERR_SHAPE;
+  if (C % 8 || ld_da % 8 || ld_da < C || C > 1024) return CY_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   BnBwdFold f;
   f.acc = (const unsigned long long*)acc->acc, f.R = acc->R, f.C = C, f.coef = coef;
   f.inv_count = 1.0 / count, f.batch_stats = batch_stats, f.accumulate = accumulate, f.dgamma = dgamma, f.dbeta = dbeta;
   const int grid = fold_grid(npix * (C / 8));
-  const size_t smem = (size_t)4 * C * sizeof(float);
+  const size_t smem = (size_t)4 * C * sizeof(float) + ((size_t)4 * C + 2) * 8;
 #define CY_BWD_APPLY(TT)                                                                                          \
   hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<TT, true>), dim3(grid), dim3(256), smem, st, (const TT*)da, ld_da,  \
                      (const TT*)y, coef, coef + C, (const float*)nullptr, (TT*)dy, npix, C, f)

@@ -270,8 +270,8 @@ class ConvChainFn(torch.autograd.Function):
             w, g, b = params[3 * i: 3 * i + 3]
             bn = cfg.bns[i]
             use_batch, update = _bn_flags(bn)
-            acc_i = ops.BN_ACC and use_batch
             Cout = w.shape[0]
+            acc_i = ops.BN_ACC and use_batch and Cout <= 1024
             if i == 0 and cfg.first:
                 y, part = ops.conv_first_fwd(cur, w, dt, want_stats=use_batch, stats_acc=acc_i)
             else:
@@ -319,7 +319,7 @@ class ConvChainFn(torch.autograd.Function):
                 ops.bn_running_update(run_items)
         # accumulators of the backward sums, from the same zeroed arena (the backward pass allocates nothing to zero)
         ctx.bwd_accs = None
-        if ops.BN_ACC and any(ctx.needs_input_grad):
+        if ops.BN_ACC and any(ctx.needs_input_grad) and all(yy.shape[1] <= 1024 for yy in ys):
             ctx.bwd_accs = [ops.bn_bwd_acc_new(yy.shape[0], yy.shape[1], yy.shape[2], yy.shape[3],
                                                cfg.pool_out and j == nconv - 1, dev) for j, yy in enumerate(ys)]
         if RAW_TAP is not None:
@@ -358,9 +358,10 @@ class ConvChainFn(torch.autograd.Function):
         ys = [t.pop(0) for _ in range(nconv)]
         coefs = [tuple(t.pop(0) for _ in range(4)) for _ in range(nconv)]
         pool_partials = None
-        accs = ctx.bwd_accs if ops.BN_ACC else None
+        acc_ok = ops.BN_ACC and all(yy.shape[1] <= 1024 for yy in ys)
+        accs = ctx.bwd_accs if acc_ok else None
         ctx.bwd_accs = None  # (a second backward through the same node gets fresh accumulators)
-        if ops.BN_ACC and accs is None:
+        if acc_ok and accs is None:
             accs = [None] * nconv
         pool_acc_filled = False
         if cfg.pool_out and dpooled is not None:
