@@ -535,7 +535,7 @@ struct ConvPlan {
 // Deep layers (14x14 / 28x28 at small batch) have too few output tiles to fill 256 CUs: split
 // the reduction over input-channel chunks across blockIdx.z.
 ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool stream_ok = false,
-                   bool prologue = false, FlowChoice fc = FlowChoice{false, 0, 0, 0, false}) {
+                   bool prologue = false, FlowChoice fc = FlowChoice{false, 0, 0, 0, false}, bool bwd_pro = false) {
   ConvPlan p;
   p.plane = use_plane_kernel(W);
   p.stream = false;
@@ -591,7 +591,8 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool 
       const char* e = getenv("CY_FLOW_3264_MIN");
       return e ? atoi(e) : 512;
     }();
-    if (flow_cfg == 0 && n3264 >= th3264 && !(prologue && Cin > 256)) {
+    // (not with the backward prologue: its extra halo buffer leaves room for one such workgroup per CU only)
+    if (flow_cfg == 0 && n3264 >= th3264 && !(prologue && Cin > 256) && !bwd_pro) {
       use = true, th = 32, bn = 64;
     } else if (flow_cfg == 1) {
       use = true;
@@ -634,7 +635,7 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool 
     }
     if (flow_cfg == 2 && fc.small_ok) use = true, th = 16, Z = 1;
     if (flow_cfg == 3 && !(prologue && Cin > 256)) use = true, th = 16, bn = 64, Z = 1;  // (experiment: 4-wave 16 x 64 tiles)
-    if (flow_cfg == 4 && !(prologue && Cin > 256)) use = true, th = 32, bn = 64, Z = 1;  // (experiment: 4-wave 32 x 64 tiles)
+    if (flow_cfg == 4 && !(prologue && Cin > 256) && !bwd_pro) use = true, th = 32, bn = 64, Z = 1;  // (experiment: 4-wave 32 x 64 tiles)
     if (const char* ov = getenv("CY_KSPLIT")) {
       const int z = atoi(ov);
       if (z >= 1) Z = z > nccf ? nccf : z;
@@ -1262,13 +1263,14 @@ static int conv_check(const cy_conv_desc* d) {
   if (d->mode1 == CY_SRC_UP2 && ((d->H & 1) || (d->W & 1))) return CY_ERR_SHAPE;
   if (d->mode1 < 0 || d->mode1 > 2) return CY_ERR_ARG;
   if (d->prologue && d->C2) return CY_ERR_ARG;
+  if (d->prologue < 0 || d->prologue > 2 || (d->prologue == 2 && d->mode1 != CY_SRC_DIRECT)) return CY_ERR_ARG;
   if (d->split_c > 0 && (d->split_c % epc || d->ldo2 % epc)) return CY_ERR_SHAPE;
   return CY_OK;
 }
 
 static ConvPlan plan_of(const cy_conv_desc* d) {
   return plan_conv(d->N, d->H, d->W, d->C1 + d->C2, d->Cout, d->in_dtype == CY_F32 ? 4 : 2, stream_applicable(d), d->prologue != 0,
-                   flow_choice(d));
+                   flow_choice(d), d->prologue == 2);
 }
 
 int cy_conv3x3_num_partials(const cy_conv_desc* d) {
@@ -1314,14 +1316,52 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
   return cy_conv3x3_fwd_bn(d, src1, src2, nullptr, scale, shift, w_packed, out, out2, stats, nullptr, ws, ws_bytes, stream);
 }
 
+static int conv_fwd_impl(const cy_conv_desc* d, const void* src1, const void* src2, const cy_bn_fold* in_fold,
+                         const float* scale, const float* shift, const cy_bn_bwd_in* bwd, const void* w_packed, void* out,
+                         void* out2, float* stats, const cy_bn_acc* out_acc, void* ws, size_t ws_bytes, void* stream);
+
 int cy_conv3x3_fwd_bn(const cy_conv_desc* d, const void* src1, const void* src2, const cy_bn_fold* in_fold,
                       const float* scale, const float* shift, const void* w_packed, void* out, void* out2,
                       float* stats, const cy_bn_acc* out_acc, void* ws, size_t ws_bytes, void* stream) {
+  if (d && d->prologue == 2) return CY_ERR_ARG;
+  return conv_fwd_impl(d, src1, src2, in_fold, scale, shift, nullptr, w_packed, out, out2, stats, out_acc, ws, ws_bytes, stream);
+}
+
+// the data gradient with the BatchNorm + ReLU backward in its load path: only the flow kernel's tilings that have room
+// for the y buffer take it
+static bool dgrad_bn_plan_ok(const cy_conv_desc* d, const ConvPlan& p) {
+  if (!p.flow || d->in_dtype == CY_F32 || d->C1 > 512) return false;
+  if (p.tile.bn == 64 && p.tile.th <= 32 && d->C1 > 256) return false;  // four-wave tilings: one coefficient set per thread
+  // Every cout block of a tile (and every tile, for its halo) repeats the in-LDS pass over (dA, y): with 64-cout tiles a
+  // 256-channel data gradient does it four times over, and the fused launch is slower than the two it replaces (28 x 28,
+  // 256 -> 256 at N = 16: 46.8 against 12.5 + 21.3 us; tools/bench_dgrad_bn.py).  It pays on the 128-cout tilings
+  // (56 x 56, 128 -> 128: 32.8 against 17.3 + 20.5).  CY_DGRAD_BN_ALL=1 lifts the rule (measurements).
+  static const int all = [] { const char* e = getenv("CY_DGRAD_BN_ALL"); return e ? atoi(e) : 0; }();
+  if (!all && p.tile.bn != 128) return false;
+  return d->in_dtype == CY_BF16 ? flow_bwd_ok<bf16>(p.tile.th, p.tile.bn, p.tile.tw) : flow_bwd_ok<f16>(p.tile.th, p.tile.bn, p.tile.tw);
+}
+
+int cy_conv3x3_dgrad_bn_ok(const cy_conv_desc* d) {
+  if (conv_check(d) != CY_OK || d->prologue != 2 || d->C2) return 0;
+  return dgrad_bn_plan_ok(d, plan_of(d)) ? 1 : 0;
+}
+
+int cy_conv3x3_dgrad_bn(const cy_conv_desc* d, const void* dA, const cy_bn_bwd_in* bn, const void* w_packed, void* out,
+                        void* out2, void* ws, size_t ws_bytes, void* stream) {
+  if (!d || d->prologue != 2 || !bn || !bn->y || !bn->coef || !bn->acc || !bn->acc->acc || !bn->dy || bn->count <= 0) return CY_ERR_ARG;
+  if (bn->acc->C != d->C1 || bn->acc->R < 1 || (bn->acc->R & (bn->acc->R - 1))) return CY_ERR_ARG;
+  return conv_fwd_impl(d, dA, nullptr, nullptr, nullptr, nullptr, bn, w_packed, out, out2, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+static int conv_fwd_impl(const cy_conv_desc* d, const void* src1, const void* src2, const cy_bn_fold* in_fold,
+                         const float* scale, const float* shift, const cy_bn_bwd_in* bwd, const void* w_packed, void* out,
+                         void* out2, float* stats, const cy_bn_acc* out_acc, void* ws, size_t ws_bytes, void* stream) {
   int rc = conv_check(d);
   if (rc != CY_OK) return rc;
   if (!src1 || !w_packed || !out) return CY_ERR_ARG;
   if (d->C2 && !src2) return CY_ERR_ARG;
-  if (d->prologue && !in_fold && (!scale || !shift)) return CY_ERR_ARG;
+  if ((d->prologue == 2) != (bwd != nullptr)) return CY_ERR_ARG;
+  if (d->prologue == 1 && !in_fold && (!scale || !shift)) return CY_ERR_ARG;
   if (in_fold && (!d->prologue || !in_fold->acc || !in_fold->coef || in_fold->C != d->C1 || in_fold->R < 1 ||
                   (in_fold->R & (in_fold->R - 1)) || in_fold->count <= 0))
     return CY_ERR_ARG;
@@ -1359,6 +1399,14 @@ int cy_conv3x3_fwd_bn(const cy_conv_desc* d, const void* src1, const void* src2,
   a.ws = (float*)ws;
   if (p.ksplit > 1 && (!ws || ws_bytes < p.ws_bytes)) return CY_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  if (bwd) {
+    if (!dgrad_bn_plan_ok(d, p)) return CY_ERR_SHAPE;
+    a.ysrc = bwd->y, a.bytes_y = a.bytes1;
+    a.dy_out = bwd->dy, a.bytes_dy = a.bytes1;
+    a.bfold.acc = (const unsigned long long*)bwd->acc->acc, a.bfold.R = bwd->acc->R, a.bfold.C = d->C1;
+    a.bfold.coef = bwd->coef, a.bfold.inv_count = 1.0 / bwd->count, a.bfold.batch_stats = bwd->batch_stats;
+    a.bfold.accumulate = bwd->accumulate, a.bfold.dgamma = bwd->dgamma, a.bfold.dbeta = bwd->dbeta;
+  }
   if (in_fold) {
     // the flow and streaming kernels derive the coefficients in place; the register-staged kernels (plane, igemm:
     // every thread fetches its channels' pairs per chunk) take them from memory after a fold launch

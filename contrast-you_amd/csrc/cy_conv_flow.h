@@ -47,10 +47,16 @@ template <typename T, int TH_, int BN_, int WGM_, int WGN_, bool W16_> struct Fl
   static constexpr int NAI = (NGA + NW / 2 - 1) / (NW / 2);    // ... per wave (wave -> plane wave & 1), at most
   static constexpr int NBITEMS = 9 * CPP * (BN / 64);          // 1 KB weight pieces per chunk
   static constexpr int NBI = (NBITEMS + NW - 1) / NW;
-  static constexpr int COEF_MAX = NTHR < 512 ? NTHR : 512;  // prologue channels held in LDS (one pair per thread)
-  static constexpr int COEF_BYTES = 2 * COEF_MAX * 4;
+  static constexpr int COEF_MAX = NTHR < 512 ? NTHR : 512;  // prologue channels held in LDS (one set per thread)
+  static constexpr int COEF_BYTES = 2 * COEF_MAX * 4;       // rows: scale, shift
   static constexpr int TAB_BYTES = ((3 * TH + 4) * 4 + 15) & ~15;
   static constexpr int SMEM = 2 * STAGE + COEF_BYTES + TAB_BYTES;
+  // backward prologue (prologue == 2): one more halo tile buffer for y (single: it is consumed by the in-place pass that
+  // opens the chunk, before the next chunk's request is issued), behind everything else
+  static constexpr int Y_OFF = SMEM;
+  static constexpr int K_OFF = SMEM + A_BYTES;  // ... and the coefficient rows k1, k0
+  static constexpr int SMEM_BWD = SMEM + A_BYTES + COEF_BYTES;
+  static constexpr bool BWD_OK = SMEM_BWD <= 160 * 1024 && (NW == 8 || 2 * SMEM_BWD <= 160 * 1024);
   static_assert(sizeof(T) == 2 && EPC == 8, "16-bit storage types only");
   static_assert(NW % 2 == 0 && MT % WGM == 0 && BN % (32 * WGN) == 0 && BN % 64 == 0, "wave split");
   static_assert(NAI <= 9 && NBI <= 9, "one DMA slot per tap");
@@ -79,7 +85,9 @@ inline long flow_image_elems(int Cout, int Cin) {
 #define FLOW_STAMP(K, V) do { } while (0)
 #endif
 
-template <typename T, int TH, int BN, int WGM, int WGN, bool W16>
+// BWD: the instantiation for prologue == 2 (the BatchNorm + ReLU backward in the load path); its own build so that the
+// forward kernels keep their register budget
+template <typename T, int TH, int BN, int WGM, int WGN, bool W16, bool BWD = false>
 __global__ void __launch_bounds__(64 * WGM * WGN, 2)
     conv3x3_flow_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (buffer-descriptor type and builtins exist in the device pass only)
@@ -159,11 +167,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
   };
   // BN+ReLU coefficients of the previous layer: requested BEFORE any DMA (vmcnt retires in order: a load behind the
   // DMAs would wait for all of them), written to LDS behind the halo requests
+  constexpr bool pro2 = BWD;  // BatchNorm + ReLU BACKWARD in the load path (source 1 = dA, a.ysrc = y); host: a.prologue == 2
   float csc = 0.f, csh = 0.f;
-  if (a.prologue && !a.fold.acc && tid < a.C1) {  // host: C1 <= COEF_MAX <= NTHR
-    csc = a.scale[tid];
-    csh = a.shift[tid];
+  if (a.prologue && (pro2 || !a.fold.acc) && tid < a.C1) {  // host: C1 <= COEF_MAX <= NTHR
+    csc = pro2 ? a.bfold.coef[tid] : a.scale[tid];
+    csh = pro2 ? a.bfold.coef[a.C1 + tid] : a.shift[tid];
   }
+  const __amdgpu_buffer_rsrc_t rsy = make_rsrc(pro2 ? a.ysrc : a.src1, pro2 ? a.bytes_y : 0);
+  const __amdgpu_buffer_rsrc_t rsd = make_rsrc(pro2 ? a.dy_out : a.out, pro2 ? a.bytes_dy : 0);
   // (the first chunk's weights need nothing from the tables below: request them first)
   plane_static_for<0, NBI>([&](auto I) { b_dma(cc0, I, 0); });
 
@@ -202,8 +213,74 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
     if (g * 64 + 64 <= C::NPOS || lane < C::NPOS - g * 64) {  // the last group may be part of a wave
       if (in2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, dst, 16, poff2[i], soff, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, poff1[i], soff, 0, 0);
+      if constexpr (pro2) {  // the same items of y (same geometry and pitch: same offsets) into the y buffer
+        auto* dsty = (__attribute__((address_space(3))) void*)(smem + C::Y_OFF + apl * APLB + 16 + g * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, dsty, 16, poff1[i], soff, 0, 0);
+      }
     }
   };
+  // backward prologue: which of this lane's items are OUTPUT positions of the tile (not halo): those it also writes to
+  // dy_out -- every position of the image is an output position of exactly one tile; the cout blocks of a tile would
+  // write the same values, so only block 0 does
+  unsigned own = 0;
+  if (pro2 && nblk == 0) {
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+      const int lin = ((wave >> 1) + (NW / 2) * i) * 64 + lane;
+      const int hr = lin / HP, hc = lin - hr * HP;
+      if (poff1[i] != OOB && hr >= 1 && hr <= TH && hc >= 1 && hc <= TW) own |= 1u << i;
+    }
+  }
+  // dy = scale * dA * [scale * y + shift > 0] + k1 * y + k0, in place over this wave's own items (as a_transform).  Four
+  // channels at a time with the coefficients re-read from LDS: the accumulators and two fragment sets are live here.
+  auto a_transform2 = [&](int cc, int st) {
+    const int cabs = cc * KC + apl * EPC;
+    const float* s_k = reinterpret_cast<const float*>(smem + C::K_OFF);
+    const unsigned soff = (unsigned)(cc * KC * (int)sizeof(T));
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+      const int g = (wave >> 1) + (NW / 2) * i;
+      if (g >= C::NGA) continue;
+      if (poff1[i] != OOB) {
+        unsigned char* p = smem + st + apl * APLB + 16 + (g * 64 + lane) * 16;
+        const unsigned char* py = smem + C::Y_OFF + apl * APLB + 16 + (g * 64 + lane) * 16;
+        const u32x4 pd = *reinterpret_cast<const u32x4*>(p), pv = *reinterpret_cast<const u32x4*>(py);
+        u32x4 pk;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const f32x4 sf = *reinterpret_cast<const f32x4*>(s_coef + cabs + 4 * h2);
+          const f32x4 bf = *reinterpret_cast<const f32x4*>(s_coef + C::COEF_MAX + cabs + 4 * h2);
+          const f32x4 k1 = *reinterpret_cast<const f32x4*>(s_k + cabs + 4 * h2);
+          const f32x4 k0 = *reinterpret_cast<const f32x4*>(s_k + C::COEF_MAX + cabs + 4 * h2);
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float dv, yv;
+            if constexpr (__is_same(T, bf16)) {
+              const unsigned wd = pd[2 * h2 + (j >> 1)], wy = pv[2 * h2 + (j >> 1)];
+              dv = __uint_as_float((j & 1) ? (wd & 0xffff0000u) : (wd << 16));
+              yv = __uint_as_float((j & 1) ? (wy & 0xffff0000u) : (wy << 16));
+            } else {
+              const unsigned wd = pd[2 * h2 + (j >> 1)], wy = pv[2 * h2 + (j >> 1)];
+              dv = (float)__builtin_bit_cast(f16, (unsigned short)((j & 1) ? (wd >> 16) : (wd & 0xffffu)));
+              yv = (float)__builtin_bit_cast(f16, (unsigned short)((j & 1) ? (wy >> 16) : (wy & 0xffffu)));
+            }
+            const float z = fmaf(sf[j], yv, bf[j]);
+            const float dz = z > 0.f ? dv : 0.f;
+            o[j] = fmaf(sf[j], dz, fmaf(k1[j], yv, k0[j]));
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const T lo = from_f32<T>(o[2 * j]), hi = from_f32<T>(o[2 * j + 1]);
+            pk[2 * h2 + j] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+          }
+        }
+        st16(p, pk);
+        if ((own >> i) & 1u) __builtin_amdgcn_raw_buffer_store_b128(pk, rsd, poff1[i], soff, 0);
+      }
+    }
+  };
+
   // BN+ReLU prologue: in place over this wave's own items of chunk cc (after its vmcnt wait, before the barrier);
   // padding positions stay zero
   auto a_transform = [&](int cc, int st) {
@@ -269,7 +346,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
   if (a.prologue) {  // wave-uniform
     // coefficients from the previous layer's sums (cy_bn_acc.h): behind the first chunk's DMA, whose flight time covers
     // the accumulator reads; workgroup 0 leaves them in memory for the backward pass
-    if (a.fold.acc) {  // (the sums of the replicas through LDS: the weight region of the second stage is idle until chunk 1)
+    float ck1 = 0.f, ck0 = 0.f;
+    if constexpr (pro2) {  // (k1, k0) from the backward sums; workgroup 0 adds dgamma / dbeta (what bn_bwd_finalize_kernel did)
+      unsigned long long* s_sum = reinterpret_cast<unsigned long long*>(smem + C::STAGE + C::A_BYTES);
+      bn_acc_gather(a.bfold.acc, a.bfold.R, a.C1, s_sum, tid, C::NTHR);
+      if (tid < a.C1) bn_bwd_fold_channel(a.bfold, s_sum, tid, blockIdx.x == 0 && blockIdx.z == 0, ck1, ck0);
+    } else if (a.fold.acc) {  // (the sums of the replicas through LDS: the weight region of the second stage is idle until chunk 1)
       unsigned long long* s_sum = reinterpret_cast<unsigned long long*>(smem + C::STAGE + C::A_BYTES);
       bn_acc_gather(a.fold.acc, a.fold.R, a.C1, s_sum, tid, C::NTHR);
       if (tid < a.C1) bn_fold_channel_lds(a.fold, s_sum, tid, blockIdx.x == 0 && blockIdx.z == 0, csc, csh);
@@ -277,6 +359,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
     if (tid < a.C1) {
       s_coef[tid] = csc;
       s_coef[C::COEF_MAX + tid] = csh;
+      if constexpr (pro2) {
+        float* s_k = reinterpret_cast<float*>(smem + C::K_OFF);
+        s_k[tid] = ck1;
+        s_k[C::COEF_MAX + tid] = ck0;
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
@@ -312,7 +399,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
   // the wave's part of chunk cc has landed (and is transformed); every wave's has; the other stage is free
   auto open_chunk = [&](int cc, int st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (a.prologue) a_transform(cc, st);
+    if constexpr (pro2) a_transform2(cc, st);
+    else if (a.prologue) a_transform(cc, st);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   int st_cur = 0, st_nxt = C::STAGE;
@@ -570,13 +658,20 @@ inline FlowChoice flow_choice(const cy_conv_desc* d) {
   return f;
 }
 
-template <typename T, int TH, int BN, int WGM, int WGN, bool W16>
+template <typename T, int TH, int BN, int WGM, int WGN, bool W16, bool BWD = false>
 int launch_conv_flow(ConvArgs a, hipStream_t st) {
   using C = FlowCfg<T, TH, BN, WGM, WGN, W16>;
-  auto kern = conv3x3_flow_kernel<T, TH, BN, WGM, WGN, W16>;
+  if constexpr (!BWD) {
+    if (a.prologue == 2) {
+      if constexpr (C::BWD_OK) return launch_conv_flow<T, TH, BN, WGM, WGN, W16, true>(a, st);
+      else return CY_ERR_SHAPE;
+    }
+  }
+  auto kern = conv3x3_flow_kernel<T, TH, BN, WGM, WGN, W16, BWD>;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            BWD ? C::SMEM_BWD : C::SMEM) != hipSuccess)
       return CY_ERR_LAUNCH;
     attr_done = true;
   }
@@ -589,9 +684,19 @@ int launch_conv_flow(ConvArgs a, hipStream_t st) {
   }();
   a.xcd_remap = xcd;
   dim3 grid(cy_cdiv(a.NH, TH) * a.tiles_w * (a.Cout / BN), 1, a.ksplit);
-  hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), C::SMEM, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), BWD ? C::SMEM_BWD : C::SMEM, st, a);
   CY_CHECK_LAUNCH();
   return CY_OK;
+}
+
+// can this tiling take the backward prologue (one more halo buffer in LDS; the four-wave tilings must still fit twice)?
+template <typename T> bool flow_bwd_ok(int th, int bn, int tw) {
+  if (th == 16 && bn == 128) return tw == 16 ? FlowCfg<T, 16, 128, 4, 2, true>::BWD_OK : FlowCfg<T, 16, 128, 4, 2, false>::BWD_OK;
+  if (th == 32 && bn == 128) return tw == 16 ? FlowCfg<T, 32, 128, 4, 2, true>::BWD_OK : FlowCfg<T, 32, 128, 4, 2, false>::BWD_OK;
+  if (th == 64 && bn == 64) return tw == 16 ? FlowCfg<T, 64, 64, 8, 1, true>::BWD_OK : FlowCfg<T, 64, 64, 8, 1, false>::BWD_OK;
+  if (th == 32 && bn == 64) return tw == 16 ? FlowCfg<T, 32, 64, 4, 1, true>::BWD_OK : FlowCfg<T, 32, 64, 4, 1, false>::BWD_OK;
+  if (th == 16 && bn == 64) return tw == 16 ? FlowCfg<T, 16, 64, 4, 1, true>::BWD_OK : FlowCfg<T, 16, 64, 4, 1, false>::BWD_OK;
+  return false;
 }
 
 template <typename T>
@@ -609,12 +714,12 @@ int dispatch_conv_flow(const ConvArgs& a, int th, int bn, int tw, hipStream_t st
     return launch_conv_flow<T, 64, 64, 8, 1, false>(a, st);
   }
   if (th == 32 && bn == 64) {  // four waves of 128 positions x 64 couts, two workgroups per CU
-    if (a.scale && a.C1 > 256) return CY_ERR_SHAPE;
+    if (a.prologue && a.C1 > 256) return CY_ERR_SHAPE;
     if (tw == 16) return launch_conv_flow<T, 32, 64, 4, 1, true>(a, st);
     return launch_conv_flow<T, 32, 64, 4, 1, false>(a, st);
   }
   if (th == 16 && bn == 64) {  // four waves of 64 positions x 64 couts, two workgroups per CU
-    if (a.scale && a.C1 > 256) return CY_ERR_SHAPE;
+    if (a.prologue && a.C1 > 256) return CY_ERR_SHAPE;
     if (tw == 16) return launch_conv_flow<T, 16, 64, 4, 1, true>(a, st);
     return launch_conv_flow<T, 16, 64, 4, 1, false>(a, st);
   }

@@ -551,7 +551,7 @@ inline int stream_partials(int Cin, int Cout, int ntiles, bool pro) { return 4 *
 // applicability (beyond the plane kernel's own): 16-bit storage, Cin / Cout in {32, 64}, no load transform
 inline bool stream_applicable(const cy_conv_desc* d) {
   const int Cin = d->C1 + d->C2;
-  if (d->in_dtype == CY_F32 || d->mode1 == CY_SRC_POOL2) return false;
+  if (d->in_dtype == CY_F32 || d->mode1 == CY_SRC_POOL2 || d->prologue == 2) return false;
   if (d->prologue && !(d->C1 == 32 && d->C2 == 0 && d->Cout == 32)) return false;
   if ((Cin != 32 && Cin != 64) || (d->Cout != 32 && d->Cout != 64)) return false;
   if (d->C2 != 0 && (d->C1 != 32 || d->C2 != 32)) return false;  // concat: one chunk per source

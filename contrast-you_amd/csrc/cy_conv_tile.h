@@ -43,6 +43,14 @@ struct ConvArgs {
   BnFold fold;               // fold.acc != null: the prologue coefficients come from the previous layer's sums
   unsigned long long* sacc;  // != null: the statistics are ADDED into this accumulator [sR][4][Cout] (no partial rows)
   int sR;
+  // prologue == 2 (data gradient with the BatchNorm + ReLU backward in its load path, flow kernel): source 1 is dA, the
+  // gradient w.r.t. relu(bn(y)); dy = scale * dA * [scale * y + shift > 0] + k1 * y + k0 is formed in LDS from (dA, y) with
+  // (k1, k0) derived from the backward sums' accumulator, convolved, and also written to dy_out for the weight gradient
+  const void* ysrc;    // y: the forward layer's raw conv output, same geometry and pitch as source 1
+  long long bytes_y;
+  BnBwdFold bfold;     // bfold.coef = the forward pass's [5][C1]
+  void* dy_out;        // [N,H,W,C1], pitch ld1
+  long long bytes_dy;
 };
 
 // ---- MFMA fragment abstraction: one "k-step" is 16 input channels ----------

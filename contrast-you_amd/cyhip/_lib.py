@@ -63,6 +63,13 @@ class BnFold(C.Structure):
                 ("count", c_double), ("eps", c_float), ("reserved", c_int32), ("coef", c_void_p)]
 
 
+class BnBwdIn(C.Structure):
+    """mirror of cy_bn_bwd_in"""
+    _fields_ = [("y", c_void_p), ("coef", c_void_p), ("acc", POINTER(BnAcc)), ("count", c_double),
+                ("batch_stats", c_int32), ("accumulate", c_int32), ("dgamma", c_void_p), ("dbeta", c_void_p),
+                ("dy", c_void_p)]
+
+
 class BnRunItem(C.Structure):
     """mirror of cy_bn_run_item"""
     _fields_ = [("coef", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p), ("C", c_int32),
@@ -113,6 +120,8 @@ _SIGS = {
     "cy_conv3x3_stat_workgroups": (c_int, [_PCD]),
     "cy_conv3x3_fwd_bn": (c_int, [_PCD, _P, _P, _PBF, _P, _P, _P, _P, _P, _P, _PBA, _P, c_size_t, _P]),
     "cy_conv3x3_first_fwd_acc": (c_int, [_P, _P, _P, _PBA, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cy_conv3x3_dgrad_bn_ok": (c_int, [_PCD]),
+    "cy_conv3x3_dgrad_bn": (c_int, [_PCD, _P, POINTER(BnBwdIn), _P, _P, _P, _P, c_size_t, _P]),
     "cy_bn_fold_coef": (c_int, [_PBF, _P]),
     "cy_bn_relu_apply_fold": (c_int, [_P, _PBF, _P, c_long, c_int, c_int, _P]),
     "cy_bn_relu_apply_pool_fold": (c_int, [_P, _PBF, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
@@ -219,7 +228,7 @@ _SIGS = {
 # functions whose int return is a count / size, not a status
 _COUNT_FUNCS = {"cy_abi_version", "cy_conv3x3_num_partials", "cy_conv3x3_first_num_partials",
                 "cy_bn_bwd_num_partials", "cy_bn_acc_replicas", "cy_conv3x3_stat_workgroups",
-                "cy_bn_relu_bwd_workgroups"}
+                "cy_bn_relu_bwd_workgroups", "cy_conv3x3_dgrad_bn_ok"}
 # (cy_maxpool2_bwd_bn_num_partials returns a count or a negative status: the caller tests the sign itself)
 
 _lib = None

@@ -392,7 +392,26 @@ class ConvChainFn(torch.autograd.Function):
             bsink = ops.grad_sink(b) if gsink is not None else None
             if bsink is None:
                 gsink = None
-            if accs is not None:
+            # The data gradient of this conv can take the BatchNorm + ReLU backward into its load path (one launch
+            # instead of two; dy comes back as its second output for the weight gradient) where the layer has such a
+            # launch plan -- the flow kernel's tilings with room for a second halo buffer.
+            Cin_i = w.shape[1]
+            want_dgrad = i > 0 or (not cfg.first and (need[1] or (ctx.has_x2 and need[2])))
+            split_i = x1.shape[1] if (i == 0 and ctx.has_x2) else None
+            fused_dx = None
+            if accs is not None and want_dgrad:
+                da_f = ops.to_nhwc(da if da.dtype == ys[i].dtype else da.to(ys[i].dtype))
+                if ops.conv3x3_dgrad_bn_ok(da_f, Cin_i, split_i):
+                    acc_i = accs[i] if accs[i] is not None else ops.bn_bwd_acc_new(*ys[i].shape[:2], *ys[i].shape[2:], False, da_f.device)
+                    if not (pool_acc_filled and i == nconv - 1):
+                        ops.bn_bwd_reduce_acc(da_f, ys[i], scale, acc_i)
+                    _, wd = packed_weights(w, dt)
+                    fused_dx, dy, dgamma, dbeta = ops.conv3x3_dgrad_bn(
+                        da_f, ys[i], scale, acc_i, ctx.batch_flags[i], wd, Cin_i, dgamma_out=gsink, dbeta_out=bsink,
+                        want_param_grads=need_g or need_b, split=split_i)
+            if fused_dx is not None:
+                pass
+            elif accs is not None:
                 # (scale is row 0 of the contiguous coefficient block [scale, shift, mean, invstd, ...] of either path)
                 dy, dgamma, dbeta = ops.bn_relu_bwd_acc(da, ys[i], scale, ctx.batch_flags[i], dgamma_out=gsink,
                                                         dbeta_out=bsink, want_param_grads=need_g or need_b,
@@ -417,8 +436,11 @@ class ConvChainFn(torch.autograd.Function):
                         wgrad_into_sink(w, wsink, ys[i - 1], None, dy, 0, ps, ph, ctx.pass_id)
                     else:
                         grads_p[3 * i] = ops.conv3x3_wgrad(ys[i - 1], None, dy, scale=ps, shift=ph)
-                _, wd = packed_weights(w, dt)
-                da, _ = ops.conv3x3_fwd(dy, None, wd, w.shape[1], want_stats=False)
+                if fused_dx is not None:
+                    da = fused_dx
+                else:
+                    _, wd = packed_weights(w, dt)
+                    da, _ = ops.conv3x3_fwd(dy, None, wd, w.shape[1], want_stats=False)
             else:
                 if need_w:
                     if wsink is not None and ops.ASYNC_WGRAD:
@@ -444,7 +466,13 @@ class ConvChainFn(torch.autograd.Function):
                                            "(the reference never asks for it)")
                     _, wd = packed_weights(w, dt)
                     C1 = x1.shape[1]
-                    if ctx.has_x2:
+                    if fused_dx is not None:
+                        if ctx.has_x2:
+                            dl1, dl2 = fused_dx
+                            dx2 = dl2 if need_x2 else None
+                        else:
+                            dl1 = fused_dx
+                    elif ctx.has_x2:
                         (dl1, dl2), _ = ops.conv3x3_fwd(dy, None, wd, w.shape[1], want_stats=False,
                                                         split=C1)
                         dx2 = dl2 if need_x2 else None

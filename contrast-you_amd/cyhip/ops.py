@@ -230,11 +230,11 @@ _desc_cache = {}
 class _Plan:
     """a conv descriptor with the plan numbers the library derives from it (queried once per shape:
     the host issue path is the step's critical resource)"""
-    __slots__ = ("d", "ref", "npart", "fwd_ws", "wgrad_ws", "pair_ws", "stat_wgs")
+    __slots__ = ("d", "ref", "npart", "fwd_ws", "wgrad_ws", "pair_ws", "stat_wgs", "dgrad_bn")
 
     def __init__(self, d: ConvDesc):
         self.d, self.ref = d, C.byref(d)
-        self.npart = self.fwd_ws = self.wgrad_ws = self.stat_wgs = None
+        self.npart = self.fwd_ws = self.wgrad_ws = self.stat_wgs = self.dgrad_bn = None
         self.pair_ws = {}  # images of the second segment -> workspace bytes of the paired weight gradient
 
 
@@ -968,6 +968,13 @@ def bn_relu_bwd_acc(da: Tensor, y: Tensor, coef: Tensor, batch_stats: bool, dgam
     return dy, dgamma, dbeta
 
 
+def bn_bwd_reduce_acc(da: Tensor, y: Tensor, coef: Tensor, acc: BnAccBuf) -> None:
+    """acc += the sums of dz and dz*xhat over (da, y) (the reduce launch of bn_relu_bwd_acc on its own)"""
+    N, Cc, H, W = y.shape
+    _lib.call("cy_bn_relu_bwd_reduce_acc", da.data_ptr(), Cc, y.data_ptr(), coef.data_ptr(), acc.ref, N * H * W, Cc,
+              dtype_code(y.dtype), _stream())
+
+
 def bn_bwd_acc_new(N: int, Cc: int, H: int, W: int, pooled: bool, device) -> BnAccBuf:
     """a zeroed accumulator for the backward sums of a BatchNorm over [N, C, H, W], sized for whichever kernel will
     fill it (the reduce launch, or the pool backward of the block's output)"""
@@ -991,6 +998,82 @@ def maxpool2_bwd_bn_acc(x: Tensor, dpool: Tensor, add: Optional[Tensor], y: Tens
     _lib.call("cy_maxpool2_bwd_bn_acc", x.data_ptr(), dpool.data_ptr(), _ptr(add), Cc, dx.data_ptr(), y.data_ptr(),
               coef.data_ptr(), acc.ref, N, H2 // 2, W2 // 2, Cc, dtype_code(x.dtype), _stream())
     return dx, acc
+
+
+# The data gradient with the BatchNorm + ReLU backward in its load path (cy_conv3x3_dgrad_bn): one launch instead of
+# cy_bn_relu_bwd_apply_fold + cy_conv3x3_fwd; dy comes back as a second output for the weight gradient.  OFF unless
+# CY_DGRAD_BN=1: measured per layer (tools/bench_dgrad_bn.py) and in the step (tools/ab.sh CY_DGRAD_BN 0 1) it does not
+# pay -- every cout block of a tile, and every tile for its halo, repeats the in-LDS pass over (dA, y) that the apply
+# launch does once per element; on the 128-cout tilings the fused launch is 3-5 us shorter than the two it replaces, on
+# the 64-cout tilings 5-13 us longer, and the step does not move (6.51 against 6.51 ms with the 128-cout layers fused,
+# 6.38 against 6.25 with all of them).  DESIGN.md section 3 "Round 4".
+DGRAD_BN = os.environ.get("CY_DGRAD_BN", "0") == "1"
+
+
+def _dgrad_bn_desc(da: Tensor, Cin: int, split: Optional[int]):
+    N, Cc, H, W = da.shape
+    dt = dtype_code(da.dtype)
+    if split:
+        return _desc(N, H, W, Cc, 0, Cin, 0, 2, dt, Cc, 0, split, split, Cin - split)
+    return _desc(N, H, W, Cc, 0, Cin, 0, 2, dt, Cc, 0, Cin)
+
+
+def conv3x3_dgrad_bn_ok(da: Tensor, Cin: int, split: Optional[int] = None) -> bool:
+    """does this layer geometry have a launch plan that takes the fused form?"""
+    if not (DGRAD_BN and BN_ACC) or da.dtype not in HALF_TYPES or not is_nhwc(da):
+        return False
+    d = _dgrad_bn_desc(da, Cin, split)
+    if d.dgrad_bn is None:
+        d.dgrad_bn = bool(_lib.call("cy_conv3x3_dgrad_bn_ok", d.ref))
+    return d.dgrad_bn
+
+
+def conv3x3_dgrad_bn(da: Tensor, y: Tensor, coef: Tensor, acc: "BnAccBuf", batch_stats: bool, wd: Tensor, Cin: int, *,
+                     dgamma_out: Optional[Tensor] = None, dbeta_out: Optional[Tensor] = None,
+                     want_param_grads: bool = True, split: Optional[int] = None):
+    """(dx or (dx1, dx2), dy, dgamma, dbeta): dy = the BatchNorm + ReLU backward of da (formed in the conv's load path
+    from da, y and the sums in `acc`), dx = conv3x3(dy, wd).  coef: row 0 of the forward pass's [5, C] block."""
+    N, Cc, H, W = y.shape
+    dev = y.device
+    d = _dgrad_bn_desc(da, Cin, split)
+    if split:
+        out = empty_nhwc(N, split, H, W, y.dtype, dev)
+        out2 = empty_nhwc(N, Cin - split, H, W, y.dtype, dev)
+    else:
+        out, out2 = empty_nhwc(N, Cin, H, W, y.dtype, dev), None
+    dy = empty_nhwc(N, Cc, H, W, y.dtype, dev)
+    accum = dgamma_out is not None
+    dgamma = dbeta = None
+    if accum:
+        pg, pb = dgamma_out, dbeta_out
+    elif want_param_grads:
+        gb = _f32(2 * Cc, dev).view(2, Cc)
+        dgamma, dbeta = gb[0], gb[1]
+        pg, pb = dgamma, dbeta
+    else:
+        pg = pb = None
+    if d.fwd_ws is None:
+        d.fwd_ws = _lib.load().cy_conv3x3_fwd_ws_bytes(d.ref)
+    nbytes = d.fwd_ws
+    ws = _ws(nbytes, dev) if nbytes else None
+    bn = _lib.BnBwdIn(y.data_ptr(), coef.data_ptr(), C.pointer(acc.s), float(N * H * W), int(batch_stats), int(accum),
+                      _ptr(pg), _ptr(pb), dy.data_ptr())
+    ev = _prof_begin()
+
+    def launch():
+        _lib.call("cy_conv3x3_dgrad_bn", d.ref, da.data_ptr(), C.byref(bn), wd.data_ptr(), out.data_ptr(), _ptr(out2),
+                  _ptr(ws), nbytes, _stream())
+
+    if accum:
+        with ordered(("bn_grad", pg.data_ptr())):  # the first workgroup adds into the parameters' .grad
+            launch()
+    else:
+        launch()
+    if ev is not None:
+        esz = y.element_size()
+        nb = esz * (3 * y.numel() + N * H * W * Cin + 9 * Cc * Cin)
+        _prof_end(ev, "conv3x3_fwd_dgrad", 2.0 * N * H * W * 9 * Cc * Cin, float(nb))
+    return ((out, out2) if split else out), dy, dgamma, dbeta
 
 
 def maxpool2_bwd(x: Tensor, dpool: Tensor, add: Optional[Tensor] = None) -> Tensor:

@@ -261,6 +261,28 @@ int cy_bn_relu_bwd_apply_fold(const void* da, int ld_da, const void* y, const fl
                               double count, int batch_stats, float* dgamma, float* dbeta, int accumulate, void* dy,
                               long npix, int C, int dtype, void* stream);
 
+/* The data gradient of a 3x3 conv with the backward of the BatchNorm + ReLU behind that conv in its load path
+ * (autograd of arch/unet.py:21-23 in one launch instead of cy_bn_relu_bwd_apply + cy_conv3x3_fwd):
+ *   dy = scale * dA * [scale*y + shift > 0] + k1*y + k0     (formed in LDS from dA and y, (k1, k0) from `acc`)
+ *   out = conv3x3(dy, w_packed)                             (w_packed = the data-gradient image of the layer)
+ * and dy is also written to bn->dy for the weight gradient.  d describes the data-gradient convolution with
+ * d->prologue == 2: C1 = the forward layer's output channels, C2 = 0, direct source; dA, y and dy share the pitch
+ * d->ld1.  The first workgroup adds (accumulate) or stores dgamma / dbeta.  Only launch plans with room for the second
+ * halo buffer take this path: ask cy_conv3x3_dgrad_bn_ok(d) (1 / 0) and fall back to the two launches otherwise. */
+typedef struct cy_bn_bwd_in {
+  const void* y;        /* the forward layer's raw conv output [N,H,W,C1] */
+  const float* coef;    /* the forward pass's [5][C1] */
+  const cy_bn_acc* acc; /* sums of dz and dz*xhat (cy_bn_relu_bwd_reduce_acc / cy_maxpool2_bwd_bn_acc) */
+  double count;         /* N*H*W */
+  int32_t batch_stats, accumulate;
+  float* dgamma;        /* [C1] or NULL */
+  float* dbeta;
+  void* dy;             /* out: [N,H,W,C1] */
+} cy_bn_bwd_in;
+int cy_conv3x3_dgrad_bn_ok(const cy_conv_desc* d);
+int cy_conv3x3_dgrad_bn(const cy_conv_desc* d, const void* dA, const cy_bn_bwd_in* bn, const void* w_packed, void* out,
+                        void* out2, void* ws, size_t ws_bytes, void* stream);
+
 /* First layer (input_dim 1..4, arch/unet.py:72): x is the f32 NCHW image
  * [N,Cin,H,W]; w is the reference-layout f32 weight [Cout][Cin][3][3]. */
 int cy_conv3x3_first_num_partials(int N, int H, int W, int Cout);

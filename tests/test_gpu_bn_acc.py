@@ -234,3 +234,91 @@ def test_unet_step_agrees_between_the_two_paths(dt):
         assert (ga[n] - gb[n]).abs().max() <= (1e-4 if dt == torch.float32 else 0.15) * gb[n].abs().max() + 1e-7, n
     for n in bb:
         assert torch.allclose(ba[n].float(), bb[n].float(), rtol=1e-5, atol=1e-6), n
+
+
+def test_unet_step_with_the_fused_data_gradient():
+    """the opt-in fused data gradient inside ConvChainFn.backward: same gradients as the two-launch form"""
+    ops = _ops()
+    from contrastyou.arch.unet import UNet
+    res = {}
+    for mode in (True, False):
+        ops.DGRAD_BN = mode
+        try:
+            torch.manual_seed(0)
+            net = UNet(input_dim=1, num_classes=4, max_channel=256).to(DEV)
+            net.compute_dtype = torch.bfloat16
+            g = torch.Generator().manual_seed(9)
+            x = torch.rand(4, 1, 64, 64, generator=g).to(DEV)
+            net.zero_grad()
+            net(x).float().square().mean().backward()
+            torch.cuda.synchronize()
+            res[mode] = {n: p.grad.clone() for n, p in net.named_parameters()}
+        finally:
+            ops.DGRAD_BN = False
+    for n, gb in res[False].items():
+        assert (res[True][n] - gb).abs().max() <= 0.1 * gb.abs().max() + 1e-7, n
+
+
+# (N, H, W, C = channels of dA / y, Cin = channels of the data gradient, split, dtype): the flow kernel's tilings with the
+# backward prologue -- 16 x 128, 32 x 128, 64 x 64 on the 18-wide halo pitch, 16 x 64 four-wave tiles, 14-wide tiles,
+# split outputs (the data gradient of a concat conv), split-K
+DGRAD_BN_CASES = [
+    (16, 56, 56, 128, 128, None, torch.bfloat16),
+    (32, 56, 56, 128, 128, None, torch.bfloat16),
+    (16, 112, 112, 64, 64, None, torch.bfloat16),
+    (16, 28, 28, 256, 256, None, torch.bfloat16),
+    (16, 28, 28, 256, 512, 256, torch.bfloat16),
+    (16, 14, 14, 512, 512, None, torch.bfloat16),
+    (16, 14, 14, 512, 256, None, torch.float16),
+    (4, 64, 64, 64, 128, 64, torch.float16),
+    (16, 56, 56, 128, 64, None, torch.bfloat16),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_BN_CASES, ids=lambda c: "x".join(str(v).replace("torch.", "") for v in c))
+def test_dgrad_with_bn_backward_prologue(case):
+    """cy_conv3x3_dgrad_bn = cy_bn_relu_bwd_apply_fold + cy_conv3x3_fwd: dy bit-equal (same arithmetic per element), the
+    data gradient equal to accumulation order, dgamma / dbeta equal; twice the same bits"""
+    ops = _ops()
+    N, H, W, C, Cin, split, dt = case
+    g = torch.Generator().manual_seed(11)
+    y = nhwc(torch.randn(N, C, H, W, generator=g), dt)
+    da = nhwc(torch.randn(N, C, H, W, generator=g), dt)
+    gm = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    bt = (torch.rand(C, generator=g) - 0.5).to(DEV)
+    w = (torch.randn(C, Cin, 3, 3, generator=g) * 0.05).to(DEV)   # forward weight [Cout = C][Cin]
+    _, wd = ops.pack_weights(w, dt, want_dgrad=True)
+    yf = y.float()
+    mean = yf.mean((0, 2, 3))
+    var = yf.var((0, 2, 3), unbiased=False)
+    istd = (var + 1e-5).rsqrt()
+    coef = torch.stack([gm * istd, bt - mean * gm * istd, mean, istd, var]).contiguous()
+    ops.DGRAD_BN = True  # (opt-in in the product path: CY_DGRAD_BN=1)
+    try:
+        ok = ops.conv3x3_dgrad_bn_ok(da, Cin, split)
+    finally:
+        ops.DGRAD_BN = False
+    assert ok, "every case here has a flow-kernel plan with room for the y buffer"
+    acc = ops.bn_bwd_acc_new(N, C, H, W, False, DEV)
+    ops.bn_bwd_reduce_acc(da, y, coef[0], acc)
+    dy0, dg0, db0 = ops.bn_relu_bwd_acc(da, y, coef[0], True, acc=acc, acc_filled=True)
+    ref, _ = ops.conv3x3_fwd(dy0, None, wd, Cin, want_stats=False, split=split)
+    dx, dy1, dg1, db1 = ops.conv3x3_dgrad_bn(da, y, coef[0], acc, True, wd, Cin, split=split)
+    torch.cuda.synchronize()
+    assert torch.equal(dy1, dy0)
+    assert torch.equal(dg1, dg0) and torch.equal(db1, db0)
+    refs = ref if split else (ref,)
+    outs = dx if split else (dx,)
+    for a, b in zip(outs, refs):
+        assert (a.float() - b.float()).abs().max() <= 1.6e-2 * b.float().abs().max()
+    dx2, dy2, _, _ = ops.conv3x3_dgrad_bn(da, y, coef[0], acc, True, wd, Cin, split=split)
+    for a, b in zip(dx2 if split else (dx2,), outs):
+        assert torch.equal(a, b)
+    assert torch.equal(dy2, dy1)
+    # against torch's own autograd of conv(relu(bn(y))) w.r.t. the conv input, f32 on the CPU
+    yc = y.float().cpu().requires_grad_(True)
+    a_ = F.relu(F.batch_norm(yc, None, None, gm.cpu(), bt.cpu(), True, 0.1, 1e-5))
+    a_.backward(da.float().cpu())
+    dxr = F.conv_transpose2d(yc.grad.to(dt).float(), w.cpu().to(dt).float(), padding=1)
+    got = torch.cat([o.float().cpu() for o in outs], 1)
+    assert (got - dxr).abs().max() <= 2.5e-2 * dxr.abs().max()
