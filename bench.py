@@ -309,6 +309,15 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # proof of the collective world the timed steps run in: what torch.distributed itself reports, and
+    # an all-reduce of ones over the group the gradient buckets use -- N ranks give N
+    dp_proof = None
+    if world > 1:
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        dp_proof = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                    "allreduce_of_ones": int(round(ones.item()))}
+
     def note(msg):
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
@@ -390,6 +399,13 @@ def main():
                        # mark inside the backward pass instead of at its end (contrastyou/optim/fused_radam.py)
                        "dp_early_buckets_per_step": (round(getattr(ctx["optimizer"], "early_buckets", 0) / max(
                            1, getattr(ctx["optimizer"], "dp_steps", 1)), 2) if world > 1 else None),
+                       "dp": None if dp_proof is None else dict(
+                           dp_proof,
+                           grad_bytes_reduced_per_step=round(getattr(ctx["optimizer"], "dp_bytes", 0) / max(
+                               1, getattr(ctx["optimizer"], "dp_steps", 1))),
+                           buckets_per_step=round(getattr(ctx["optimizer"], "dp_buckets", 0) / max(
+                               1, getattr(ctx["optimizer"], "dp_steps", 1)), 2),
+                           early_start=bool(__import__("cyhip.ops", fromlist=["ops"]).DP_EARLY)),
                        "step_tflops_per_gpu": None if flops_step is None else round(flops_step / 1e12, 3),
                        "achieved_step_tflops_per_gpu": None if flops_step is None else round(
                            flops_step / per_step / 1e12, 1)},

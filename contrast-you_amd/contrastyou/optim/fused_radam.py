@@ -118,6 +118,10 @@ class FusedRAdam(torch.optim.Optimizer):
         pending, self._pending = getattr(self, "_pending", None), None
         if pending is not None:
             self._apply_state(pending)
+        if self._dp and not ops.DP_EARLY_FORCED:
+            # early start of the marked buckets: by rule, from the gradient volume and the world size (ops.dp_early_rule)
+            nbytes = 4 * sum(f.numel for f in self._flat if f is not None)
+            ops.DP_EARLY = ops.dp_early_rule(nbytes, dist.get_world_size(self._pg))
         self.broadcast_state()
         bump_weights_epoch()
 
@@ -232,6 +236,8 @@ class FusedRAdam(torch.optim.Optimizer):
                 else:
                     h = dist.all_reduce(view, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self._pg,
                                         async_op=True)
+                self.dp_bytes = getattr(self, "dp_bytes", 0) + 4 * view.numel()
+                self.dp_buckets = getattr(self, "dp_buckets", 0) + 1
                 self._inflight.append((gi, i, j, view, h, None if avg else world))
         if wait:
             self._wait_inflight()

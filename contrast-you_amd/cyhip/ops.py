@@ -480,7 +480,23 @@ def join_side_streams(onto: Optional["torch.cuda.Stream"] = None) -> None:
 # OFF unless CY_DP_EARLY=1: correct in the two-rank rehearsals (tests/test_gpu_distributed.py), but in one process on a
 # one-rank RCCL group (tools/dp_single_rank.py) the early start costs 0.24 ms of step time -- about what it could
 # hide at N = 8.  Not something to switch on without a multi-GPU measurement.
+# CY_DP_EARLY: "0" / "1" force it; unset = the rule of `dp_early_rule` (applied by FusedRAdam when its flat buffers are
+# built, i.e. before any step is captured).
 DP_EARLY = os.environ.get("CY_DP_EARLY", "0") == "1"
+DP_EARLY_FORCED = os.environ.get("CY_DP_EARLY") in ("0", "1")
+
+
+def dp_early_rule(grad_bytes: int, world: int) -> bool:
+    """Start gradient buckets inside the backward pass only where the all-reduce they would otherwise expose behind it
+    is worth more than the early start costs.  Measured cost of the early start on a one-rank RCCL group: 0.24 ms per
+    step (tools/dp_single_rank.py).  Exposed time of the late order, estimated: a ring all-reduce
+    moves 2 (w - 1) / w of the bytes per GPU; RCCL's multi-ring schedule over the seven xGMI links of a node reaches
+    ~400 GB/s per GPU for tens of MB, plus ~2 x 30 us of collective latency.  On iff that estimate exceeds 0.3 ms:
+    the 34.5 MB of U-Net gradients at 8 ranks give 0.21 ms -> off; models from ~55 MB of gradients up switch it on."""
+    if world <= 1:
+        return False
+    exposed = 2.0 * (world - 1) / world * grad_bytes / 400e9 + 60e-6
+    return exposed > 0.3e-3
 marks_wanted = False   # set by a data-parallel FusedRAdam
 MARK_TAGS = ("decoder", "conv5", "conv4")
 _step_id = {}          # device index -> [int32 device scalar, host value]

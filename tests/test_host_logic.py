@@ -313,3 +313,30 @@ def test_feature_tap_tail_equals_the_slice_of_the_concatenation():
         assert torch.equal(tap.tail(3), full[-3:]) and torch.equal(tap.tail(6), full)
         tap.tail(4).sum().backward()
         assert a.grad_fn is not None and net.blk.weight.grad is not None
+
+
+def test_dp_early_rule_and_bucket_boundaries():
+    """data parallel: the early start of gradient buckets is decided by a rule (gradient volume, world size), and when
+    it is on no bucket mixes parameters of different "gradients final" marks (one bucket over the whole
+    U-Net could never start early)"""
+    from contrastyou.arch.unet import UNet
+    from contrastyou.optim.fused_radam import FlatParams, FusedRAdam
+    from cyhip import ops
+    assert not ops.dp_early_rule(int(34.5e6), 8)      # the U-Net's gradients at 8 ranks: 0.21 ms exposed -> off
+    assert ops.dp_early_rule(int(80e6), 8)
+    assert not ops.dp_early_rule(int(1e9), 1)
+    net = UNet(input_dim=1, num_classes=4, max_channel=512)
+    opt = FusedRAdam(net.parameters(), lr=1e-3, data_parallel=False)
+    f = FlatParams(list(net.parameters()))
+    was = ops.DP_EARLY
+    try:
+        ops.DP_EARLY = False
+        assert len(opt._buckets(f)) == 1
+        ops.DP_EARLY = True
+        cuts = opt._buckets(f)
+        tags = [{p.__dict__.get("_cy_ready_tag") for p in f.params[i:j]} for _, _, i, j in cuts]
+        assert all(len(t) == 1 for t in tags), tags
+        assert [next(iter(t)) for t in tags] == ["decoder", "conv5", "conv4", None]
+        assert sum(b - a for a, b, _, _ in cuts) == f.numel
+    finally:
+        ops.DP_EARLY = was
