@@ -587,10 +587,7 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool 
     // rounds of work anyway this beats the one-per-CU tiles (N = 32: 64 -> 64 at 112 x 112 65 (plane) -> 57 us,
     // 128 -> 256 at 56 x 56 data gradient 66 -> 62) -- below that the one-per-CU tiles stay better (Conv3b 41 vs 45)
     const long n3264 = cy_cdiv((long)N * H, 32) * (W / fc.tw) * (Cout / 64);
-    static const int th3264 = [] {
-      const char* e = getenv("CY_FLOW_3264_MIN");
-      return e ? atoi(e) : 512;
-    }();
+    constexpr int th3264 = 512;  // (a round of them on 256 CUs at two per CU: swept with tools/flow_sweep.sh)
     // (not with the backward prologue: its extra halo buffer leaves room for one such workgroup per CU only)
     if (flow_cfg == 0 && n3264 >= th3264 && !(prologue && Cin > 256) && !bwd_pro) {
       use = true, th = 32, bn = 64;
@@ -636,10 +633,6 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool 
     if (flow_cfg == 2 && fc.small_ok) use = true, th = 16, Z = 1;
     if (flow_cfg == 3 && !(prologue && Cin > 256)) use = true, th = 16, bn = 64, Z = 1;  // (experiment: 4-wave 16 x 64 tiles)
     if (flow_cfg == 4 && !(prologue && Cin > 256) && !bwd_pro) use = true, th = 32, bn = 64, Z = 1;  // (experiment: 4-wave 32 x 64 tiles)
-    if (const char* ov = getenv("CY_KSPLIT")) {
-      const int z = atoi(ov);
-      if (z >= 1) Z = z > nccf ? nccf : z;
-    }
     if (use) {
     p.flow = true;
     p.plane = false;
@@ -661,10 +654,7 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool 
     p.tile.bn = Cout >= 128 ? 128 : (Cout > 32 ? 64 : 32);
     // 128-cout layers with fewer tiles than CUs (56x56 at N=16: 224 tiles): two 64-cout workgroups
     // per tile instead of one (10-13 % faster there, 10-50 % slower at 448 tiles)
-    static const int bn64_below = [] {
-      const char* e = getenv("CY_PLANE_BN64_BELOW");
-      return e ? atoi(e) : 300;
-    }();
+    constexpr int bn64_below = 300;
     if (Cout == 128 && cy_cdiv((long)N * H, kPlaneTH) * (W / kPlaneTW) < bn64_below) p.tile.bn = 64;
   }
   const int tiles = cy_cdiv((long)N * H, p.tile.th) * cy_cdiv(W, p.tile.tw);
@@ -679,11 +669,7 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool 
   }
   p.one_per_cu = false;
   if (p.plane && p.tile.bn == 128) {
-    static const int mode = [] {
-      const char* e = getenv("CY_PLANE_ONE_PER_CU");
-      return e ? atoi(e) : 1;
-    }();
-    if (mode && ncc >= 2) {  // aim at 192..288 workgroups, each with >= 2 chunks to pipeline
+    if (ncc >= 2) {  // aim at 192..288 workgroups, each with >= 2 chunks to pipeline
       int z1 = blocks >= 256 ? 1 : 256 / blocks;
       if (z1 > ncc / 2) z1 = ncc / 2;
       if (z1 < 1) z1 = 1;
@@ -692,10 +678,6 @@ ConvPlan plan_conv(int N, int H, int W, int Cin, int Cout, int elem_bytes, bool 
         Z = z1;
       }
     }
-  }
-  if (const char* ov = getenv("CY_KSPLIT")) {  // tuning override (tools/bench_layers.py)
-    const int z = atoi(ov);
-    if (z >= 1 && Cout % 8 == 0) Z = z > ncc ? ncc : z;
   }
   p.ksplit = Z;
   long fb = (npix + 15) / 16;  // split-K layers are small (<= 12.5k pixels): many short workgroups

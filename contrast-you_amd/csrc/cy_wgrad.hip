@@ -669,7 +669,7 @@ __global__ void __launch_bounds__(256)
 }
 
 struct WgPlan {
-  bool twelve;  // bf16: the twelve-wave kernel (CY_WGRAD12=0 keeps wgrad_kernel, for A/B runs)
+  bool twelve;  // 16-bit storage: the twelve-wave kernels (f32: wgrad_kernel)
   bool spec;    // ... in its wave-specialised form (64 x 64 blocks; CY_WGRAD_SPEC=0 keeps wgrad12_kernel)
   bool dma;     // ... with the loader waves on LDS-DMA (CY_WGRAD_DMA=0: register staging)
   bool blk_order;  // ... and 4 x 4 pixel patches as k-steps where the tile allows (CY_WGRAD_BLK=0: row-major k)
@@ -679,11 +679,7 @@ struct WgPlan {
 
 WgPlan plan_wgrad(const cy_conv_desc* d) {
   WgPlan p;
-  static const bool twelve_enabled = [] {
-    const char* e = getenv("CY_WGRAD12");
-    return !(e && e[0] == '0');
-  }();
-  p.twelve = twelve_enabled && d->in_dtype != CY_F32;
+  p.twelve = d->in_dtype != CY_F32;  // (the four-wave wgrad_kernel serves f32 only; the paired launch has no four-wave form)
   const int Cin = d->C1 + d->C2;
   if (d->in_dtype == CY_F32) {
     p.wco = 1, p.wci = 1, p.wk = 4;
@@ -732,10 +728,7 @@ WgPlan plan_wgrad(const cy_conv_desc* d) {
     const long opx = (long)d->N * d->H * d->W;
     const long px1 = d->mode1 == CY_SRC_UP2 ? opx / 4 : opx;
     const bool small = px1 * d->ld1 * eb <= lim && (!d->C2 || opx * d->ld2 * eb <= lim) && opx * d->ldo * eb <= lim;
-    static const int min_w = [] {  // (CY_WGRAD_MINW: experiments)
-      const char* e = getenv("CY_WGRAD_MINW");
-      return e ? atoi(e) : 14;
-    }();
+    constexpr int min_w = 14;
     const bool base = p.twelve && spec_enabled && d->mode1 != CY_SRC_POOL2 && d->W >= min_w;
     const bool dma_ok = dma_enabled && small && (d->C2 == 0 || d->C1 % (32 * p.wci) == 0);
     const bool patches = dma_ok && blk_enabled && p.TH % 4 == 0 && p.TW % 4 == 0;
@@ -748,10 +741,6 @@ WgPlan plan_wgrad(const cy_conv_desc* d) {
   // enough workgroups to fill 256 CUs twice (wgrad_kernel: two per CU) or once (twelve waves: one
   // per CU), slabs bounded to ~48 MB
   int S = (p.twelve ? 256 : 512) / out_tiles;
-  if (const char* e = getenv("CY_WGRAD_SMUL")) {  // tuning: scale the number of pixel splits
-    const int f = atoi(e);
-    if (f > 1) S *= f;
-  }
   const long slab_bytes = 9L * p.co_pad * p.ci_pad * 4;
   const long cap = (48L << 20) / slab_bytes;
   if (S > cap) S = (int)cap;

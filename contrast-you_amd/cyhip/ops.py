@@ -524,7 +524,7 @@ def begin_step_marks(device) -> None:
     _ready_marks.clear()
 
 
-_MARK_AT = tuple(t for t in os.environ.get("CY_DP_MARK_AT", ",".join(MARK_TAGS)).split(",") if t)  # (experiments)
+_MARK_AT = MARK_TAGS
 
 
 def grad_ready_mark(tag: str, device) -> None:
