@@ -245,6 +245,15 @@ class _SPINFONCEEpochHook(_INFONCEEpochHook):
         return loss
 
 
+def nearest_source_index(dst: int, in_size: int, out_size: int) -> int:
+    """source index of F.interpolate(mode="nearest") for output index `dst`: min(floor(dst * float32(in / out)), in - 1)
+    with the scale and the product in float32, as ATen computes it -- integer (dst * in) // out differs from that for
+    some sizes (224 -> 48: dst 21 reads 97, not 98)"""
+    import numpy as np
+    scale = np.float32(in_size) / np.float32(out_size)
+    return min(int(np.floor(np.float32(dst) * scale)), in_size - 1)
+
+
 class _SuperPixelInfoNCEEPochHook(_INFONCEEpochHook):
     """infonce.py:308-340: project both views densely, sample 5 positions per image (same seed for both views and
     for the superpixel map), label every sampled vector with the superpixel id under it"""
@@ -264,11 +273,13 @@ class _SuperPixelInfoNCEEPochHook(_INFONCEEpochHook):
         dev = rows.device
         superpixel_mask = (batch_data["superpixel"][0].to(dev) * 255.0).type(torch.uint8).float()
         superpixel_mask_tf = affine_transformer(superpixel_mask)
-        # F.interpolate(mode="nearest") to (sh, sw), then the sampled positions: source index floor(dst * in / out)
+        # F.interpolate(mode="nearest") to (sh, sw), then the sampled positions: the source index of ATen's nearest
+        # kernel (float32 scale arithmetic, `nearest_source_index`), all positions with ONE gather and one host read
         H, W = superpixel_mask_tf.shape[-2:]
-        labels = [int(superpixel_mask_tf[i, 0, (a * H) // sh, (b * W) // sw].item())
-                  for i, im in enumerate(pts) for a, b in im]
-        labels = [int(v) & 0xff for v in labels]  # (.type(torch.uint8), infonce.py:336)
+        ii = torch.tensor([i for i, im in enumerate(pts) for _ in im], device=dev)
+        aa = torch.tensor([nearest_source_index(a, H, sh) for im in pts for a, _ in im], device=dev)
+        bb = torch.tensor([nearest_source_index(b, W, sw) for im in pts for _, b in im], device=dev)
+        labels = [int(v) & 0xff for v in superpixel_mask_tf[ii, 0, aa, bb].tolist()]  # (.type(torch.uint8), infonce.py:336)
         loss = self._criterion(norm_features_tf_selected, norm_tf_features_selected, target=labels)
         self.meters["loss"].add(loss.detach())
         self._n += 1

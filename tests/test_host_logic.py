@@ -340,3 +340,18 @@ def test_dp_early_rule_and_bucket_boundaries():
         assert sum(b - a for a, b, _, _ in cuts) == f.numel
     finally:
         ops.DP_EARLY = was
+
+
+def test_nearest_source_index_is_atens():
+    """the superpixel hook's label lookup = F.interpolate(mode="nearest") at the sampled positions, for every size
+    (ADVICE r03: integer (dst * in) // out is a different index at e.g. 224 -> 48)"""
+    import torch.nn.functional as F
+    from semi_seg.hooks.infonce import nearest_source_index
+    diff = 0
+    for n_in, n_out in ((224, 48), (224, 46), (224, 92), (224, 184), (256, 82), (72, 6), (224, 20), (48, 6), (224, 224)):
+        src = torch.arange(n_in, dtype=torch.float32).view(1, 1, n_in, 1).expand(1, 1, n_in, 4).contiguous()
+        want = F.interpolate(src, size=(n_out, 4), mode="nearest")[0, 0, :, 0].long().tolist()
+        got = [nearest_source_index(d, n_in, n_out) for d in range(n_out)]
+        assert got == want, (n_in, n_out)
+        diff += sum(g != (d * n_in) // n_out for d, g in enumerate(got))
+    assert diff > 0  # (the sizes above include ones where the integer formula is wrong)
