@@ -572,13 +572,26 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-template <typename T>
+// STATS (as maxpool2_bwd_kernel): the gradient this kernel writes is the dA of relu(bn(y)) -- the last BatchNorm of the block
+// whose output the Upsample consumed -- and its backward sums are added into an accumulator from the values in registers
+// (the rounded gradient, as a separate reduce pass would read it back).  Needs 256 % (C/8) == 0.
+template <typename T, bool STATS>
 __global__ void __launch_bounds__(256)
     upsample2_bwd_kernel(const T* __restrict__ dup, int ld_dup, T* __restrict__ dx, int N, int H,
-                         int W, int C) {
+                         int W, int C, const T* __restrict__ y, const float* __restrict__ coef, unsigned long long* sacc,
+                         int sR) {
   const int G = C / 8;
   const long total = (long)N * H * W * G;
   const int W2 = 2 * W;
+  float a1[8], a2[8], sc[8], sh[8], mu[8], is[8];
+  if constexpr (STATS) {
+    const int g = threadIdx.x % G;  // (the grid stride is a multiple of G: a thread keeps its channel group)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a1[j] = a2[j] = 0.f;
+      sc[j] = coef[g * 8 + j], sh[j] = coef[C + g * 8 + j], mu[j] = coef[2 * C + g * 8 + j], is[j] = coef[3 * C + g * 8 + j];
+    }
+  }
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int g = (int)(i % G);
     long p = i / G;
@@ -595,6 +608,40 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = (a[j] + b[j]) + (c[j] + d[j]);
     store8<T>(dx + ((long)(n * H + h) * W + w) * C + g * 8, a);
+    if constexpr (STATS) {
+      float yv[8], dv[8];
+      load8<T>(y + ((long)(n * H + h) * W + w) * C + g * 8, yv);
+      if constexpr (sizeof(T) == 2) {
+        Chunk<T>::unpack(Chunk<T>::pack(a), dv);  // the stored (rounded) gradient
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[j] = a[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float z = fmaf(sc[j], yv[j], sh[j]);
+        const float dz = z > 0.f ? dv[j] : 0.f;
+        a1[j] += dz;
+        a2[j] += dz * ((yv[j] - mu[j]) * is[j]);
+      }
+    }
+  }
+  if constexpr (STATS) {
+    __shared__ float sred[256 * 16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sred[threadIdx.x * 16 + j] = a1[j];
+      sred[threadIdx.x * 16 + 8 + j] = a2[j];
+    }
+    __syncthreads();
+    const int per_g = 256 / G;
+    for (int e = threadIdx.x; e < 2 * C; e += 256) {
+      const int which = e / C, c = e - which * C;
+      const int g = c >> 3, jj = c & 7;
+      float t = 0.f;
+      for (int k = 0; k < per_g; ++k) t += sred[(g + k * G) * 16 + which * 8 + jj];
+      bn_acc_add(sacc, sR, C, (int)blockIdx.x & (sR - 1), which, c, t);
+    }
   }
 }
 
@@ -941,25 +988,49 @@ static int maxpool2_bwd_bn_impl(const void* x, const void* dpool, const void* ad
   return CY_OK;
 }
 
-int cy_upsample2_bwd(const void* dup, int ld_dup, void* dx, int N, int H, int W, int C, int dtype,
-                     void* stream) {
+static int upsample2_bwd_impl(const void* dup, int ld_dup, void* dx, const void* y, const float* coef,
+                              unsigned long long* sacc, int sR, int N, int H, int W, int C, int dtype, void* stream) {
   if (!dup || !dx || N <= 0 || H <= 0 || W <= 0) return CY_ERR_ARG;
   if (C % 8 || ld_dup % 8 || ld_dup < C) return CY_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = stream_grid((long)N * H * W * (C / 8));
-  if (dtype == CY_BF16)
-    hipLaunchKernelGGL(upsample2_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dup,
-                       ld_dup, (bf16*)dx, N, H, W, C);
-  else if (dtype == CY_F16)
-    hipLaunchKernelGGL(upsample2_bwd_kernel<f16>, dim3(grid), dim3(256), 0, st, (const f16*)dup,
-                       ld_dup, (f16*)dx, N, H, W, C);
-  else if (dtype == CY_F32)
-    hipLaunchKernelGGL(upsample2_bwd_kernel<float>, dim3(grid), dim3(256), 0, st,
-                       (const float*)dup, ld_dup, (float*)dx, N, H, W, C);
-  else
-    return CY_ERR_DTYPE;
+  int grid = stream_grid((long)N * H * W * (C / 8));
+  if (sacc) {
+    if (C / 8 > 256 || 256 % (C / 8)) return CY_ERR_SHAPE;
+    grid = cy_upsample2_bwd_bn_workgroups(N, H, W, C);
+  }
+#define CY_UP_BWD(TT)                                                                                             \
+  do {                                                                                                            \
+    if (sacc) hipLaunchKernelGGL((upsample2_bwd_kernel<TT, true>), dim3(grid), dim3(256), 0, st, (const TT*)dup,   \
+                                 ld_dup, (TT*)dx, N, H, W, C, (const TT*)y, coef, sacc, sR);                      \
+    else hipLaunchKernelGGL((upsample2_bwd_kernel<TT, false>), dim3(grid), dim3(256), 0, st, (const TT*)dup,       \
+                            ld_dup, (TT*)dx, N, H, W, C, (const TT*)nullptr, (const float*)nullptr,               \
+                            (unsigned long long*)nullptr, 0);                                                     \
+  } while (0)
+  if (dtype == CY_BF16) CY_UP_BWD(bf16);
+  else if (dtype == CY_F16) CY_UP_BWD(f16);
+  else if (dtype == CY_F32) CY_UP_BWD(float);
+  else return CY_ERR_DTYPE;
+#undef CY_UP_BWD
   CY_CHECK_LAUNCH();
   return CY_OK;
+}
+
+int cy_upsample2_bwd(const void* dup, int ld_dup, void* dx, int N, int H, int W, int C, int dtype,
+                     void* stream) {
+  return upsample2_bwd_impl(dup, ld_dup, dx, nullptr, nullptr, nullptr, 0, N, H, W, C, dtype, stream);
+}
+
+int cy_upsample2_bwd_bn_workgroups(int N, int H, int W, int C) {
+  if (N <= 0 || H <= 0 || W <= 0 || C % 8 || C / 8 > 256 || 256 % (C / 8)) return CY_ERR_SHAPE;
+  long b = ((long)N * H * W * (C / 8) + 255) / 256;
+  if (b > 1024) b = 1024;
+  return (int)(b < 1 ? 1 : b);
+}
+
+int cy_upsample2_bwd_bn_acc(const void* dup, int ld_dup, void* dx, const void* y, const float* coef,
+                            const cy_bn_acc* acc, int N, int H, int W, int C, int dtype, void* stream) {
+  if (!y || !coef || !acc || !acc->acc || acc->C != C || acc->R < 1 || (acc->R & (acc->R - 1))) return CY_ERR_ARG;
+  return upsample2_bwd_impl(dup, ld_dup, dx, y, coef, (unsigned long long*)acc->acc, acc->R, N, H, W, C, dtype, stream);
 }
 
 }  // extern "C"

@@ -129,6 +129,8 @@ _SIGS = {
     "cy_bn_relu_bwd_reduce_acc": (c_int, [_P, c_int, _P, _P, _PBA, c_long, c_int, c_int, _P]),
     "cy_bn_relu_bwd_workgroups": (c_int, [c_long, c_int]),
     "cy_maxpool2_bwd_bn_acc": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _PBA, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cy_upsample2_bwd_bn_workgroups": (c_int, [c_int, c_int, c_int, c_int]),
+    "cy_upsample2_bwd_bn_acc": (c_int, [_P, c_int, _P, _P, _P, _PBA, c_int, c_int, c_int, c_int, c_int, _P]),
     "cy_bn_relu_bwd_apply_fold": (c_int, [_P, c_int, _P, _P, _PBA, c_double, c_int, _P, _P, c_int, _P, c_long, c_int,
                                           c_int, _P]),
     "cy_conv3x3_first_num_partials": (c_int, [c_int, c_int, c_int, c_int]),

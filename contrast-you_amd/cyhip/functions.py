@@ -322,6 +322,11 @@ class ConvChainFn(torch.autograd.Function):
         if ops.BN_ACC and any(ctx.needs_input_grad) and all(yy.shape[1] <= 1024 for yy in ys):
             ctx.bwd_accs = [ops.bn_bwd_acc_new(yy.shape[0], yy.shape[1], yy.shape[2], yy.shape[3],
                                                cfg.pool_out and j == nconv - 1, dev) for j, yy in enumerate(ys)]
+            # whoever produces the gradient of `out` may add the sums of this block's last BatchNorm while it has the
+            # values in registers (an _UpConv's upsample backward does): what it needs travels with the tensor
+            out._cy_tail = (ys[-1], coefs[-1][0], ctx.bwd_accs[-1])
+        # ... and this block, if it upsamples on load, is such a producer for the block whose output it reads
+        ctx.up_tail = getattr(x1, "_cy_tail", None) if (cfg.mode == ops.CY_SRC_UP2 and ops.BN_ACC) else None
         if RAW_TAP is not None:
             for i in range(nconv):
                 RAW_TAP(cfg.bns[i], ys[i], coefs[i][0], coefs[i][1], out if i == nconv - 1 else None)
@@ -364,6 +369,16 @@ class ConvChainFn(torch.autograd.Function):
         if acc_ok and accs is None:
             accs = [None] * nconv
         pool_acc_filled = False
+        if accs is not None and accs[-1] is not None and accs[-1].filled_for is not None and not cfg.pool_out:
+            # the producer of `dout` (an upsample backward) has added this block's last BatchNorm's sums -- valid only if
+            # `dout` IS that producer's tensor (autograd hands a single contribution through; a sum of several consumers'
+            # gradients is another tensor, and the accumulator then holds a partial sum: start a fresh one)
+            made = accs[-1].filled_for  # (the producer's tensor, kept alive: no address reuse, no in-place accumulation)
+            if (dout is not None and dout.data_ptr() == made.data_ptr() and dout._version == made._version
+                    and dout.shape == made.shape and dout.dtype == ys[-1].dtype and ops.is_nhwc(dout)):
+                pool_acc_filled = True
+            else:
+                accs[-1] = None
         if cfg.pool_out and dpooled is not None:
             if dpooled.dtype != out.dtype:
                 dpooled = dpooled.to(out.dtype)
@@ -482,7 +497,14 @@ class ConvChainFn(torch.autograd.Function):
                         if cfg.mode == ops.CY_SRC_POOL2:
                             dx1 = ops.maxpool2_bwd(x1, dl1)
                         elif cfg.mode == ops.CY_SRC_UP2:
-                            dx1 = ops.upsample2_bwd(dl1)
+                            dx1 = None
+                            if ctx.up_tail is not None and ctx.up_tail[2].filled_for is None:
+                                y_t, coef_t, acc_t = ctx.up_tail
+                                dx1 = ops.upsample2_bwd_bn_acc(dl1, y_t, coef_t, acc_t)
+                                if dx1 is not None:
+                                    acc_t.filled_for = dx1
+                            if dx1 is None:
+                                dx1 = ops.upsample2_bwd(dl1)
                         else:
                             dx1 = dl1
                         if dx1.dtype != ctx.x_dtype:

@@ -779,10 +779,11 @@ def bn_arena_end(prev: Optional[BnArena]) -> None:
 
 class BnAccBuf:
     """an accumulator [R][4][C] (+ R flags) and its ctypes view"""
-    __slots__ = ("t", "R", "C", "s", "ref")
+    __slots__ = ("t", "R", "C", "s", "ref", "filled_for")
 
     def __init__(self, t: Tensor, R: int, Cc: int):
         self.t, self.R, self.C = t, R, Cc
+        self.filled_for = None  # the gradient tensor whose producer has added its sums already
         self.s = _lib.BnAcc(t.data_ptr(), R, Cc)
         self.ref = C.byref(self.s)
 
@@ -993,11 +994,24 @@ def bn_bwd_reduce_acc(da: Tensor, y: Tensor, coef: Tensor, acc: BnAccBuf) -> Non
 
 def bn_bwd_acc_new(N: int, Cc: int, H: int, W: int, pooled: bool, device) -> BnAccBuf:
     """a zeroed accumulator for the backward sums of a BatchNorm over [N, C, H, W], sized for whichever kernel will
-    fill it (the reduce launch, or the pool backward of the block's output)"""
+    fill it (the reduce launch, the pool backward of the block's output, or the upsample backward of its consumer)"""
     wgs = _lib.call("cy_bn_relu_bwd_workgroups", N * H * W, Cc)
     if pooled and POOL_BN_FUSE and H % 2 == 0 and W % 2 == 0:
         wgs = max(wgs, _lib.load().cy_maxpool2_bwd_bn_num_partials(N, H // 2, W // 2, Cc))
+    wgs = max(wgs, _lib.load().cy_upsample2_bwd_bn_workgroups(N, H, W, Cc))
     return bn_acc_new(Cc, wgs, device)
+
+
+def upsample2_bwd_bn_acc(dup: Tensor, y: Tensor, coef: Tensor, acc: BnAccBuf) -> Optional[Tensor]:
+    """upsample2_bwd whose result is the dA of relu(bn(y)): that BatchNorm's backward sums are added into `acc`;
+    None where the fused form does not apply"""
+    N, Cc, H2, W2 = dup.shape
+    if _lib.load().cy_upsample2_bwd_bn_workgroups(N, H2 // 2, W2 // 2, Cc) <= 0 or dup.dtype != y.dtype:
+        return None
+    dx = empty_nhwc(N, Cc, H2 // 2, W2 // 2, dup.dtype, dup.device)
+    _lib.call("cy_upsample2_bwd_bn_acc", dup.data_ptr(), Cc, dx.data_ptr(), y.data_ptr(), coef.data_ptr(), acc.ref, N,
+              H2 // 2, W2 // 2, Cc, dtype_code(dup.dtype), _stream())
+    return dx
 
 
 def maxpool2_bwd_bn_acc(x: Tensor, dpool: Tensor, add: Optional[Tensor], y: Tensor, coef: Tensor,

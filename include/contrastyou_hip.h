@@ -255,6 +255,13 @@ int cy_bn_relu_bwd_workgroups(long npix, int C);
 int cy_maxpool2_bwd_bn_acc(const void* x, const void* dpool, const void* add, int ld_add, void* dx, const void* y,
                            const float* coef, const cy_bn_acc* acc, int N, int H, int W, int C, int dtype,
                            void* stream);
+/* cy_upsample2_bwd whose output is the dA of relu(bn(y)) (the last BatchNorm of the block the Upsample read): that
+ * layer's backward sums are added into `acc` from the values in registers (what cy_maxpool2_bwd_bn_acc does for the
+ * encoder).  (H, W) are the low-resolution dims; y is [N,H,W,C].  cy_upsample2_bwd_bn_workgroups: the adders per
+ * channel (for cy_bn_acc_replicas), or CY_ERR_SHAPE where the form does not apply (256 % (C/8) != 0). */
+int cy_upsample2_bwd_bn_workgroups(int N, int H, int W, int C);
+int cy_upsample2_bwd_bn_acc(const void* dup, int ld_dup, void* dx, const void* y, const float* coef,
+                            const cy_bn_acc* acc, int N, int H, int W, int C, int dtype, void* stream);
 /* dy = scale*dz + k1*y + k0 with (k1, k0) derived from the accumulator; the first workgroup adds (accumulate != 0) or
  * stores dgamma / dbeta (either may be NULL) */
 int cy_bn_relu_bwd_apply_fold(const void* da, int ld_da, const void* y, const float* coef, const cy_bn_acc* acc,

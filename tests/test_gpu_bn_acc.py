@@ -322,3 +322,53 @@ def test_dgrad_with_bn_backward_prologue(case):
     dxr = F.conv_transpose2d(yc.grad.to(dt).float(), w.cpu().to(dt).float(), padding=1)
     got = torch.cat([o.float().cpu() for o in outs], 1)
     assert (got - dxr).abs().max() <= 2.5e-2 * dxr.abs().max()
+
+
+def test_upsample_backward_adds_the_consumers_bn_sums():
+    """cy_upsample2_bwd_bn_acc: same gradient as cy_upsample2_bwd, and the accumulator holds what the reduce launch adds"""
+    ops = _ops()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(21)
+    N, C, H = 4, 128, 28
+    dup = nhwc(torch.randn(N, C, 2 * H, 2 * H, generator=g), dt)
+    y = nhwc(torch.randn(N, C, H, H, generator=g), dt)
+    coef = torch.rand(5, C, generator=g).to(DEV) + 0.25
+    coef[1] -= 0.75
+    ref = ops.upsample2_bwd(dup)
+    acc = ops.bn_bwd_acc_new(N, C, H, H, False, DEV)
+    dx = ops.upsample2_bwd_bn_acc(dup, y, coef[0], acc)
+    assert torch.equal(dx, ref)
+    acc2 = ops.bn_bwd_acc_new(N, C, H, H, False, DEV)
+    ops.bn_bwd_reduce_acc(ref, y, coef[0], acc2)
+    a1, a2 = acc_sums(acc)
+    b1, b2 = acc_sums(acc2)
+    assert torch.allclose(a1, b1, rtol=0, atol=2e-6 * b1.abs().max().item())
+    assert torch.allclose(a2, b2, rtol=0, atol=2e-6 * b2.abs().max().item())
+
+
+def test_producer_side_sums_are_dropped_when_other_gradients_join():
+    """a block output with TWO consumers (the decoder's upsample and a loss on the features): autograd sums their
+    gradients, so the sums the upsample backward added describe only its own share and must not be used"""
+    ops = _ops()
+    from contrastyou.arch.unet import UNet
+    res = {}
+    for mode in (True, False):
+        ops.BN_ACC = mode
+        try:
+            torch.manual_seed(0)
+            net = UNet(input_dim=1, num_classes=4, max_channel=128).to(DEV)
+            net.compute_dtype = torch.float32
+            feats = {}
+            h = net.get_module("Up_conv4").register_forward_hook(lambda m, i, o: feats.__setitem__("f", o))
+            g = torch.Generator().manual_seed(9)
+            x = torch.rand(3, 1, 64, 64, generator=g).to(DEV)
+            net.zero_grad()
+            logits = net(x)
+            (logits.float().square().mean() + feats["f"].float().square().mean()).backward()
+            h.remove()
+            torch.cuda.synchronize()
+            res[mode] = {n: p.grad.clone() for n, p in net.named_parameters()}
+        finally:
+            ops.BN_ACC = True
+    for n, gb in res[False].items():
+        assert (res[True][n] - gb).abs().max() <= 1e-4 * gb.abs().max() + 1e-8, n
