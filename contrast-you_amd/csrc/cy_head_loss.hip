@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256)
 
 __global__ void __launch_bounds__(256)
     head_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                           float* __restrict__ db, int nblk, int KC, int K) {
+                           float* __restrict__ db, int nblk, int KC, int K, int accumulate) {
   // 4 outputs per block, 64 slices of the block partials each, fixed slice order
   __shared__ double sred[64][4];
   const int el = threadIdx.x & 3, sl = threadIdx.x >> 2;
@@ -224,9 +224,9 @@ __global__ void __launch_bounds__(256)
     double t = 0.0;
     for (int q = 0; q < 64; ++q) t += sred[q][el];
     if (i < KC) {
-      if (dw) dw[i] = (float)t;
+      if (dw) dw[i] = accumulate ? dw[i] + (float)t : (float)t;
     } else if (db) {
-      db[i - KC] = (float)t;
+      db[i - KC] = accumulate ? db[i - KC] + (float)t : (float)t;
     }
   }
 }
@@ -474,9 +474,25 @@ size_t cy_head1x1_bwd_ws_bytes(long npix, int C, int K) {
   return (size_t)head_dw_blocks(npix) * (K * C + K) * sizeof(float);
 }
 
+static int head1x1_bwd_impl(const void* x, const float* w, const float* dlogits, void* dx, float* dw,
+                            float* db, int accumulate, long npix, int C, int K, int x_dtype, void* ws, size_t ws_bytes,
+                            void* stream);
+
 int cy_head1x1_bwd(const void* x, const float* w, const float* dlogits, void* dx, float* dw,
                    float* db, long npix, int C, int K, int x_dtype, void* ws, size_t ws_bytes,
                    void* stream) {
+  return head1x1_bwd_impl(x, w, dlogits, dx, dw, db, 0, npix, C, K, x_dtype, ws, ws_bytes, stream);
+}
+
+int cy_head1x1_bwd_into(const void* x, const float* w, const float* dlogits, void* dx, float* dw,
+                        float* db, long npix, int C, int K, int x_dtype, void* ws, size_t ws_bytes,
+                        void* stream) {
+  return head1x1_bwd_impl(x, w, dlogits, dx, dw, db, 1, npix, C, K, x_dtype, ws, ws_bytes, stream);
+}
+
+static int head1x1_bwd_impl(const void* x, const float* w, const float* dlogits, void* dx, float* dw,
+                            float* db, int accumulate, long npix, int C, int K, int x_dtype, void* ws, size_t ws_bytes,
+                            void* stream) {
   if (!x || !w || !dlogits || npix <= 0) return CY_ERR_ARG;
   if (C % 8 || K < 1 || K > KWIDE || (size_t)(K * C + K) * 4 > 60000) return CY_ERR_SHAPE;
   if (x_dtype != CY_BF16 && x_dtype != CY_F32 && x_dtype != CY_F16) return CY_ERR_DTYPE;
@@ -541,7 +557,7 @@ int cy_head1x1_bwd(const void* x, const float* w, const float* dlogits, void* dx
     }
     CY_CHECK_LAUNCH();
     hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3(cy_cdiv(K * C + K, 4)), dim3(256), 0, st,
-                       (const float*)ws, dw, db, nblk, K * C, K);
+                       (const float*)ws, dw, db, nblk, K * C, K, accumulate);
     CY_CHECK_LAUNCH();
   }
   return CY_OK;

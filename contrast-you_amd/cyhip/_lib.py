@@ -154,6 +154,8 @@ _SIGS = {
     "cy_head1x1_bwd_ws_bytes": (c_size_t, [c_long, c_int, c_int]),
     "cy_head1x1_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_int, c_int, c_int, _P, c_size_t,
                                _P]),
+    "cy_head1x1_bwd_into": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_int, c_int, c_int, _P, c_size_t,
+                               _P]),
     "cy_softmax_kl_ws_bytes": (c_size_t, [c_long]),
     "cy_softmax_kl_fwd": (c_int, [_P, _P, _P, c_long, c_int, c_float, _P, c_size_t, _P]),
     "cy_softmax_kl_bwd": (c_int, [_P, _P, _P, _P, c_long, c_int, c_float, _P]),

@@ -532,19 +532,16 @@ class HeadFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or (
             ctx.has_bias and ctx.needs_input_grad[2])
+        # like the conv / BN parameters: the reduction kernel adds straight into live .grad buffers (ordered across
+        # streams), so that autograd never has to merge the two passes' contributions itself
+        wsink = ops.grad_sink(w) if (need_dw and ctx.needs_input_grad[1] and w.dtype == torch.float32) else None
+        bsink = ops.grad_sink(ctx.bias) if (wsink is not None and ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if wsink is not None and (bsink is not None or not ctx.has_bias):
+            dx, _, _ = ops.head_bwd(x, w, dlogits, need_dx, True, dw_into=wsink, db_into=bsink)
+            return dx, None, None
         dx, dw, db = ops.head_bwd(x, w, dlogits, need_dx, need_dw)
         if dw is not None:
             dw = dw.to(w.dtype)
-            # like the conv / BN parameters: accumulate straight into live .grad buffers (ordered across
-            # streams), so that autograd never has to merge the two passes' contributions itself
-            wsink = ops.grad_sink(w) if ctx.needs_input_grad[1] else None
-            bsink = ops.grad_sink(ctx.bias) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-            if wsink is not None and (bsink is not None or not ctx.has_bias):
-                with ops.ordered(("head_grad", wsink.data_ptr())):
-                    wsink.add_(dw.view_as(wsink))
-                    if bsink is not None:
-                        bsink.add_(db.view_as(bsink))
-                return dx, None, None
         return dx, dw if ctx.needs_input_grad[1] else None, db if ctx.has_bias else None
 
 

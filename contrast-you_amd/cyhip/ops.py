@@ -1151,7 +1151,10 @@ def head_fwd(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
     return logits
 
 
-def head_bwd(x: Tensor, w: Tensor, dlogits: Tensor, need_dx: bool, need_dw: bool):
+def head_bwd(x: Tensor, w: Tensor, dlogits: Tensor, need_dx: bool, need_dw: bool,
+             dw_into: Optional[Tensor] = None, db_into: Optional[Tensor] = None):
+    """(dx, dw, db); with dw_into (and db_into for a head with bias) the parameter gradients are ADDED into those live
+    .grad buffers by the reduction kernel and returned as None"""
     N, Cc, H, W = x.shape
     K = w.shape[0]
     npix = N * H * W
@@ -1162,10 +1165,15 @@ def head_bwd(x: Tensor, w: Tensor, dlogits: Tensor, need_dx: bool, need_dw: bool
     nbytes = 0
     ws = None
     if need_dw:
-        dw = _f32(K * Cc, x.device)
-        db = _f32(K, x.device)
         nbytes = _lib.load().cy_head1x1_bwd_ws_bytes(npix, Cc, K)
         ws = _ws(nbytes, x.device)
+        if dw_into is not None:
+            with ordered(("head_grad", dw_into.data_ptr())):
+                _lib.call("cy_head1x1_bwd_into", x.data_ptr(), w2.data_ptr(), dlogits.data_ptr(), _ptr(dx),
+                          dw_into.data_ptr(), _ptr(db_into), npix, Cc, K, dtype_code(x.dtype), _ptr(ws), nbytes, _stream())
+            return dx, None, None
+        dw = _f32(K * Cc, x.device)
+        db = _f32(K, x.device)
     _lib.call("cy_head1x1_bwd", x.data_ptr(), w2.data_ptr(), dlogits.data_ptr(), _ptr(dx), _ptr(dw),
               _ptr(db), npix, Cc, K, dtype_code(x.dtype), _ptr(ws), nbytes, _stream())
     if dw is not None:
@@ -1279,7 +1287,8 @@ def proj_head_fwd(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, slo
     hid, out = w1.shape[0], w2.shape[0]
     dev = x.device
     pooled, y1 = _f32(B * Cc, dev).view(B, Cc), _f32(B * hid, dev).view(B, hid)
-    y2, z, norms = _f32(B * out, dev).view(B, out), _f32(B * out, dev).view(B, out), _f32(B, dev)
+    y2, norms = _f32(B * out, dev).view(B, out), _f32(B, dev)
+    z = torch.empty((B, out), dtype=torch.float32, device=dev)  # (not a view: SupConLoss1 rejoins its two chunks through z)
     _lib.call("cy_proj_head_fwd", x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
               pooled.data_ptr(), y1.data_ptr(), y2.data_ptr(), z.data_ptr(), norms.data_ptr(), B, H * W, Cc, hid, out,
               float(slope), float(eps), dtype_code(x.dtype), _stream())

@@ -371,6 +371,11 @@ size_t cy_head1x1_bwd_ws_bytes(long npix, int C, int K);
 int cy_head1x1_bwd(const void* x, const float* w, const float* dlogits, void* dx, float* dw,
                    float* db, long npix, int C, int K, int x_dtype, void* ws, size_t ws_bytes,
                    void* stream);
+/* the same with the parameter gradients ADDED into dw [K][C] / db [K] (the live .grad buffers of the head: autograd's
+ * accumulation folded into the reduction, as for the conv and BatchNorm parameters) */
+int cy_head1x1_bwd_into(const void* x, const float* w, const float* dlogits, void* dx, float* dw,
+                        float* db, long npix, int C, int K, int x_dtype, void* ws, size_t ws_bytes,
+                        void* stream);
 
 /* ------------------------------------------------------------------------
  * Supervised loss  KL_div(softmax(logits), one_hot(target))
