@@ -1300,7 +1300,8 @@ int cy_conv3x3_fwd(const cy_conv_desc* d, const void* src1, const void* src2, co
 
 static int conv_fwd_impl(const cy_conv_desc* d, const void* src1, const void* src2, const cy_bn_fold* in_fold,
                          const float* scale, const float* shift, const cy_bn_bwd_in* bwd, const void* w_packed, void* out,
-                         void* out2, float* stats, const cy_bn_acc* out_acc, void* ws, size_t ws_bytes, void* stream);
+                         void* out2, float* stats, const cy_bn_acc* out_acc, void* ws, size_t ws_bytes, void* stream,
+                         const cy_bn_dz_out* dz = nullptr);
 
 int cy_conv3x3_fwd_bn(const cy_conv_desc* d, const void* src1, const void* src2, const cy_bn_fold* in_fold,
                       const float* scale, const float* shift, const void* w_packed, void* out, void* out2,
@@ -1335,9 +1336,36 @@ int cy_conv3x3_dgrad_bn(const cy_conv_desc* d, const void* dA, const cy_bn_bwd_i
   return conv_fwd_impl(d, dA, nullptr, nullptr, nullptr, nullptr, bn, w_packed, out, out2, nullptr, nullptr, ws, ws_bytes, stream);
 }
 
+// the epilogue can take the backward sums of the BatchNorm behind its output: flow kernel, no split-K, the channel range
+// aligned with the cout blocks (all couts, or the second part of a split output)
+static bool dgrad_dz_plan_ok(const cy_conv_desc* d, const ConvPlan& p, int c0, int Cc) {
+  if (!p.flow || p.ksplit != 1 || d->in_dtype == CY_F32 || d->prologue) return false;
+  // (16-row tiles only: with four fragments per wave and cout block the sums' working set -- 32 partial sums, 16 registers of
+  //  y, 16 of coefficients beside 128 accumulators -- does not fit, the compiler spills ~900 registers in the epilogue and
+  //  the launch takes 3-4 x as long: tools/bench_dgrad_dz.py)
+  if (p.tile.th != 16) return false;
+  if (c0 % p.tile.bn || Cc % p.tile.bn || Cc <= 0) return false;
+  return c0 == 0 ? (Cc == d->Cout && d->split_c == 0) : (d->split_c == c0 && Cc == d->Cout - c0);
+}
+
+int cy_conv3x3_dgrad_dz_ok(const cy_conv_desc* d, int c0, int C) {
+  if (conv_check(d) != CY_OK) return 0;
+  return dgrad_dz_plan_ok(d, plan_of(d), c0, C) ? 1 : 0;
+}
+
+int cy_conv3x3_dgrad_dz(const cy_conv_desc* d, const void* dy, const void* w_packed, void* out, void* out2,
+                        const cy_bn_dz_out* dz, void* ws, size_t ws_bytes, void* stream) {
+  if (!dz || !dz->y || !dz->coef || !dz->acc || !dz->acc->acc || dz->acc->C != dz->C || dz->acc->R < 1 ||
+      (dz->acc->R & (dz->acc->R - 1)))
+    return CY_ERR_ARG;
+  return conv_fwd_impl(d, dy, nullptr, nullptr, nullptr, nullptr, nullptr, w_packed, out, out2, nullptr, nullptr, ws, ws_bytes,
+                       stream, dz);
+}
+
 static int conv_fwd_impl(const cy_conv_desc* d, const void* src1, const void* src2, const cy_bn_fold* in_fold,
                          const float* scale, const float* shift, const cy_bn_bwd_in* bwd, const void* w_packed, void* out,
-                         void* out2, float* stats, const cy_bn_acc* out_acc, void* ws, size_t ws_bytes, void* stream) {
+                         void* out2, float* stats, const cy_bn_acc* out_acc, void* ws, size_t ws_bytes, void* stream,
+                         const cy_bn_dz_out* dz) {
   int rc = conv_check(d);
   if (rc != CY_OK) return rc;
   if (!src1 || !w_packed || !out) return CY_ERR_ARG;
@@ -1381,6 +1409,11 @@ static int conv_fwd_impl(const cy_conv_desc* d, const void* src1, const void* sr
   a.ws = (float*)ws;
   if (p.ksplit > 1 && (!ws || ws_bytes < p.ws_bytes)) return CY_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  if (dz) {
+    if (!dgrad_dz_plan_ok(d, p, dz->c0, dz->C)) return CY_ERR_SHAPE;
+    a.dz_y = dz->y, a.dz_coef = dz->coef, a.dz_acc = (unsigned long long*)dz->acc->acc, a.dz_R = dz->acc->R;
+    a.dz_ld = dz->C, a.dz_c0 = dz->c0, a.dz_C = dz->C;
+  }
   if (bwd) {
     if (!dgrad_bn_plan_ok(d, p)) return CY_ERR_SHAPE;
     a.ysrc = bwd->y, a.bytes_y = a.bytes1;

@@ -60,7 +60,7 @@ template <typename T, int TH_, int BN_, int WGM_, int WGN_, bool W16_> struct Fl
   static_assert(sizeof(T) == 2 && EPC == 8, "16-bit storage types only");
   static_assert(NW % 2 == 0 && MT % WGM == 0 && BN % (32 * WGN) == 0 && BN % 64 == 0, "wave split");
   static_assert(NAI <= 9 && NBI <= 9, "one DMA slot per tap");
-  static_assert(WGM * 2 * BN * 4 <= STAGE, "statistics scratch");
+  static_assert(WGM * 2 * BN * 4 <= 16384 && 16384 + 4 * BN * 4 <= STAGE, "statistics scratch, then the epilogue's coefficient rows");
   static_assert(SMEM <= 160 * 1024, "LDS");
   static_assert(COEF_MAX <= NTHR, "one prologue coefficient pair per thread");
   static_assert((4 * COEF_MAX + 1) * 8 <= B_BYTES, "the accumulator sums of the fold fit the second stage's weight region");
@@ -87,9 +87,12 @@ inline long flow_image_elems(int Cout, int Cin) {
 
 // BWD: the instantiation for prologue == 2 (the BatchNorm + ReLU backward in the load path); its own build so that the
 // forward kernels keep their register budget
-template <typename T, int TH, int BN, int WGM, int WGN, bool W16, bool BWD = false>
+// MODE 2: the instantiation whose epilogue adds the backward sums of the BatchNorm behind its output (a.dz_y) -- its own
+// build for the same reason
+template <typename T, int TH, int BN, int WGM, int WGN, bool W16, int MODE = 0>
 __global__ void __launch_bounds__(64 * WGM * WGN, 2)
     conv3x3_flow_kernel(const ConvArgs a) {
+  constexpr bool BWD = MODE == 1, DZK = MODE == 2;
 #if defined(__HIP_DEVICE_COMPILE__)  // (buffer-descriptor type and builtins exist in the device pass only)
   using C = FlowCfg<T, TH, BN, WGM, WGN, W16>;
   using M = Mma<T>;
@@ -172,6 +175,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
   if (a.prologue && (pro2 || !a.fold.acc) && tid < a.C1) {  // host: C1 <= COEF_MAX <= NTHR
     csc = pro2 ? a.bfold.coef[tid] : a.scale[tid];
     csh = pro2 ? a.bfold.coef[a.C1 + tid] : a.shift[tid];
+  }
+  // backward sums in the epilogue (a.dz_y): this workgroup's couts' forward coefficients, requested before any DMA
+  const bool dz_on = DZK && a.ksplit == 1 && n0 >= a.dz_c0 && n0 < a.dz_c0 + a.dz_C;  // wave-uniform; host: block-aligned
+  float dzc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (dz_on && tid < BN) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dzc[q] = a.dz_coef[q * a.dz_C + (n0 - a.dz_c0) + tid];
   }
   const __amdgpu_buffer_rsrc_t rsy = make_rsrc(pro2 ? a.ysrc : a.src1, pro2 ? a.bytes_y : 0);
   const __amdgpu_buffer_rsrc_t rsd = make_rsrc(pro2 ? a.dy_out : a.out, pro2 ? a.bytes_dy : 0);
@@ -491,10 +501,53 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
     (void)position(0, R, w);
     col_ok = C::W16 ? (w < a.W) : (pcol >= 1 && pcol <= TW && w < a.W);
   }
+  // DZ (STATS_ == 2): the output is the dA of relu(bn(y)); the sums are of dz = dA * [scale * y + shift > 0] and dz * xhat
+  // (xhat = y * invstd - mean * invstd), with this lane's four channels of y per fragment and group fetched one fragment
+  // ahead and the coefficient rows [scale, shift, invstd, -mean * invstd][BN] read from LDS (s_dz)
+  const float* s_dz = reinterpret_cast<const float*>(smem + 16384);
+  const T* dzy = reinterpret_cast<const T*>(a.dz_y);
   auto epilogue = [&](auto STATS_, auto MASKED_) {
     constexpr bool STATS = decltype(STATS_)::value != 0, MASKED = decltype(MASKED_)::value != 0;
+    constexpr bool DZ = decltype(STATS_)::value == 2;
+    u32x2 ycur[4], ynxt[4];
+    auto yload = [&](int n, int m, u32x2 (&yv)[4]) {
+      int R, w;
+      // (unconditional loads from a clamped address: a load behind a per-lane branch turns every live value of the
+      //  unrolled epilogue into a phi web; invalid positions are masked out of the sums below)
+      const bool ok = position(m, R, w);
+      const size_t gpos = ok ? (size_t)R * a.W + w : 0;
+      const T* yp = dzy + gpos * a.dz_ld + (n0 - a.dz_c0) + (wn * N_REP + n) * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) yv[g] = *reinterpret_cast<const u32x2*>(yp + 8 * g);
+    };
+    auto unpack2 = [&](unsigned wd) {
+      if constexpr (__is_same(T, bf16)) {
+        return f32x2{__uint_as_float(wd << 16), __uint_as_float(wd & 0xffff0000u)};
+      } else {
+        return f32x2{(float)__builtin_bit_cast(f16, (unsigned short)(wd & 0xffffu)),
+                     (float)__builtin_bit_cast(f16, (unsigned short)(wd >> 16))};
+      }
+    };
+    if constexpr (DZ) yload(0, 0, ycur);
 #pragma unroll
   for (int n = 0; n < N_REP; ++n) {
+    // phase A: the block's accumulators -> the packed 16-bit store payload (frees 16 registers per fragment for 8:
+    // everything below works from the payload, and with the DZ sums the live set would not fit otherwise)
+    u32x2 packed[M_REP][4];
+#pragma unroll
+    for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        T pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk[j] = from_f32<T>(acc[m][n][4 * g + j]);
+        packed[m][g] = __builtin_bit_cast(u32x2, *reinterpret_cast<const s16x4*>(pk));
+        if constexpr (DZ) {  // (materialise the payload HERE: the optimiser otherwise sinks the conversions to their first
+                             //  use and the 16 accumulator registers of every fragment stay live through the whole block)
+          asm volatile("" : "+v"(packed[m][g][0]), "+v"(packed[m][g][1]));
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
     f32x2 p1[8], p2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) p1[i] = p2[i] = f32x2{0.f, 0.f};
@@ -503,33 +556,54 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
       int R, w;
       const bool ok = position(m, R, w);
       const size_t gp = (size_t)R * a.W + w;
-      u32x2 packed[4];
+      if constexpr (DZ) {
+        if (m + 1 < M_REP) yload(n, m + 1, ynxt);
+        else if (n + 1 < N_REP) yload(n + 1, 0, ynxt);
+        // (the coefficient rows read below are the same for every m: without a barrier the unrolled code reads all
+        //  sixteen vectors of a cout block once, up front -- 64 registers beside the accumulators, ~900 spills)
+        asm volatile("" ::: "memory");
+      }
+      int zofs = 0;  // an opaque zero per fragment: the coefficient reads of different fragments must not be merged
+      if constexpr (DZ) asm volatile("s_mov_b32 %0, 0" : "=s"(zofs));
+      if constexpr (STATS) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        T pk[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pk[j] = from_f32<T>(acc[m][n][4 * g + j]);
-        packed[g] = __builtin_bit_cast(u32x2, *reinterpret_cast<const s16x4*>(pk));
-        if constexpr (STATS) {
+        for (int g = 0; g < 4; ++g) {
+          f32x4 csf, cbf, cis, cmi;
+          if constexpr (DZ) {
+            asm volatile("" ::: "memory");  // (pins this group's four reads here: see above)
+            const int cl = (wn * N_REP + n) * 32 + 8 * g + 4 * h + zofs;
+            csf = *reinterpret_cast<const f32x4*>(s_dz + cl), cbf = *reinterpret_cast<const f32x4*>(s_dz + BN + cl);
+            cis = *reinterpret_cast<const f32x4*>(s_dz + 2 * BN + cl), cmi = *reinterpret_cast<const f32x4*>(s_dz + 3 * BN + cl);
+          }
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
-            f32x2 q;
-            if constexpr (sizeof(T) == 2 && ElemTr<T>::EPC == 8 && __is_same(T, bf16)) {
-              q = f32x2{__uint_as_float(packed[g][k] << 16), __uint_as_float(packed[g][k] & 0xffff0000u)};
-            } else {
-              q = f32x2{to_f32<T>(pk[2 * k]), to_f32<T>(pk[2 * k + 1])};
-            }
+            f32x2 q = unpack2(packed[m][g][k]);
             if constexpr (MASKED) {
               if (!ok) q = f32x2{0.f, 0.f};
             }
-            p1[2 * g + k] += q;
-            p2[2 * g + k] += q * q;
+            if constexpr (DZ) {
+              const f32x2 yv = unpack2(ycur[g][k]);
+              const f32x2 sf2 = f32x2{csf[2 * k], csf[2 * k + 1]}, bf2 = f32x2{cbf[2 * k], cbf[2 * k + 1]};
+              const f32x2 is2 = f32x2{cis[2 * k], cis[2 * k + 1]}, mi2 = f32x2{cmi[2 * k], cmi[2 * k + 1]};
+              const f32x2 z = sf2 * yv + bf2;
+              const f32x2 dz = f32x2{z[0] > 0.f ? q[0] : 0.f, z[1] > 0.f ? q[1] : 0.f};
+              p1[2 * g + k] += dz;
+              p2[2 * g + k] += dz * (yv * is2 + mi2);
+            } else {
+              p1[2 * g + k] += q;
+              p2[2 * g + k] += q * q;
+            }
           }
+          if constexpr (DZ) __builtin_amdgcn_sched_barrier(0);  // (one channel group's four coefficient vectors at a time)
         }
+      }
+      if constexpr (DZ) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ycur[g] = ynxt[g];
       }
 #pragma unroll
       for (int g = 0; g < 4; g += 2) {  // half-wave swaps pair the 8-byte channel runs into 16-byte stores
-        u32x2 lo = packed[g], hi = packed[g + 1];
+        u32x2 lo = packed[m][g], hi = packed[m][g + 1];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const auto sw = __builtin_amdgcn_permlane32_swap(lo[j], hi[j], false, false);
@@ -543,7 +617,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
           *reinterpret_cast<u32x4*>(dst) = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
       }
-      __builtin_amdgcn_sched_barrier(0);  // (one fragment at a time: hoisted conversions would not fit the registers)
+      __builtin_amdgcn_sched_barrier(0);  // (one fragment at a time)
     }
     float s1v[16], s2v[16];
 #pragma unroll
@@ -598,10 +672,22 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
   }
   };
   // (compile-time variants: a run-time `do_stats` inside the unrolled loops turns every sum into a phi web)
-  if (!do_stats) epilogue(TapC<0>{}, TapC<0>{});
+  if constexpr (DZK) {
+    if (dz_on) {  // (the coefficient rows of this block's couts: in LDS behind the statistics scratch)
+      if (tid < BN) {
+        float* w_dz = reinterpret_cast<float*>(smem + 16384);
+        w_dz[tid] = dzc[0], w_dz[BN + tid] = dzc[1], w_dz[2 * BN + tid] = dzc[3], w_dz[3 * BN + tid] = -dzc[2] * dzc[3];
+      }
+      __syncthreads();
+      if (rows_full) epilogue(TapC<2>{}, TapC<0>{});
+      else epilogue(TapC<2>{}, TapC<1>{});
+    } else {
+      epilogue(TapC<0>{}, TapC<0>{});
+    }
+  } else if (!do_stats) epilogue(TapC<0>{}, TapC<0>{});
   else if (rows_full) epilogue(TapC<1>{}, TapC<0>{});
   else epilogue(TapC<1>{}, TapC<1>{});
-  if (do_stats) {
+  if (do_stats || dz_on) {
     __syncthreads();
     if (tid < BN && n0 + tid < a.Cout) {
       float t1 = 0.f, t2 = 0.f;
@@ -610,7 +696,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
         t1 += sstat[(qq * 2 + 0) * BN + tid];
         t2 += sstat[(qq * 2 + 1) * BN + tid];
       }
-      if (a.sacc) {
+      if (dz_on) {
+        bn_acc_add(a.dz_acc, a.dz_R, a.dz_C, tile & (a.dz_R - 1), 0, n0 - a.dz_c0 + tid, t1);
+        bn_acc_add(a.dz_acc, a.dz_R, a.dz_C, tile & (a.dz_R - 1), 1, n0 - a.dz_c0 + tid, t2);
+      } else if (a.sacc) {
         bn_acc_add(a.sacc, a.sR, a.Cout, tile & (a.sR - 1), 0, n0 + tid, t1);
         bn_acc_add(a.sacc, a.sR, a.Cout, tile & (a.sR - 1), 1, n0 + tid, t2);
       } else {
@@ -658,16 +747,18 @@ inline FlowChoice flow_choice(const cy_conv_desc* d) {
   return f;
 }
 
-template <typename T, int TH, int BN, int WGM, int WGN, bool W16, bool BWD = false>
+template <typename T, int TH, int BN, int WGM, int WGN, bool W16, int MODE = 0>
 int launch_conv_flow(ConvArgs a, hipStream_t st) {
   using C = FlowCfg<T, TH, BN, WGM, WGN, W16>;
-  if constexpr (!BWD) {
+  constexpr bool BWD = MODE == 1;
+  if constexpr (MODE == 0) {
     if (a.prologue == 2) {
-      if constexpr (C::BWD_OK) return launch_conv_flow<T, TH, BN, WGM, WGN, W16, true>(a, st);
+      if constexpr (C::BWD_OK) return launch_conv_flow<T, TH, BN, WGM, WGN, W16, 1>(a, st);
       else return CY_ERR_SHAPE;
     }
+    if (a.dz_y != nullptr) return launch_conv_flow<T, TH, BN, WGM, WGN, W16, 2>(a, st);
   }
-  auto kern = conv3x3_flow_kernel<T, TH, BN, WGM, WGN, W16, BWD>;
+  auto kern = conv3x3_flow_kernel<T, TH, BN, WGM, WGN, W16, MODE>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -51,6 +51,13 @@ struct ConvArgs {
   BnBwdFold bfold;     // bfold.coef = the forward pass's [5][C1]
   void* dy_out;        // [N,H,W,C1], pitch ld1
   long long bytes_dy;
+  // data gradient whose output is the dA of a BatchNorm + ReLU (flow kernel epilogue, cy_conv3x3_dgrad_dz): the sums of
+  // dz = dA * [scale * y + shift > 0] and dz * xhat of the output channels [dz_c0, dz_c0 + dz_C) are added into dz_acc
+  // from the values in registers -- the separate reduce pass over (dA, y) goes
+  const void* dz_y;         // y of that BatchNorm [N,H,W,dz_C], pitch dz_ld; null: off
+  const float* dz_coef;     // its forward [5][dz_C]
+  unsigned long long* dz_acc;
+  int dz_ld, dz_c0, dz_C, dz_R;
 };
 
 // ---- MFMA fragment abstraction: one "k-step" is 16 input channels ----------

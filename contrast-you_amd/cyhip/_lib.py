@@ -70,6 +70,11 @@ class BnBwdIn(C.Structure):
                 ("dy", c_void_p)]
 
 
+class BnDzOut(C.Structure):
+    """mirror of cy_bn_dz_out"""
+    _fields_ = [("y", c_void_p), ("coef", c_void_p), ("acc", POINTER(BnAcc)), ("c0", c_int32), ("C", c_int32)]
+
+
 class BnRunItem(C.Structure):
     """mirror of cy_bn_run_item"""
     _fields_ = [("coef", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p), ("C", c_int32),
@@ -122,6 +127,8 @@ _SIGS = {
     "cy_conv3x3_first_fwd_acc": (c_int, [_P, _P, _P, _PBA, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cy_conv3x3_dgrad_bn_ok": (c_int, [_PCD]),
     "cy_conv3x3_dgrad_bn": (c_int, [_PCD, _P, POINTER(BnBwdIn), _P, _P, _P, _P, c_size_t, _P]),
+    "cy_conv3x3_dgrad_dz_ok": (c_int, [_PCD, c_int, c_int]),
+    "cy_conv3x3_dgrad_dz": (c_int, [_PCD, _P, _P, _P, _P, POINTER(BnDzOut), _P, c_size_t, _P]),
     "cy_bn_fold_coef": (c_int, [_PBF, _P]),
     "cy_bn_relu_apply_fold": (c_int, [_P, _PBF, _P, c_long, c_int, c_int, _P]),
     "cy_bn_relu_apply_pool_fold": (c_int, [_P, _PBF, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
@@ -232,7 +239,7 @@ _SIGS = {
 # functions whose int return is a count / size, not a status
 _COUNT_FUNCS = {"cy_abi_version", "cy_conv3x3_num_partials", "cy_conv3x3_first_num_partials",
                 "cy_bn_bwd_num_partials", "cy_bn_acc_replicas", "cy_conv3x3_stat_workgroups",
-                "cy_bn_relu_bwd_workgroups", "cy_conv3x3_dgrad_bn_ok"}
+                "cy_bn_relu_bwd_workgroups", "cy_conv3x3_dgrad_bn_ok", "cy_conv3x3_dgrad_dz_ok"}
 # (cy_maxpool2_bwd_bn_num_partials returns a count or a negative status: the caller tests the sign itself)
 
 _lib = None

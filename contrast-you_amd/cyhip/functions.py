@@ -327,6 +327,7 @@ class ConvChainFn(torch.autograd.Function):
             out._cy_tail = (ys[-1], coefs[-1][0], ctx.bwd_accs[-1])
         # ... and this block, if it upsamples on load, is such a producer for the block whose output it reads
         ctx.up_tail = getattr(x1, "_cy_tail", None) if (cfg.mode == ops.CY_SRC_UP2 and ops.BN_ACC) else None
+        ctx.x2_tail = getattr(x2, "_cy_tail", None) if (x2 is not None and ops.BN_ACC) else None
         if RAW_TAP is not None:
             for i in range(nconv):
                 RAW_TAP(cfg.bns[i], ys[i], coefs[i][0], coefs[i][1], out if i == nconv - 1 else None)
@@ -397,7 +398,12 @@ class ConvChainFn(torch.autograd.Function):
         grads_p: List[Optional[Tensor]] = [None] * (3 * nconv)
         da = dout
         dx1 = dx2 = None
+        dz_filled = False  # the data gradient that produced `da` has added this iteration's BatchNorm's backward sums
         for i in reversed(range(nconv)):
+            if i == nconv - 1:
+                sums_done = pool_acc_filled
+            else:
+                sums_done, dz_filled = dz_filled, False
             w, g, b = params[3 * i: 3 * i + 3]
             scale, shift, mean, invstd = coefs[i]
             need_w, need_g, need_b = need[3 + 3 * i], need[3 + 3 * i + 1], need[3 + 3 * i + 2]
@@ -418,7 +424,7 @@ class ConvChainFn(torch.autograd.Function):
                 da_f = ops.to_nhwc(da if da.dtype == ys[i].dtype else da.to(ys[i].dtype))
                 if ops.conv3x3_dgrad_bn_ok(da_f, Cin_i, split_i):
                     acc_i = accs[i] if accs[i] is not None else ops.bn_bwd_acc_new(*ys[i].shape[:2], *ys[i].shape[2:], False, da_f.device)
-                    if not (pool_acc_filled and i == nconv - 1):
+                    if not sums_done:
                         ops.bn_bwd_reduce_acc(da_f, ys[i], scale, acc_i)
                     _, wd = packed_weights(w, dt)
                     fused_dx, dy, dgamma, dbeta = ops.conv3x3_dgrad_bn(
@@ -430,7 +436,7 @@ class ConvChainFn(torch.autograd.Function):
                 # (scale is row 0 of the contiguous coefficient block [scale, shift, mean, invstd, ...] of either path)
                 dy, dgamma, dbeta = ops.bn_relu_bwd_acc(da, ys[i], scale, ctx.batch_flags[i], dgamma_out=gsink,
                                                         dbeta_out=bsink, want_param_grads=need_g or need_b,
-                                                        acc=accs[i], acc_filled=pool_acc_filled and i == nconv - 1)
+                                                        acc=accs[i], acc_filled=sums_done)
             else:
                 dy, dgamma, dbeta = ops.bn_relu_bwd(da, ys[i], scale, shift, mean, invstd, ctx.batch_flags[i],
                                                     dgamma_out=gsink, dbeta_out=bsink,
@@ -455,7 +461,14 @@ class ConvChainFn(torch.autograd.Function):
                     da = fused_dx
                 else:
                     _, wd = packed_weights(w, dt)
-                    da, _ = ops.conv3x3_fwd(dy, None, wd, w.shape[1], want_stats=False)
+                    # the output is the dA of this block's previous BatchNorm: its backward sums from the epilogue
+                    # where the launch plan allows (then the next iteration skips the reduce launch)
+                    if (accs is not None and accs[i - 1] is not None
+                            and ops.conv3x3_dgrad_dz_ok(dy, w.shape[1], None, 0, w.shape[1])):
+                        da = ops.conv3x3_dgrad_dz(dy, wd, w.shape[1], ys[i - 1], coefs[i - 1][0], accs[i - 1])
+                        dz_filled = True
+                    else:
+                        da, _ = ops.conv3x3_fwd(dy, None, wd, w.shape[1], want_stats=False)
             else:
                 if need_w:
                     if wsink is not None and ops.ASYNC_WGRAD:
@@ -488,8 +501,16 @@ class ConvChainFn(torch.autograd.Function):
                         else:
                             dl1 = fused_dx
                     elif ctx.has_x2:
-                        (dl1, dl2), _ = ops.conv3x3_fwd(dy, None, wd, w.shape[1], want_stats=False,
-                                                        split=C1)
+                        t2 = ctx.x2_tail
+                        if (t2 is not None and need_x2 and t2[2].filled_for is None
+                                and ops.conv3x3_dgrad_dz_ok(dy, w.shape[1], C1, C1, w.shape[1] - C1)):
+                            # the second part of the output is the dA of the block that produced x2 (an _UpConv): its
+                            # BatchNorm's backward sums from this launch's epilogue
+                            dl1, dl2 = ops.conv3x3_dgrad_dz(dy, wd, w.shape[1], t2[0], t2[1], t2[2], split=C1)
+                            t2[2].filled_for = dl2
+                        else:
+                            (dl1, dl2), _ = ops.conv3x3_fwd(dy, None, wd, w.shape[1], want_stats=False,
+                                                            split=C1)
                         dx2 = dl2 if need_x2 else None
                     else:
                         dl1, _ = ops.conv3x3_fwd(dy, None, wd, w.shape[1], want_stats=False)

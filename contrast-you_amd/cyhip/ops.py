@@ -1106,6 +1106,59 @@ def conv3x3_dgrad_bn(da: Tensor, y: Tensor, coef: Tensor, acc: "BnAccBuf", batch
     return ((out, out2) if split else out), dy, dgamma, dbeta
 
 
+# A data gradient whose output is the dA of a BatchNorm + ReLU adds that layer's backward sums in its epilogue
+# (cy_conv3x3_dgrad_dz): the reduce launch over (dA, y) goes.  OFF unless CY_DGRAD_DZ=1: on the 16-row tilings the fused
+# launch takes what the two took (28.0 against 20.6 + 7.5 us at 56 x 56 x 128, tools/bench_dgrad_dz.py), on the tilings
+# with four fragments per wave the sums' working set spills ~900 registers (3-4 x slower: excluded by the plan), and the
+# step does not move (tools/ab.sh CY_DGRAD_DZ 0 1: 6.28 against 6.28 ms) -- the conv kernels are what the step waits for,
+# work moved into them costs what it saved.  DESIGN.md section 3 "Round 4".
+DGRAD_DZ = os.environ.get("CY_DGRAD_DZ", "0") == "1"
+_dz_ok_cache = {}
+
+
+def conv3x3_dgrad_dz_ok(dy: Tensor, Cin: int, split: Optional[int], c0: int, Cs: int) -> bool:
+    if not (DGRAD_DZ and BN_ACC) or dy.dtype not in HALF_TYPES:
+        return False
+    N, Cc, H, W = dy.shape
+    key = (N, Cc, H, W, Cin, split, c0, Cs, dy.dtype)
+    ok = _dz_ok_cache.get(key)
+    if ok is None:
+        dt = dtype_code(dy.dtype)
+        d = _desc(N, H, W, Cc, 0, Cin, 0, 0, dt, Cc, 0, split, split, Cin - split) if split else \
+            _desc(N, H, W, Cc, 0, Cin, 0, 0, dt, Cc, 0, Cin)
+        ok = _dz_ok_cache[key] = bool(_lib.call("cy_conv3x3_dgrad_dz_ok", d.ref, c0, Cs))
+    return ok
+
+
+def conv3x3_dgrad_dz(dy: Tensor, wd: Tensor, Cin: int, y: Tensor, coef: Tensor, acc: "BnAccBuf", *,
+                     split: Optional[int] = None):
+    """conv3x3_fwd(dy, wd) as a data gradient whose output -- all of it, or with `split` its second part -- is the dA
+    of relu(bn(y)): that layer's backward sums are added into `acc` by the epilogue.  Returns out or (out1, out2)."""
+    N, Cc, H, W = dy.shape
+    dev = dy.device
+    dt = dtype_code(dy.dtype)
+    if split:
+        out = empty_nhwc(N, split, H, W, dy.dtype, dev)
+        out2 = empty_nhwc(N, Cin - split, H, W, dy.dtype, dev)
+        d = _desc(N, H, W, Cc, 0, Cin, 0, 0, dt, Cc, 0, split, split, Cin - split)
+    else:
+        out, out2 = empty_nhwc(N, Cin, H, W, dy.dtype, dev), None
+        d = _desc(N, H, W, Cc, 0, Cin, 0, 0, dt, Cc, 0, Cin)
+    if d.fwd_ws is None:
+        d.fwd_ws = _lib.load().cy_conv3x3_fwd_ws_bytes(d.ref)
+    nbytes = d.fwd_ws
+    ws = _ws(nbytes, dev) if nbytes else None
+    dz = _lib.BnDzOut(y.data_ptr(), coef.data_ptr(), C.pointer(acc.s), split or 0, y.shape[1])
+    ev = _prof_begin()
+    _lib.call("cy_conv3x3_dgrad_dz", d.ref, dy.data_ptr(), wd.data_ptr(), out.data_ptr(), _ptr(out2), C.byref(dz),
+              _ptr(ws), nbytes, _stream())
+    if ev is not None:
+        esz = dy.element_size()
+        nb = esz * (dy.numel() + y.numel() + N * H * W * Cin + 9 * Cc * Cin)
+        _prof_end(ev, "conv3x3_fwd_dgrad", 2.0 * N * H * W * 9 * Cc * Cin, float(nb))
+    return (out, out2) if split else out
+
+
 def maxpool2_bwd(x: Tensor, dpool: Tensor, add: Optional[Tensor] = None) -> Tensor:
     N, Cc, H2, W2 = x.shape
     dx = empty_nhwc(N, Cc, H2, W2, x.dtype, x.device)

@@ -290,6 +290,21 @@ int cy_conv3x3_dgrad_bn_ok(const cy_conv_desc* d);
 int cy_conv3x3_dgrad_bn(const cy_conv_desc* d, const void* dA, const cy_bn_bwd_in* bn, const void* w_packed, void* out,
                         void* out2, void* ws, size_t ws_bytes, void* stream);
 
+/* A data gradient whose output (all couts, or the second part of a split output: channels [c0, c0 + C)) is the dA of
+ * a BatchNorm + ReLU: the epilogue adds that layer's backward sums (dz = dA * [scale*y + shift > 0], dz * xhat) into
+ * `acc` from the values it has in registers -- y of that layer is read once, at the output positions -- and the reduce
+ * launch (cy_bn_relu_bwd_reduce_acc) is not needed.  Flow-kernel plans without split-K whose cout blocks align with the
+ * range: ask cy_conv3x3_dgrad_dz_ok(d, c0, C). */
+typedef struct cy_bn_dz_out {
+  const void* y;        /* [N,H,W,C], contiguous */
+  const float* coef;    /* that layer's forward [5][C] */
+  const cy_bn_acc* acc;
+  int32_t c0, C;
+} cy_bn_dz_out;
+int cy_conv3x3_dgrad_dz_ok(const cy_conv_desc* d, int c0, int C);
+int cy_conv3x3_dgrad_dz(const cy_conv_desc* d, const void* dy, const void* w_packed, void* out, void* out2,
+                        const cy_bn_dz_out* dz, void* ws, size_t ws_bytes, void* stream);
+
 /* First layer (input_dim 1..4, arch/unet.py:72): x is the f32 NCHW image
  * [N,Cin,H,W]; w is the reference-layout f32 weight [Cout][Cin][3][3]. */
 int cy_conv3x3_first_num_partials(int N, int H, int W, int Cout);

@@ -372,3 +372,54 @@ def test_producer_side_sums_are_dropped_when_other_gradients_join():
             ops.BN_ACC = True
     for n, gb in res[False].items():
         assert (res[True][n] - gb).abs().max() <= 1e-4 * gb.abs().max() + 1e-8, n
+
+
+# (N, H, W, C of dy, Cin of the data gradient, split, dtype)
+DGRAD_DZ_CASES = [
+    (16, 56, 56, 128, 128, None, torch.bfloat16),
+    (32, 56, 56, 128, 128, None, torch.bfloat16),
+    (16, 112, 112, 64, 64, None, torch.bfloat16),
+    (16, 28, 28, 256, 256, None, torch.bfloat16),
+    (16, 28, 28, 256, 512, 256, torch.bfloat16),
+    (6, 28, 28, 128, 128, None, torch.float16),
+    (3, 40, 48, 64, 128, 64, torch.float16),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_DZ_CASES, ids=lambda c: "x".join(str(v).replace("torch.", "") for v in c))
+def test_dgrad_epilogue_adds_the_backward_sums(case):
+    """cy_conv3x3_dgrad_dz: the same data gradient as cy_conv3x3_fwd, and the accumulator holds what the reduce launch
+    over (its output, y) adds -- for the whole output, or the second part of a split output"""
+    ops = _ops()
+    N, H, W, C, Cin, split, dt = case
+    g = torch.Generator().manual_seed(31)
+    dy = nhwc(torch.randn(N, C, H, W, generator=g), dt)
+    w = (torch.randn(C, Cin, 3, 3, generator=g) * 0.05).to(DEV)
+    _, wd = ops.pack_weights(w, dt, want_dgrad=True)
+    Cs = Cin - split if split else Cin
+    y = nhwc(torch.randn(N, Cs, H, W, generator=g), dt)
+    coef = torch.rand(5, Cs, generator=g).to(DEV) + 0.25
+    coef[1] -= 0.75
+    ops.DGRAD_DZ = True  # (opt-in in the product path: CY_DGRAD_DZ=1)
+    try:
+        ok = ops.conv3x3_dgrad_dz_ok(dy, Cin, split, split or 0, Cs)
+    finally:
+        ops.DGRAD_DZ = False
+    if not ok:
+        pytest.skip("no 16-row flow-kernel plan without split-K for this geometry")
+    ref, _ = ops.conv3x3_fwd(dy, None, wd, Cin, want_stats=False, split=split)
+    acc = ops.bn_bwd_acc_new(N, Cs, H, W, False, DEV)
+    out = ops.conv3x3_dgrad_dz(dy, wd, Cin, y, coef[0], acc, split=split)
+    refs = ref if split else (ref,)
+    outs = out if split else (out,)
+    for a, b in zip(outs, refs):
+        assert torch.equal(a, b)
+    acc2 = ops.bn_bwd_acc_new(N, Cs, H, W, False, DEV)
+    ops.bn_bwd_reduce_acc(refs[-1], y, coef[0], acc2)
+    a1, a2 = acc_sums(acc)
+    b1, b2 = acc_sums(acc2)
+    assert torch.allclose(a1, b1, rtol=0, atol=3e-6 * b1.abs().max().item()), (a1 - b1).abs().max()
+    assert torch.allclose(a2, b2, rtol=0, atol=3e-6 * b2.abs().max().item()), (a2 - b2).abs().max()
+    acc3 = ops.bn_bwd_acc_new(N, Cs, H, W, False, DEV)
+    ops.conv3x3_dgrad_dz(dy, wd, Cin, y, coef[0], acc3, split=split)
+    assert torch.equal(acc3.t, acc.t)

@@ -12,6 +12,8 @@ REPO = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(REPO / "contrast-you_amd"))
 from cyhip import ops  # noqa: E402
 
+ops.DGRAD_BN = True
+
 
 def timeit(fn, iters=20):
     for _ in range(2):
