@@ -88,8 +88,34 @@ __device__ __forceinline__ double bn_acc_read(const unsigned long long* acc, int
 // limb rows, then the flag).  One thread per channel walking the replicas (the first version) is a chain of dependent
 // round trips -- R / 4 of them, 4-8 us on the 32-channel layers with R = 32; here every thread has its R * 4 * C / nthr
 // loads in flight at once and adds them with LDS atomics (integer adds: any order gives the same words).
+template <int RR>
+__device__ __forceinline__ void bn_acc_gather_direct(const unsigned long long* acc, int C, unsigned long long* s_sum,
+                                                     int tid, int nthr) {
+  // few replicas: a thread sums its word's RR replicas itself, all loads in flight at once -- no LDS atomics, one barrier
+  const int row = 4 * C;
+  for (int i = tid; i < row; i += nthr) {
+    unsigned long long v[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) v[r] = acc[(size_t)r * row + i];
+    unsigned long long t = v[0];
+#pragma unroll
+    for (int r = 1; r < RR; ++r) t += v[r];
+    s_sum[i] = t;
+  }
+  if (tid == 0) {
+    unsigned long long bad = 0;
+    for (int r = 0; r < RR; ++r) bad |= acc[(size_t)RR * row + r];
+    s_sum[row] = bad;
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ void bn_acc_gather(const unsigned long long* acc, int R, int C, unsigned long long* s_sum,
                                               int tid, int nthr) {
+  if (R == 1) return bn_acc_gather_direct<1>(acc, C, s_sum, tid, nthr);
+  if (R == 2) return bn_acc_gather_direct<2>(acc, C, s_sum, tid, nthr);
+  if (R == 4) return bn_acc_gather_direct<4>(acc, C, s_sum, tid, nthr);
+  if (R == 8) return bn_acc_gather_direct<8>(acc, C, s_sum, tid, nthr);
   const int row = 4 * C;
   for (int i = tid; i <= row; i += nthr) s_sum[i] = 0ull;
   __syncthreads();
@@ -101,6 +127,15 @@ __device__ __forceinline__ void bn_acc_gather(const unsigned long long* acc, int
   }
   if (tid < R && acc[n + tid]) atomicOr(&s_sum[row], 1ull);
   __syncthreads();
+}
+
+// 1 / sqrt(x) in f64 without the compiler's division + square-root sequences (a microsecond per channel in a kernel
+// prologue that is nothing but latency): the hardware estimate and two Newton steps (full f64 accuracy for x > 0)
+__device__ __forceinline__ double bn_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
 }
 __device__ __forceinline__ double bn_sum_read(const unsigned long long* s_sum, int C, int q, int c) {
   if (s_sum[4 * C]) return __builtin_nan("");
@@ -123,7 +158,7 @@ __device__ __forceinline__ void bn_fold_finish(const BnFold& f, int c, bool lead
   const double mean = s1 * f.inv_count;
   double var = s2 * f.inv_count - mean * mean;
   if (var < 0.0) var = 0.0;
-  const double istd = 1.0 / sqrt(var + (double)f.eps);
+  const double istd = bn_rsqrt(var + (double)f.eps);
   const double g = f.gamma ? (double)f.gamma[c] : 1.0, b = f.beta ? (double)f.beta[c] : 0.0;
   sc = (float)(g * istd);
   sh = (float)(b - mean * g * istd);

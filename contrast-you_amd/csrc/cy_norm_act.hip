@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(256) bn_running_update_kernel(const BnRunArgs 
 
 // grid of the folding elementwise kernels: every workgroup reads the accumulator, so few, long-running workgroups
 inline int fold_grid(long items) {
-  long b = (items + 1023) / 1024;  // (512 / 2048 and 256 / 2048 measured the same or slower: profiles of the C2 step)
+  long b = (items + 255) / 256;  // (as many workgroups as the plain kernels on the small maps, whose time is latency)
   if (b > 1024) b = 1024;
   if (b < 1) b = 1;
   return (int)b;
