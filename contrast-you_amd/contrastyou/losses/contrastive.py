@@ -70,8 +70,6 @@ def _rejoin(a: Tensor, b: Tensor) -> Tensor:
 class SupConLoss1(nn.Module):
     def __init__(self, temperature=0.07, exclude_other_pos=False):
         super().__init__()
-        if exclude_other_pos:
-            raise NotImplementedError("exclude_other_pos=True is not on the InfoNCE hook path")
         self._t = temperature
         self._exclude_pos = exclude_other_pos
         self.defer_checks = False
@@ -92,7 +90,7 @@ class SupConLoss1(nn.Module):
         else:
             labels = torch.arange(n, dtype=torch.int32, device=dev)  # SimCLR: only the other view
         P = _rejoin(proj_feat1, proj_feat2)
-        loss, diag, stats = SupConFn.apply(P, labels, pos, float(self._t))
+        loss, diag, stats = SupConFn.apply(P, labels, pos, float(self._t), self._exclude_pos)
         self._last = (P.detach(), stats, labels, pos)
         # device-side evidence for the reference's two checks: one aminmax launch now, the arithmetic in validate()
         mn, mx = torch.aminmax(diag)

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from cyhip import ops
-from cyhip.functions import (AdaptiveAvgPoolFn, ClusterHeadFn, AvgPoolFn, DenseProjHiddenFn, GroupSoftmaxFn, HeadFn, L2NormFn,
+from cyhip.functions import (AdaptiveAvgPoolFn, AdaptiveMaxPoolFn, ClusterHeadFn, AvgPoolFn, DenseProjHiddenFn, GroupSoftmaxFn, HeadFn, L2NormFn,
                              LinearFn, ProjHeadFn)
 
 from .nn import Flatten, Identical, Normalize, SoftmaxWithT
@@ -34,12 +34,13 @@ class ProjectionHead(nn.Module):
         super().__init__()
         assert head_type in ("mlp", "linear"), head_type
         assert pool_name in ("adaptive_avg", "adaptive_max"), pool_name
-        if pool_name != "adaptive_avg" or tuple(spatial_size) != (1, 1):
-            raise NotImplementedError("the HIP projection head implements adaptive_avg pooling to (1, 1), "
-                                      "the only configuration INFONCEHook creates for encoder features")
+        if tuple(_pair(spatial_size)) != (1, 1):
+            # (the reference flattens the pooled map into nn.Linear(input_dim, ...): only (1, 1) has that many features)
+            raise NotImplementedError("ProjectionHead pools to (1, 1): nn.Linear(input_dim, ...) follows the Flatten")
         self._input_dim, self._output_dim = input_dim, output_dim
         self._head_type, self._normalize = head_type, normalize
-        pool = nn.AdaptiveAvgPool2d((1, 1))
+        self._pool_name = pool_name
+        pool = nn.AdaptiveAvgPool2d((1, 1)) if pool_name == "adaptive_avg" else nn.AdaptiveMaxPool2d((1, 1))
         tail = Normalize() if normalize else Identical()
         if head_type == "mlp":
             self._header = nn.Sequential(pool, Flatten(), nn.Linear(input_dim, hidden_dim),
@@ -49,10 +50,10 @@ class ProjectionHead(nn.Module):
 
     def forward(self, features: Tensor) -> Tensor:
         h = self._header
-        if (self._head_type == "mlp" and self._normalize and h[2].bias is not None and h[4].bias is not None
-                and ops.proj_head_ok(features, h[2].weight, h[4].weight)):
+        if (self._pool_name == "adaptive_avg" and self._head_type == "mlp" and self._normalize and h[2].bias is not None
+                and h[4].bias is not None and ops.proj_head_ok(features, h[2].weight, h[4].weight)):
             return ProjHeadFn.apply(features, h[2].weight, h[2].bias, h[4].weight, h[4].bias)  # one launch
-        x = AvgPoolFn.apply(features)
+        x = AvgPoolFn.apply(features) if self._pool_name == "adaptive_avg" else AdaptiveMaxPoolFn.apply(features, (1, 1))
         if self._head_type == "mlp":
             x = LinearFn.apply(x, h[2].weight, h[2].bias, 1, 0.01)
             x = LinearFn.apply(x, h[4].weight, h[4].bias, 0, 0.0)
@@ -79,12 +80,13 @@ class DenseProjectionHead(nn.Module):
         super().__init__()
         assert head_type in ("mlp", "linear"), head_type
         assert pool_name in ("adaptive_avg", "adaptive_max", "identical", "none"), pool_name
-        if pool_name != "adaptive_avg":
-            raise NotImplementedError("the HIP dense projector implements adaptive_avg pooling (the hook's setting)")
+        if pool_name in ("identical", "none", None):
+            raise NotImplementedError("the HIP dense projector pools (adaptive_avg: the hook's setting, or adaptive_max)")
         self._input_dim, self._output_dim = input_dim, output_dim
         self._head_type, self._normalize = head_type, normalize
         self._pool_name, self._spatial_size = pool_name, _pair(spatial_size)
-        self._pooling_module = nn.AdaptiveAvgPool2d(self._spatial_size)
+        self._pooling_module = (nn.AdaptiveAvgPool2d if pool_name == "adaptive_avg" else nn.AdaptiveMaxPool2d)(
+            self._spatial_size)
         if head_type == "mlp":
             self._projector = nn.Sequential(nn.Conv2d(input_dim, hidden_dim, 1, 1, 0),
                                             nn.LeakyReLU(0.01, inplace=True),
@@ -92,8 +94,28 @@ class DenseProjectionHead(nn.Module):
         else:
             self._projector = nn.Sequential(nn.Conv2d(input_dim, output_dim, 1, 1, 0))
 
+    def _rows_max(self, features: Tensor) -> Tensor:
+        """pool_name="adaptive_max": a maximum does not commute with the second 1x1 conv, so the projector runs on every
+        pixel (rows = pixels through the Linear kernels) and the [N, H, W, out] map is max-pooled per bin"""
+        pr = self._projector
+        x = ops.to_nhwc(features)
+        N, Cc, H, W = x.shape
+        rows = x.permute(0, 2, 3, 1).reshape(N * H * W, Cc)
+        if self._head_type == "mlp":
+            rows = LinearFn.apply(rows, pr[0].weight.reshape(pr[0].weight.shape[0], -1), pr[0].bias, 1, 0.01)
+            rows = LinearFn.apply(rows, pr[2].weight.reshape(pr[2].weight.shape[0], -1), pr[2].bias, 0, 0.0)
+        else:
+            rows = LinearFn.apply(rows, pr[0].weight.reshape(pr[0].weight.shape[0], -1), pr[0].bias, 0, 0.0)
+        fmap = rows.view(N, H, W, -1).permute(0, 3, 1, 2)  # NHWC memory
+        pooled = AdaptiveMaxPoolFn.apply(fmap, self._spatial_size)
+        return L2NormFn.apply(pooled) if self._normalize else pooled
+
     def _rows(self, features: Tensor, bins: Optional[Tensor]) -> Tensor:
         pr = self._projector
+        if self._pool_name == "adaptive_max":
+            if bins is not None:
+                raise NotImplementedError("point evaluation is implemented for adaptive_avg pooling")
+            return self._rows_max(features)
         if self._head_type == "mlp":
             hp = DenseProjHiddenFn.apply(features, pr[0].weight, pr[0].bias, self._spatial_size, bins)
             w2 = pr[2].weight.reshape(pr[2].weight.shape[0], -1)

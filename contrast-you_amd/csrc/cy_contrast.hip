@@ -173,6 +173,96 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- SupConLoss1(exclude_other_pos=True), contrastyou/losses/contrastive.py:87-91 --------------------------------------
+// Per positive pair (i, j) the denominator holds that pair and the negatives only, the negatives' sum rescaled by
+// kappa_i = 1 / (neg_i / (pos_i + neg_i) + 1e-4):
+//   loss_i = (1 / c_i) sum_{j in pos_i} [ s_ij - log(e_ij + a_i) ],   a_i = kappa_i sum_{k in neg_i} e_ik + 1e-16,  e = exp(s - M)
+// with M the global maximum (detached, as in the reference).  On the materialised similarity matrix: row maxima from
+// supcon_rowstats_kernel, then one wave per row.  rs[row] = (a_i, c_i, kappa_i T_i / c_i, loss_i), T_i = sum_pos 1 / (e_ij + a_i).
+__global__ void __launch_bounds__(256)
+    supcon_excl_rows_kernel(const float* __restrict__ S, const int32_t* __restrict__ labels,
+                            const uint8_t* __restrict__ pm, const float* __restrict__ tmp, float* __restrict__ rs,
+                            float* __restrict__ Mout, int n) {
+  const int R = 2 * n;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  float M = -INFINITY;
+  for (int i = lane; i < R; i += 64) M = fmaxf(M, tmp[i * 4]);  // (every wave: the row maxima are 4 R bytes)
+  M = wave_max(M);
+  const float* sr = S + (size_t)row * R;
+  float ln = 0.f, cnt = 0.f;
+  for (int j = lane; j < R; j += 64) {
+    if (j == row) continue;
+    if (is_pos(labels, pm, n, row, j)) cnt += 1.f;
+    else ln += expf(sr[j] - M);
+  }
+  ln = wave_sum(ln);
+  cnt = wave_sum(cnt);
+  const float negc = (float)(R - 1) - cnt;
+  const float kappa = 1.f / (negc / (cnt + negc) + 1e-4f);
+  const float ai = ln * kappa + 1e-16f;
+  float T = 0.f, ls = 0.f;
+  for (int j = lane; j < R; j += 64) {
+    if (j == row || !is_pos(labels, pm, n, row, j)) continue;
+    const float sm = sr[j] - M;
+    const float d = expf(sm) + ai;
+    T += 1.f / d;
+    ls += sm - logf(d);
+  }
+  T = wave_sum(T);
+  ls = wave_sum(ls);
+  if (lane == 0) {
+    rs[row * 4 + 0] = ai;
+    rs[row * 4 + 1] = cnt;
+    rs[row * 4 + 2] = kappa * T / cnt;
+    rs[row * 4 + 3] = ls / cnt;  // cnt == 0 -> NaN like the reference
+    if (row == 0) Mout[0] = M;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    supcon_excl_loss_kernel(float* __restrict__ rs, float* __restrict__ loss, const float* __restrict__ Mptr, int R) {
+  __shared__ double ssum[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < R; i += 256) acc += (double)rs[i * 4 + 3];
+  ssum[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) ssum[threadIdx.x] += ssum[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss[0] = (float)(-ssum[0] / (double)R);
+    rs[3] = Mptr[0];  // (where cy_supcon_matrices looks for the shift; row 0's loss term has been summed)
+  }
+}
+
+// G + G^T with G_ij = -(g/R) d loss_i / d s_ij:  pos: (1/c_i) a_i / (e_ij + a_i);  neg: -e_ij kappa_i T_i / c_i
+__global__ void __launch_bounds__(256)
+    supcon_excl_gsym_kernel(const float* __restrict__ S, const float* __restrict__ rs, const float* __restrict__ Mptr,
+                            const int32_t* __restrict__ labels, const uint8_t* __restrict__ pm,
+                            const float* __restrict__ gscale, float* __restrict__ G, int n) {
+  const int R = 2 * n;
+  const long total = (long)R * R;
+  const float gs = gscale[0] / (float)R;
+  const float M = Mptr[0];
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const int i = (int)(e / R), j = (int)(e % R);
+    float v = 0.f;
+    if (i != j) {
+      const float eij = expf(S[e] - M);
+      if (is_pos(labels, pm, n, i, j)) {
+        const float ai = rs[i * 4 + 0], aj = rs[j * 4 + 0];
+        v = -gs * (ai / ((eij + ai) * rs[i * 4 + 1]) + aj / ((eij + aj) * rs[j * 4 + 1]));
+      } else {
+        v = gs * eij * (rs[i * 4 + 2] + rs[j * 4 + 2]);
+      }
+    }
+    G[e] = v;
+  }
+}
+
 __global__ void __launch_bounds__(256)
     supcon_matrices_kernel(const float* __restrict__ S, const float* __restrict__ rs,
                            const int32_t* __restrict__ labels, const uint8_t* __restrict__ pm,
@@ -885,6 +975,37 @@ int cy_supcon_bwd(const float* P, const int32_t* labels, const uint8_t* pos_mask
   const int R = 2 * n;
   hipLaunchKernelGGL(supcon_gsym_kernel, dim3(grid_for((long)R * R)), dim3(256), 0, st, S,
                      row_stats, labels, pos_mask, gscale, G, n);
+  CY_CHECK_LAUNCH();
+  return launch_sgemm(G, P, dP, R, D, R, 1.f / t, 0, st);
+}
+
+int cy_supcon_excl_fwd(const float* P, const int32_t* labels, const uint8_t* pos_mask, float* S, float* loss,
+                       float* row_stats, float* tmp, int n, int D, float t, void* stream) {
+  if (!P || (!labels && !pos_mask) || !S || !loss || !row_stats || !tmp) return CY_ERR_ARG;
+  if (n <= 0 || D <= 0 || !(t > 0.f)) return CY_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int R = 2 * n;
+  int rc = launch_sgemm(P, P, S, R, R, D, 1.f / t, 1, st);
+  if (rc != CY_OK) return rc;
+  hipLaunchKernelGGL(supcon_rowstats_kernel, dim3(cy_cdiv(R, 4)), dim3(256), 0, st, S, labels, pos_mask, tmp, n);
+  CY_CHECK_LAUNCH();
+  hipLaunchKernelGGL(supcon_excl_rows_kernel, dim3(cy_cdiv(R, 4)), dim3(256), 0, st, S, labels, pos_mask, (const float*)tmp,
+                     row_stats, tmp + (size_t)4 * R, n);
+  CY_CHECK_LAUNCH();
+  hipLaunchKernelGGL(supcon_excl_loss_kernel, dim3(1), dim3(256), 0, st, row_stats, loss, (const float*)(tmp + (size_t)4 * R), R);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_supcon_excl_bwd(const float* P, const int32_t* labels, const uint8_t* pos_mask, const float* S,
+                       const float* row_stats, const float* tmp, const float* gscale, float* G, float* dP, int n, int D,
+                       float t, void* stream) {
+  if (!P || (!labels && !pos_mask) || !S || !row_stats || !tmp || !gscale || !G || !dP) return CY_ERR_ARG;
+  if (n <= 0 || D <= 0 || !(t > 0.f)) return CY_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int R = 2 * n;
+  hipLaunchKernelGGL(supcon_excl_gsym_kernel, dim3(grid_for((long)R * R)), dim3(256), 0, st, S, row_stats,
+                     tmp + (size_t)4 * R, labels, pos_mask, gscale, G, n);
   CY_CHECK_LAUNCH();
   return launch_sgemm(G, P, dP, R, D, R, 1.f / t, 0, st);
 }

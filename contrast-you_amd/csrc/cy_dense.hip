@@ -314,6 +314,60 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---------------------------------------------------------------- adaptive max pool (nn.AdaptiveMaxPool2d, projectors/nn.py:16-23)
+// out[bin][c] = max over the bin (torch's bin boundaries: bin_rect), arg = pixel index inside the image of the FIRST
+// maximum in row-major order (torch's `val > max` scan); a NaN wins like in torch
+template <typename T>
+__global__ void __launch_bounds__(256)
+    adaptive_maxpool_fwd_kernel(const T* __restrict__ x, float* __restrict__ out, int32_t* __restrict__ arg, int H,
+                                int W, int C, int ldx, int sh, int sw) {
+  const BinRect R = bin_rect(nullptr, blockIdx.x, sh, sw, H, W);
+  const int bw = R.c1 - R.c0, npx = (R.r1 - R.r0) * bw;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float best = -INFINITY;
+    int bi = -1;
+    for (int q = 0; q < npx; ++q) {
+      const size_t px = bin_pixel(R, q, bw, H, W);
+      const float v = to_f32<T>(x[px * ldx + c]);
+      if (bi < 0 || v > best || v != v) {
+        if (!(best != best)) best = v, bi = (int)(px % ((size_t)H * W));  // (a NaN already held stays)
+      }
+    }
+    out[(size_t)blockIdx.x * C + c] = best;
+    arg[(size_t)blockIdx.x * C + c] = bi;
+  }
+}
+
+// gather form: dx[n,r,c,:] = sum over the <= 3 x 3 bins containing (r, c) of dpool where that bin's arg-max is (r, c)
+template <typename T>
+__global__ void __launch_bounds__(256)
+    adaptive_maxpool_bwd_kernel(const float* __restrict__ dpool, const int32_t* __restrict__ arg, T* __restrict__ dx,
+                                int N, int H, int W, int C, int ldx, int sh, int sw) {
+  const long total = (long)N * H * W * C;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const int c = (int)(e % C);
+    const long pix = e / C;
+    const int w = (int)(pix % W);
+    const long t = pix / W;
+    const int h = (int)(t % H), n = (int)(t / H);
+    const int me = h * W + w;
+    float s = 0.f;
+    const int i_hi = min(sh - 1, (int)(((long)(h + 1) * sh - 1) / H));
+    const int j_hi = min(sw - 1, (int)(((long)(w + 1) * sw - 1) / W));
+    for (int i = max(0, i_hi - 2); i <= i_hi; ++i) {
+      const int r0 = (i * H) / sh, r1 = ((i + 1) * H + sh - 1) / sh;
+      if (h < r0 || h >= r1) continue;
+      for (int j = max(0, j_hi - 2); j <= j_hi; ++j) {
+        const int c0 = (j * W) / sw, c1 = ((j + 1) * W + sw - 1) / sw;
+        if (w < c0 || w >= c1) continue;
+        const size_t b = (((size_t)n * sh + i) * sw + j) * C + c;
+        if (arg[b] == me) s += dpool[b];
+      }
+    }
+    dx[pix * ldx + c] = from_f32<T>(s);
+  }
+}
+
 // ---------------------------------------------------------------- row gather / scatter
 __global__ void __launch_bounds__(256)
     gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
@@ -480,6 +534,42 @@ int cy_adaptive_avgpool_bwd(const float* dpool, void* dx, int N, int H, int W, i
                        (float*)dx, N, H, W, C, ldx, sh, sw);
   else
     return CY_ERR_DTYPE;
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_adaptive_maxpool_fwd(const void* x, float* out, int32_t* arg, int N, int H, int W, int C, int ldx, int sh,
+                            int sw, int dtype, void* stream) {
+  if (!x || !out || !arg || N <= 0) return CY_ERR_ARG;
+  if (ldx < C || sh <= 0 || sw <= 0 || sh > H || sw > W) return CY_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = N * sh * sw;
+#define CY_AMP(TT)                                                                                             \
+  hipLaunchKernelGGL(adaptive_maxpool_fwd_kernel<TT>, dim3(nb), dim3(256), 0, st, (const TT*)x, out, arg, H, W, \
+                     C, ldx, sh, sw)
+  if (dtype == CY_BF16) CY_AMP(bf16);
+  else if (dtype == CY_F16) CY_AMP(f16);
+  else if (dtype == CY_F32) CY_AMP(float);
+  else return CY_ERR_DTYPE;
+#undef CY_AMP
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_adaptive_maxpool_bwd(const float* dpool, const int32_t* arg, void* dx, int N, int H, int W, int C, int ldx,
+                            int sh, int sw, int dtype, void* stream) {
+  if (!dpool || !arg || !dx || N <= 0) return CY_ERR_ARG;
+  if (ldx < C || sh <= 0 || sw <= 0 || sh > H || sw > W) return CY_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for((long)N * H * W * C);
+#define CY_AMP(TT)                                                                                              \
+  hipLaunchKernelGGL(adaptive_maxpool_bwd_kernel<TT>, dim3(grid), dim3(256), 0, st, dpool, arg, (TT*)dx, N, H, W, \
+                     C, ldx, sh, sw)
+  if (dtype == CY_BF16) CY_AMP(bf16);
+  else if (dtype == CY_F16) CY_AMP(f16);
+  else if (dtype == CY_F32) CY_AMP(float);
+  else return CY_ERR_DTYPE;
+#undef CY_AMP
   CY_CHECK_LAUNCH();
   return CY_OK;
 }

@@ -178,6 +178,8 @@ _SIGS = {
     "cy_l2norm_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "cy_supcon_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "cy_supcon_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "cy_supcon_excl_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "cy_supcon_excl_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "cy_supcon_fused_ws_bytes": (c_size_t, [c_int, c_int]),
     "cy_supcon_fused_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_float, _P]),
     "cy_supcon_fused_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_float, _P]),
@@ -198,6 +200,8 @@ _SIGS = {
                           [c_float, c_int, _P, c_size_t, _P]),
     "cy_adaptive_avgpool_fwd": (c_int, [_P, _P, c_int, _P] + [c_int] * 8 + [_P]),
     "cy_adaptive_avgpool_bwd": (c_int, [_P, _P] + [c_int] * 8 + [_P]),
+    "cy_adaptive_maxpool_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cy_adaptive_maxpool_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cy_gather_rows_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "cy_gather_rows_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "cy_cluster_head_fwd": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, c_int, c_int, c_float, c_int, _P]),

@@ -705,11 +705,16 @@ class SupConFn(torch.autograd.Function):
     statistics; for D <= 256 the 2n x 2n matrix itself exists only tile-wise inside the kernels."""
 
     @staticmethod
-    def forward(ctx, P: Tensor, labels: Optional[Tensor], pos_mask: Optional[Tensor], t: float):
+    def forward(ctx, P: Tensor, labels: Optional[Tensor], pos_mask: Optional[Tensor], t: float, exclude_pos: bool = False):
         ops.require_gpu(P)
         P = P.float().contiguous()
-        ctx.fused = ops.supcon_fused_ok(P)
-        if ctx.fused:
+        ctx.excl = bool(exclude_pos)
+        ctx.fused = ops.supcon_fused_ok(P) and not ctx.excl
+        if ctx.excl:  # exclude_other_pos=True (contrastive.py:87-91): on the materialised matrix
+            loss, S, stats, tmp = ops.supcon_excl_fwd(P, labels, pos_mask, t)
+            diag = S.diagonal().clone()
+            ctx.save_for_backward(P, stats, S, tmp)
+        elif ctx.fused:
             loss, diag, stats = ops.supcon_fwd_fused(P, labels, pos_mask, t)
             ctx.save_for_backward(P, stats)
         else:
@@ -723,11 +728,14 @@ class SupConFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g: Tensor, _gd, _gstats):
         gs = g.reshape(1).float().contiguous()
+        if ctx.excl:
+            P, stats, S, tmp = ctx.saved_tensors
+            return ops.supcon_excl_bwd(P, ctx.labels, ctx.pos_mask, S, stats, tmp, gs, ctx.t), None, None, None, None
         if ctx.fused:
             P, stats = ctx.saved_tensors
-            return ops.supcon_bwd_fused(P, ctx.labels, ctx.pos_mask, stats, gs, ctx.t), None, None, None
+            return ops.supcon_bwd_fused(P, ctx.labels, ctx.pos_mask, stats, gs, ctx.t), None, None, None, None
         P, stats, S = ctx.saved_tensors
-        return ops.supcon_bwd(P, ctx.labels, ctx.pos_mask, S, stats, gs, ctx.t), None, None, None
+        return ops.supcon_bwd(P, ctx.labels, ctx.pos_mask, S, stats, gs, ctx.t), None, None, None, None
 
 
 class AffineFn(torch.autograd.Function):
@@ -794,6 +802,27 @@ class AdaptiveAvgPoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g: Tensor):
         return ops.adaptive_avgpool_bwd(g.float().contiguous(), ctx.shape, ctx.dtype, ctx.size), None
+
+
+class AdaptiveMaxPoolFn(torch.autograd.Function):
+    """nn.AdaptiveMaxPool2d(size) on an NHWC map -> f32 rows [N*sh*sw, C] (contrastyou/projectors/nn.py:16-23,
+    pool_name="adaptive_max")"""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, size):
+        ops.require_gpu(x)
+        x = ops.to_nhwc(x)
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            x = x.float()
+        ctx.shape, ctx.dtype, ctx.size = tuple(x.shape), x.dtype, tuple(size)
+        out, arg = ops.adaptive_maxpool_fwd(x, ctx.size)
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (arg,) = ctx.saved_tensors
+        return ops.adaptive_maxpool_bwd(g.float().contiguous(), arg, ctx.shape, ctx.dtype, ctx.size), None
 
 
 class GatherRowsFn(torch.autograd.Function):

@@ -1417,6 +1417,27 @@ def supcon_bwd(P: Tensor, labels, pos_mask, S: Tensor, stats: Tensor, gscale: Te
     return dP
 
 
+def supcon_excl_fwd(P: Tensor, labels: Optional[Tensor], pos_mask: Optional[Tensor], t: float):
+    """SupConLoss1(exclude_other_pos=True): (loss, S, row statistics, tmp) on the materialised similarity matrix"""
+    R, D = P.shape
+    S = _f32(R * R, P.device).view(R, R)
+    stats = _f32(R * 4, P.device).view(R, 4)
+    tmp = _f32(R * 4 + 1, P.device)
+    loss = _f32(1, P.device)
+    _lib.call("cy_supcon_excl_fwd", P.data_ptr(), _ptr(labels), _ptr(pos_mask), S.data_ptr(), loss.data_ptr(),
+              stats.data_ptr(), tmp.data_ptr(), R // 2, D, float(t), _stream())
+    return loss.view(()), S, stats, tmp
+
+
+def supcon_excl_bwd(P: Tensor, labels, pos_mask, S: Tensor, stats: Tensor, tmp: Tensor, gscale: Tensor, t: float) -> Tensor:
+    R, D = P.shape
+    G = _f32(R * R, P.device)
+    dP = torch.empty_like(P)
+    _lib.call("cy_supcon_excl_bwd", P.data_ptr(), _ptr(labels), _ptr(pos_mask), S.data_ptr(), stats.data_ptr(),
+              tmp.data_ptr(), gscale.data_ptr(), G.data_ptr(), dP.data_ptr(), R // 2, D, float(t), _stream())
+    return dP
+
+
 SUPCON_FUSED = os.environ.get("CY_SUPCON_FUSED", "1") != "0"
 
 
@@ -1554,6 +1575,26 @@ def adaptive_avgpool_bwd(dpool: Tensor, shape, dtype, size: Tuple[int, int]) -> 
     dx = empty_nhwc(N, Cc, H, W, dtype, dpool.device)
     _lib.call("cy_adaptive_avgpool_bwd", dpool.data_ptr(), dx.data_ptr(), N, H, W, Cc, Cc, size[0], size[1],
               dtype_code(dtype), _stream())
+    return dx
+
+
+def adaptive_maxpool_fwd(x: Tensor, size: Tuple[int, int]):
+    """nn.AdaptiveMaxPool2d(size) on an NHWC map -> (rows [N*sh*sw, C] f32, arg-max pixel indices int32)"""
+    require_gpu(x)
+    N, Cc, H, W = x.shape
+    nb = N * size[0] * size[1]
+    out = _f32(nb * Cc, x.device).view(nb, Cc)
+    arg = torch.empty((nb, Cc), dtype=torch.int32, device=x.device)
+    _lib.call("cy_adaptive_maxpool_fwd", x.data_ptr(), out.data_ptr(), arg.data_ptr(), N, H, W, Cc, Cc, size[0], size[1],
+              dtype_code(x.dtype), _stream())
+    return out, arg
+
+
+def adaptive_maxpool_bwd(dpool: Tensor, arg: Tensor, shape, dtype, size: Tuple[int, int]) -> Tensor:
+    N, Cc, H, W = shape
+    dx = empty_nhwc(N, Cc, H, W, dtype, dpool.device)
+    _lib.call("cy_adaptive_maxpool_bwd", dpool.data_ptr(), arg.data_ptr(), dx.data_ptr(), N, H, W, Cc, Cc, size[0],
+              size[1], dtype_code(dtype), _stream())
     return dx
 
 

@@ -461,6 +461,14 @@ int cy_supcon_fwd(const float* P, const int32_t* labels, const uint8_t* pos_mask
 int cy_supcon_bwd(const float* P, const int32_t* labels, const uint8_t* pos_mask, const float* S,
                   const float* row_stats, const float* gscale, float* G, float* dP, int n, int D,
                   float t, void* stream);
+/* SupConLoss1(exclude_other_pos=True) (losses/contrastive.py:87-91): per positive pair the denominator holds that pair and
+ * the negatives only, the negatives' sum rescaled by 1 / (neg / (pos + neg) + 1e-4).  On the materialised similarity
+ * matrix S [2n][2n]; row_stats [2n][4] and tmp [4 * 2n + 1] are kept for the backward (tmp[8n] = the global maximum). */
+int cy_supcon_excl_fwd(const float* P, const int32_t* labels, const uint8_t* pos_mask, float* S, float* loss,
+                       float* row_stats, float* tmp, int n, int D, float t, void* stream);
+int cy_supcon_excl_bwd(const float* P, const int32_t* labels, const uint8_t* pos_mask, const float* S,
+                       const float* row_stats, const float* tmp, const float* gscale, float* G, float* dP, int n, int D,
+                       float t, void* stream);
 /* materialise sim_logits (S-M), sim_exp, pos_mask, neg_mask, each f32 [R][R]
  * (contrastive.py:79-82; read only for the TensorBoard figures). any may be NULL */
 /* The same loss and gradient with S (and the gradient matrix) formed tile by tile in the MFMA accumulators and
@@ -560,6 +568,13 @@ int cy_dense_proj_bwd(const void* x, const float* w1, const float* b1, const int
 int cy_adaptive_avgpool_fwd(const void* x, const int32_t* bins, int nb, float* out, int N, int H,
                             int W, int C, int ldx, int sh, int sw, int dtype, void* stream);
 int cy_adaptive_avgpool_bwd(const float* dpool, void* dx, int N, int H, int W, int C, int ldx,
+                            int sh, int sw, int dtype, void* stream);
+/* nn.AdaptiveMaxPool2d(size) (projectors/nn.py:16-23: pool_name="adaptive_max" of both projection heads) on an NHWC map:
+ * out [N*sh*sw][C] f32 and arg [N*sh*sw][C] = pixel index (inside the image) of the first maximum in row-major order;
+ * backward in gather form (bins may overlap: deterministic, no atomics). */
+int cy_adaptive_maxpool_fwd(const void* x, float* out, int32_t* arg, int N, int H, int W, int C, int ldx, int sh,
+                            int sw, int dtype, void* stream);
+int cy_adaptive_maxpool_bwd(const float* dpool, const int32_t* arg, void* dx, int N, int H, int W, int C, int ldx,
                             int sh, int sw, int dtype, void* stream);
 /* out[m][:] = src[idx[m]][:] (f32 rows of length D); backward scatters rows
  * (idx distinct). */

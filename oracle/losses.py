@@ -38,11 +38,12 @@ def softmax_mse(a: Tensor, b: Tensor) -> Tensor:
 
 
 # ---------------------------------------------------------------- projection heads
-def projection_head(sd: Dict[str, Tensor], feat: Tensor, normalize: bool = True) -> Tensor:
+def projection_head(sd: Dict[str, Tensor], feat: Tensor, normalize: bool = True, pool: str = "adaptive_avg") -> Tensor:
     """contrastyou/projectors/heads.py:14-22 (head_type='mlp'):
     AdaptiveAvgPool2d(1) -> Flatten -> Linear -> LeakyReLU(0.01) -> Linear -> F.normalize(dim=1)
+    (pool="adaptive_max": nn.AdaptiveMaxPool2d(1) instead, projectors/nn.py:16-23)
     sd keys: '_header.2.weight/bias', '_header.4.weight/bias' (nn.Sequential indices)."""
-    x = feat.mean(dim=(2, 3))
+    x = feat.mean(dim=(2, 3)) if pool == "adaptive_avg" else feat.amax(dim=(2, 3))
     x = F.linear(x, sd["_header.2.weight"], sd["_header.2.bias"])
     x = F.leaky_relu(x, 0.01)
     x = F.linear(x, sd["_header.4.weight"], sd["_header.4.bias"])
@@ -50,13 +51,13 @@ def projection_head(sd: Dict[str, Tensor], feat: Tensor, normalize: bool = True)
 
 
 def dense_projection_head(sd: Dict[str, Tensor], feat: Tensor, spatial_size: Sequence[int],
-                          normalize: bool = True) -> Tensor:
+                          normalize: bool = True, pool: str = "adaptive_avg") -> Tensor:
     """contrastyou/projectors/heads.py:33-38,112-119: conv1x1 -> LeakyReLU -> conv1x1 ->
-    AdaptiveAvgPool2d(spatial_size) -> F.normalize over channels."""
+    AdaptiveAvgPool2d(spatial_size) (or AdaptiveMaxPool2d, pool="adaptive_max") -> F.normalize over channels."""
     x = F.conv2d(feat, sd["_projector.0.weight"], sd["_projector.0.bias"])
     x = F.leaky_relu(x, 0.01)
     x = F.conv2d(x, sd["_projector.2.weight"], sd["_projector.2.bias"])
-    x = F.adaptive_avg_pool2d(x, tuple(spatial_size))
+    x = (F.adaptive_avg_pool2d if pool == "adaptive_avg" else F.adaptive_max_pool2d)(x, tuple(spatial_size))
     return F.normalize(x, p=2, dim=1) if normalize else x
 
 
@@ -74,6 +75,25 @@ def supcon_masks(n: int, target: Optional[Sequence[int]] = None, mask: Optional[
     neg = 1 - pos
     off = 1 - torch.eye(2 * n)
     return pos.repeat(2, 2) * off, neg.repeat(2, 2) * off
+
+
+def supcon_loss_exclude_pos(z1: Tensor, z2: Tensor, target: Optional[Sequence[int]] = None,
+                            mask: Optional[Tensor] = None, t: float = 0.07) -> Tensor:
+    """SupConLoss1(exclude_other_pos=True) (contrastive.py:84-91): per positive pair the denominator holds that pair and
+    the negatives, the negatives' sum divided by (neg / (pos + neg) + 1e-4):
+    loss = -mean_i[ sum_j pos_ij (S_ij - log(E_ij + negsum_i / (negratio_i + 1e-4) + 1e-16)) / sum_j pos_ij ]"""
+    n = z1.shape[0]
+    pos, neg = supcon_masks(n, target, mask)
+    pos, neg = pos.to(z1), neg.to(z1)
+    P = torch.cat([z1, z2], dim=0)
+    S = P @ P.t() / t
+    S = S - S.max().detach()
+    E = torch.exp(S)
+    pos_count, neg_count = pos.sum(1), neg.sum(1)
+    neg_sum = (E * neg).sum(1, keepdim=True)
+    ratio = (neg_count / (pos_count + neg_count))[:, None]
+    log_ratio = S - torch.log(E + neg_sum / (ratio + 1e-4) + 1e-16)
+    return -((log_ratio * pos).sum(1) / pos_count).mean()
 
 
 def supcon_loss(z1: Tensor, z2: Tensor, target: Optional[Sequence[int]] = None,

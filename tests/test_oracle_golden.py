@@ -271,3 +271,28 @@ def test_self_paced_supcon_with_ignore_mask_matches_reference(golden_dir):
         assert abs(ratio - float(g[f"spm_{mode}_ratio"])) < 1e-6
         close(a.grad, g[f"spm_{mode}_dz1"], rtol=1e-4, atol=1e-6)
         close(b.grad, g[f"spm_{mode}_dz2"], rtol=1e-4, atol=1e-6)
+
+
+def test_round4_option_gaps_oracle_vs_reference(golden_dir):
+    """SupConLoss1(exclude_other_pos=True) and the adaptive_max pooling of both projection heads: the oracle's
+    restatements against the reference's own outputs and gradients (tests/golden/round4.npz)"""
+    import numpy as np
+    from oracle import losses as ol
+    g = np.load(golden_dir / "round4.npz")
+    z1 = torch.from_numpy(g["x_z1"]).requires_grad_(True)
+    z2 = torch.from_numpy(g["x_z2"]).requires_grad_(True)
+    loss = ol.supcon_loss_exclude_pos(z1, z2, target=g["x_target"].tolist())
+    loss.backward()
+    assert abs(loss.item() - float(g["x_loss"])) < 1e-6
+    assert np.allclose(z1.grad.numpy(), g["x_dz1"], atol=1e-6) and np.allclose(z2.grad.numpy(), g["x_dz2"], atol=1e-6)
+    z1.grad = z2.grad = None
+    loss = ol.supcon_loss_exclude_pos(z1, z2, mask=torch.from_numpy(g["x_mask"]))
+    loss.backward()
+    assert abs(loss.item() - float(g["x_mask_loss"])) < 1e-6
+    assert np.allclose(z1.grad.numpy(), g["x_mask_dz1"], atol=1e-6)
+    psd = ol.init_projector_sd(64, 128, 96, seed=5)
+    z = ol.projection_head(psd, torch.from_numpy(g["pm_feat"]), pool="adaptive_max")
+    assert np.allclose(z.numpy(), g["pm_z"], atol=1e-6)
+    dsd = ol.init_dense_projector_sd(16, 32, 24, seed=6)
+    dz = ol.dense_projection_head(dsd, torch.from_numpy(g["dm_feat"]), (4, 4), pool="adaptive_max")
+    assert np.allclose(dz.numpy(), g["dm_z"], atol=1e-6)
