@@ -110,12 +110,20 @@ __device__ __forceinline__ void bn_acc_gather_direct(const unsigned long long* a
   __syncthreads();
 }
 
+// WIDE (the elementwise kernels, which have the registers): 16 and 32 replicas the same way -- the LDS-atomic form
+// below costs a workgroup R * 4 * C 64-bit LDS atomics (8192 at R = 32), 5-13 us of every such launch on cold data
+// (tools/bench_ew_cold.py) with four workgroups per CU queueing at one LDS
+template <bool WIDE = false>
 __device__ __forceinline__ void bn_acc_gather(const unsigned long long* acc, int R, int C, unsigned long long* s_sum,
                                               int tid, int nthr) {
   if (R == 1) return bn_acc_gather_direct<1>(acc, C, s_sum, tid, nthr);
   if (R == 2) return bn_acc_gather_direct<2>(acc, C, s_sum, tid, nthr);
   if (R == 4) return bn_acc_gather_direct<4>(acc, C, s_sum, tid, nthr);
   if (R == 8) return bn_acc_gather_direct<8>(acc, C, s_sum, tid, nthr);
+  if constexpr (WIDE) {
+    if (R == 16) return bn_acc_gather_direct<16>(acc, C, s_sum, tid, nthr);
+    if (R == 32) return bn_acc_gather_direct<32>(acc, C, s_sum, tid, nthr);
+  }
   const int row = 4 * C;
   for (int i = tid; i <= row; i += nthr) s_sum[i] = 0ull;
   __syncthreads();
@@ -154,12 +162,19 @@ __device__ __forceinline__ void bn_fold_channel_lds(const BnFold& f, const unsig
                                                     float& sc, float& sh) {
   bn_fold_finish(f, c, leader, bn_sum_read(s_sum, f.C, 0, c), bn_sum_read(s_sum, f.C, 1, c), sc, sh);
 }
+// (g, b: gamma[c] and beta[c], which a caller with registers to spare requests BEFORE the gather -- read here they are one
+//  more dependent round trip to memory in a prologue that is nothing but such round trips)
+__device__ __forceinline__ void bn_fold_finish_gb(const BnFold& f, int c, bool leader, double s1, double s2, double g, double b,
+                                                  float& sc, float& sh);
 __device__ __forceinline__ void bn_fold_finish(const BnFold& f, int c, bool leader, double s1, double s2, float& sc, float& sh) {
+  bn_fold_finish_gb(f, c, leader, s1, s2, f.gamma ? (double)f.gamma[c] : 1.0, f.beta ? (double)f.beta[c] : 0.0, sc, sh);
+}
+__device__ __forceinline__ void bn_fold_finish_gb(const BnFold& f, int c, bool leader, double s1, double s2, double g, double b,
+                                                  float& sc, float& sh) {
   const double mean = s1 * f.inv_count;
   double var = s2 * f.inv_count - mean * mean;
   if (var < 0.0) var = 0.0;
   const double istd = bn_rsqrt(var + (double)f.eps);
-  const double g = f.gamma ? (double)f.gamma[c] : 1.0, b = f.beta ? (double)f.beta[c] : 0.0;
   sc = (float)(g * istd);
   sh = (float)(b - mean * g * istd);
   if (leader && f.coef) {
@@ -173,21 +188,34 @@ __device__ __forceinline__ void bn_fold_finish(const BnFold& f, int c, bool lead
 
 // backward coefficients of channel c: dy = scale * dz + k1 * y + k0; the leader adds the parameter gradients
 // (after bn_acc_gather(f.acc, f.R, f.C, s_sum, ...))
-__device__ __forceinline__ void bn_bwd_fold_channel(const BnBwdFold& f, const unsigned long long* s_sum, int c, bool leader,
-                                                    float& k1o, float& k0o) {
+// (sc, mu, is: rows 0, 2, 3 of the forward coefficients at c; dg_old, db_old: the leader's current gradient words when it
+//  accumulates -- all requested by the caller before the gather, see bn_fold_finish_gb)
+__device__ __forceinline__ void bn_bwd_fold_finish(const BnBwdFold& f, const unsigned long long* s_sum, int c, bool leader,
+                                                   float sc_, float mu_, float is_, float dg_old, float db_old, float& k1o,
+                                                   float& k0o) {
   const double t1 = bn_sum_read(s_sum, f.C, 0, c), t2 = bn_sum_read(s_sum, f.C, 1, c);
   double k1 = 0.0, k0 = 0.0;
   if (f.batch_stats) {
-    const double sc = (double)f.coef[c], mu = (double)f.coef[2 * f.C + c], is = (double)f.coef[3 * f.C + c];
+    const double sc = (double)sc_, mu = (double)mu_, is = (double)is_;
     k1 = -sc * is * t2 * f.inv_count;
     k0 = -sc * t1 * f.inv_count - k1 * mu;
   }
   k1o = (float)k1;
   k0o = (float)k0;
   if (leader) {
-    if (f.dbeta) f.dbeta[c] = f.accumulate ? f.dbeta[c] + (float)t1 : (float)t1;
-    if (f.dgamma) f.dgamma[c] = f.accumulate ? f.dgamma[c] + (float)t2 : (float)t2;
+    if (f.dbeta) f.dbeta[c] = f.accumulate ? db_old + (float)t1 : (float)t1;
+    if (f.dgamma) f.dgamma[c] = f.accumulate ? dg_old + (float)t2 : (float)t2;
   }
+}
+__device__ __forceinline__ void bn_bwd_fold_channel(const BnBwdFold& f, const unsigned long long* s_sum, int c, bool leader,
+                                                    float& k1o, float& k0o) {
+  float sc = 0.f, mu = 0.f, is = 0.f, dg = 0.f, db = 0.f;
+  if (f.batch_stats) sc = f.coef[c], mu = f.coef[2 * f.C + c], is = f.coef[3 * f.C + c];
+  if (leader && f.accumulate) {
+    if (f.dbeta) db = f.dbeta[c];
+    if (f.dgamma) dg = f.dgamma[c];
+  }
+  bn_bwd_fold_finish(f, s_sum, c, leader, sc, mu, is, dg, db, k1o, k0o);
 }
 #endif
 

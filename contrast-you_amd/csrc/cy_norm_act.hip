@@ -79,14 +79,22 @@ __global__ void __launch_bounds__(1024)
 // FOLD (cy_bn_acc.h): the coefficients are derived from the producing conv's accumulator by every workgroup (one channel
 // per thread, through LDS); workgroup 0 leaves them in memory for the backward pass.  The host keeps the grid small
 // enough that the accumulator reads (R * C * 32 bytes per workgroup, from L2) stay a small share of the tensor traffic.
+// threads of a workgroup of the elementwise kernels: the folding forms run 1024 (a quarter of the workgroups, i.e. of the
+// accumulator gathers -- R * C * 32 bytes each, through one L2 -- and a gather that is one round trip: tools/bench_ew_cold.py)
+template <bool FOLD> constexpr int ew_threads() { return FOLD ? 1024 : 256; }
+
 template <bool FOLD>
 __device__ __forceinline__ void bn_fold_table(const BnFold& f, float* s_coef) {
   if constexpr (FOLD) {
+    constexpr int NT = ew_threads<FOLD>();
     unsigned long long* s_sum = reinterpret_cast<unsigned long long*>(s_coef + 2 * f.C);  // [4 C + 1] (host: C % 8 == 0)
-    bn_acc_gather(f.acc, f.R, f.C, s_sum, threadIdx.x, 256);
-    for (int c = threadIdx.x; c < f.C; c += 256) {
+    const int c = threadIdx.x;  // (host: C <= 1024 = NT)  gamma / beta requested ahead of the gather
+    const float pg = (c < f.C && f.gamma) ? f.gamma[c] : 1.f, pb = (c < f.C && f.beta) ? f.beta[c] : 0.f;
+    bn_acc_gather<true>(f.acc, f.R, f.C, s_sum, threadIdx.x, NT);
+    if (c < f.C) {
       float a, b;
-      bn_fold_channel_lds(f, s_sum, c, blockIdx.x == 0, a, b);
+      bn_fold_finish_gb(f, c, blockIdx.x == 0, bn_sum_read(s_sum, f.C, 0, c), bn_sum_read(s_sum, f.C, 1, c), (double)pg,
+                        (double)pb, a, b);
       s_coef[c] = a;
       s_coef[f.C + c] = b;
     }
@@ -95,17 +103,18 @@ __device__ __forceinline__ void bn_fold_table(const BnFold& f, float* s_coef) {
 }
 
 template <typename TI, typename TO, bool FOLD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(ew_threads<FOLD>())
     bn_relu_apply_kernel(const TI* __restrict__ y, const float* __restrict__ scale,
                          const float* __restrict__ shift, TO* __restrict__ out, long npix, int C, const BnFold fold) {
   extern __shared__ __attribute__((aligned(16))) float s_coef[];  // FOLD: [2][C] floats, then [4 C + 1] 64-bit sums
   // unit of work: 8 channels of one pixel (one 16-byte bf16 chunk / two f32 chunks).  The item after the current one
   // is always in flight; the FIRST one is requested before the coefficients are derived (FOLD: the accumulator's round
   // trip and the data's overlap -- on the small maps the kernel is nothing but that chain of latencies).
+  constexpr long NT = ew_threads<FOLD>();
   const int G = C / 8;
   const long total = npix * G;
-  const long stride = (long)gridDim.x * 256L;
-  long i = blockIdx.x * 256L + threadIdx.x;
+  const long stride = (long)gridDim.x * NT;
+  long i = blockIdx.x * NT + threadIdx.x;
   u32x4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
   auto request = [&](long idx) {
     const int g = (int)(idx % G);
@@ -156,7 +165,7 @@ __global__ void __launch_bounds__(256)
 // the writes and lets the next block's first conv (and its weight gradient) read a plain tensor -- i.e. run on the
 // DMA-fed kernels, which cannot take a maximum on load.
 template <typename TI, typename TO, bool FOLD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(ew_threads<FOLD>())
     bn_relu_apply_pool_kernel(const TI* __restrict__ y, const float* __restrict__ scale,
                               const float* __restrict__ shift, TO* __restrict__ out, TO* __restrict__ pooled,
                               int N, int H, int W, int C, const BnFold fold) {
@@ -165,7 +174,8 @@ __global__ void __launch_bounds__(256)
   const int G = C / 8;
   const long total = (long)N * H * W * G;
   const int W2 = 2 * W;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+  constexpr long NT = ew_threads<FOLD>();
+  for (long i = blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
     const int g = (int)(i % G);
     long p = i / G;
     const int w = (int)(p % W);
@@ -397,7 +407,7 @@ __global__ void __launch_bounds__(256)
 // FOLD (cy_bn_acc.h): (k1, k0) are derived from the backward sums' accumulator by every workgroup; workgroup 0 adds the
 // parameter gradients (what bn_bwd_finalize_kernel did in a launch of its own)
 template <typename T, bool FOLD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(ew_threads<FOLD>())
     bn_relu_bwd_apply_kernel(const T* __restrict__ da, int ld_da, const T* __restrict__ y,
                              const float* __restrict__ scale, const float* __restrict__ shift,
                              const float* __restrict__ coef, T* __restrict__ dy, long npix, int C, const BnBwdFold fold) {
@@ -405,9 +415,10 @@ __global__ void __launch_bounds__(256)
   const int G = C / 8;
   const bool pow2 = (G & (G - 1)) == 0;
   const int gshift = 31 - __clz(G);
+  constexpr long NT = ew_threads<FOLD>();
   const long total = npix * G;
-  const long stride = (long)gridDim.x * 256L;
-  long i = blockIdx.x * 256L + threadIdx.x;
+  const long stride = (long)gridDim.x * NT;
+  long i = blockIdx.x * NT + threadIdx.x;
   // the next item's (da, y) are always in flight; the first one's before the coefficients are derived (see
   // bn_relu_apply_kernel)
   u32x4 rd0 = {0u, 0u, 0u, 0u}, rd1 = {0u, 0u, 0u, 0u}, rv0 = {0u, 0u, 0u, 0u}, rv1 = {0u, 0u, 0u, 0u};
@@ -422,14 +433,21 @@ __global__ void __launch_bounds__(256)
   if (i < total) request(i);
   if constexpr (FOLD) {
     unsigned long long* s_sum = reinterpret_cast<unsigned long long*>(s_coef + 4 * C);
-    for (int c = threadIdx.x; c < C; c += 256) {  // (the forward coefficients: requested before the accumulator)
-      s_coef[c] = scale[c];
-      s_coef[C + c] = shift[c];
-    }
-    bn_acc_gather(fold.acc, fold.R, C, s_sum, threadIdx.x, 256);
-    for (int c = threadIdx.x; c < C; c += 256) {
+    // (host: C <= 1024 = NT) the forward coefficients and moments of this thread's channel and, for the leader, the gradient
+    // words it adds to: all requested ahead of the gather, used after it -- one round trip to memory, not three
+    const bool leader = blockIdx.x == 0;
+    const int c = threadIdx.x;
+    const bool on = c < C;
+    const float psc = on ? scale[c] : 0.f, psh = on ? shift[c] : 0.f;
+    const float pm = (on && fold.batch_stats) ? fold.coef[2 * C + c] : 0.f, pi = (on && fold.batch_stats) ? fold.coef[3 * C + c] : 0.f;
+    const float pdg = (on && leader && fold.accumulate && fold.dgamma) ? fold.dgamma[c] : 0.f;
+    const float pdb = (on && leader && fold.accumulate && fold.dbeta) ? fold.dbeta[c] : 0.f;
+    bn_acc_gather<true>(fold.acc, fold.R, C, s_sum, threadIdx.x, (int)NT);
+    if (on) {
       float k1v, k0v;
-      bn_bwd_fold_channel(fold, s_sum, c, blockIdx.x == 0, k1v, k0v);
+      bn_bwd_fold_finish(fold, s_sum, c, leader, psc, pm, pi, pdg, pdb, k1v, k0v);
+      s_coef[c] = psc;
+      s_coef[C + c] = psh;
       s_coef[2 * C + c] = k1v;
       s_coef[3 * C + c] = k0v;
     }
@@ -496,7 +514,8 @@ __global__ void __launch_bounds__(256)
       sc[j] = scale[g * 8 + j], sh[j] = shift[g * 8 + j], mu[j] = mean[g * 8 + j], is[j] = invstd[g * 8 + j];
     }
   }
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+  constexpr long NT = 256;
+  for (long i = blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
     const int g = (int)(i % G);
     long p = i / G;
     const int w = (int)(p % W);
@@ -592,7 +611,8 @@ __global__ void __launch_bounds__(256)
       sc[j] = coef[g * 8 + j], sh[j] = coef[C + g * 8 + j], mu[j] = coef[2 * C + g * 8 + j], is[j] = coef[3 * C + g * 8 + j];
     }
   }
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+  constexpr long NT = 256;
+  for (long i = blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
     const int g = (int)(i % G);
     long p = i / G;
     const int w = (int)(p % W);
@@ -668,10 +688,11 @@ __global__ void __launch_bounds__(256) bn_running_update_kernel(const BnRunArgs 
   }
 }
 
-// grid of the folding elementwise kernels: every workgroup reads the accumulator, so few, long-running workgroups
+// grid of the folding elementwise kernels: every workgroup reads the accumulator, so few, long-running workgroups of
+// 1024 threads (one per CU)
 inline int fold_grid(long items) {
-  long b = (items + 255) / 256;  // (as many workgroups as the plain kernels on the small maps, whose time is latency)
-  if (b > 1024) b = 1024;
+  long b = (items + 1023) / 1024;
+  if (b > 256) b = 256;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -714,7 +735,7 @@ static int bn_relu_apply_impl(const void* y, const float* scale, const float* sh
   const size_t smem = f ? (size_t)2 * C * sizeof(float) + ((size_t)4 * C + 2) * 8 : 0;
 #define CY_APPLY(TI, TO)                                                                                        \
   do {                                                                                                          \
-    if (f) hipLaunchKernelGGL((bn_relu_apply_kernel<TI, TO, true>), dim3(grid), dim3(256), smem, st, (const TI*)y, \
+    if (f) hipLaunchKernelGGL((bn_relu_apply_kernel<TI, TO, true>), dim3(grid), dim3(1024), smem, st, (const TI*)y, \
                               scale, shift, (TO*)out, npix, C, bf);                                             \
     else hipLaunchKernelGGL((bn_relu_apply_kernel<TI, TO, false>), dim3(grid), dim3(256), 0, st, (const TI*)y,  \
                             scale, shift, (TO*)out, npix, C, bf);                                               \
@@ -754,7 +775,7 @@ static int bn_relu_apply_pool_impl(const void* y, const float* scale, const floa
   const size_t smem = f ? (size_t)2 * C * sizeof(float) + ((size_t)4 * C + 2) * 8 : 0;
 #define CY_APPLY_POOL(TI, TO)                                                                                      \
   do {                                                                                                             \
-    if (f) hipLaunchKernelGGL((bn_relu_apply_pool_kernel<TI, TO, true>), dim3(grid), dim3(256), smem, st,          \
+    if (f) hipLaunchKernelGGL((bn_relu_apply_pool_kernel<TI, TO, true>), dim3(grid), dim3(1024), smem, st,          \
                               (const TI*)y, scale, shift, (TO*)out, (TO*)pooled, N, H, W, C, bf);                  \
     else hipLaunchKernelGGL((bn_relu_apply_pool_kernel<TI, TO, false>), dim3(grid), dim3(256), 0, st, (const TI*)y, \
                             scale, shift, (TO*)out, (TO*)pooled, N, H, W, C, bf);                                  \
@@ -906,7 +927,7 @@ int cy_bn_relu_bwd_apply_fold(const void* da, int ld_da, const void* y, const fl
   const int grid = fold_grid(npix * (C / 8));
   const size_t smem = (size_t)4 * C * sizeof(float) + ((size_t)4 * C + 2) * 8;
 #define CY_BWD_APPLY(TT)                                                                                          \
-  hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<TT, true>), dim3(grid), dim3(256), smem, st, (const TT*)da, ld_da,  \
+  hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<TT, true>), dim3(grid), dim3(1024), smem, st, (const TT*)da, ld_da,  \
                      (const TT*)y, coef, coef + C, (const float*)nullptr, (TT*)dy, npix, C, f)
   if (dtype == CY_BF16) CY_BWD_APPLY(bf16);
   else if (dtype == CY_F16) CY_BWD_APPLY(f16);
