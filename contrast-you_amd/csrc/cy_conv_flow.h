@@ -359,11 +359,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 2)
     float ck1 = 0.f, ck0 = 0.f;
     if constexpr (pro2) {  // (k1, k0) from the backward sums; workgroup 0 adds dgamma / dbeta (what bn_bwd_finalize_kernel did)
       unsigned long long* s_sum = reinterpret_cast<unsigned long long*>(smem + C::STAGE + C::A_BYTES);
-      bn_acc_gather(a.bfold.acc, a.bfold.R, a.C1, s_sum, tid, C::NTHR);
+      bn_acc_gather<true>(a.bfold.acc, a.bfold.R, a.C1, s_sum, tid, C::NTHR);
       if (tid < a.C1) bn_bwd_fold_channel(a.bfold, s_sum, tid, blockIdx.x == 0 && blockIdx.z == 0, ck1, ck0);
     } else if (a.fold.acc) {  // (the sums of the replicas through LDS: the weight region of the second stage is idle until chunk 1)
       unsigned long long* s_sum = reinterpret_cast<unsigned long long*>(smem + C::STAGE + C::A_BYTES);
-      bn_acc_gather(a.fold.acc, a.fold.R, a.C1, s_sum, tid, C::NTHR);
+      bn_acc_gather<true>(a.fold.acc, a.fold.R, a.C1, s_sum, tid, C::NTHR);
       if (tid < a.C1) bn_fold_channel_lds(a.fold, s_sum, tid, blockIdx.x == 0 && blockIdx.z == 0, csc, csh);
     }
     if (tid < a.C1) {

@@ -235,7 +235,7 @@ __global__ void __launch_bounds__((256 * NB / stream_nbw<KCH, NB>()), (PRO ? 2 :
       // the first DMA is issued behind this); workgroup 0 leaves them in memory for the backward pass
       float* scoef = reinterpret_cast<float*>(smem);
       unsigned long long* s_sum = reinterpret_cast<unsigned long long*>(smem + 512);
-      bn_acc_gather(a.fold.acc, a.fold.R, a.C1, s_sum, tid, C::NTHR);
+      bn_acc_gather<true>(a.fold.acc, a.fold.R, a.C1, s_sum, tid, C::NTHR);
       if (tid < a.C1) {  // host: C1 == 32
         float c0, c1;
         bn_fold_channel_lds(a.fold, s_sum, tid, blockIdx.x == 0, c0, c1);
