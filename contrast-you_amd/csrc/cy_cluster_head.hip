@@ -144,7 +144,9 @@ __device__ __forceinline__ void ch_stage_w(const float* __restrict__ w, float* s
   }
 }
 
-template <typename T>
+// LINEAR (cy_head1x1_fwd with more than 16 outputs, e.g. DenseClusterHead(normalize=True)): no softmax, the tile's logits
+// [32 px][K] -- one contiguous run of the [M][K] output -- go out as they stand in LDS, 256 contiguous bytes per store
+template <typename T, bool LINEAR = false>
 __global__ void __launch_bounds__(512)
     cluster_head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                             float* __restrict__ probs, long M, int C, int K, int S, int k, float invT) {
@@ -185,13 +187,26 @@ __global__ void __launch_bounds__(512)
         if (co < K) sL[i * ldl + co] = acc[nb][reg] + sBias[co];
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    CY_CH_KQ_SWITCH(k, ch_softmax_rows<KQ>(sL, ldl, probs, M, p0, S, k, invT, lane));
+    if constexpr (LINEAR) {
+      const long rows = M - p0 < 32 ? M - p0 : 32;
+      float* o = probs + (size_t)p0 * K;
+      int px = 0, co = lane;  // element e = px * K + co of the tile, e = lane, lane + 64, ...
+      while (co >= K) co -= K, ++px;
+      for (int e = lane; e < (int)rows * K; e += 64) {
+        o[e] = sL[px * ldl + co];
+        co += 64;
+        while (co >= K) co -= K, ++px;
+      }
+    } else {
+      CY_CH_KQ_SWITCH(k, ch_softmax_rows<KQ>(sL, ldl, probs, M, p0, S, k, invT, lane));
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
 
 // slab layout per wave: [K_pad 128][C] dW then [128] db
-template <typename T>
+// LINEAR (cy_head1x1_bwd, wide): `dprobs` is dlogits [M][K] itself, copied into the tile
+template <typename T, bool LINEAR = false>
 __global__ void __launch_bounds__(256)
     cluster_head_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ probs,
                             const float* __restrict__ dprobs, T* __restrict__ dx, float* __restrict__ slabs, long M,
@@ -218,9 +233,48 @@ __global__ void __launch_bounds__(256)
   for (long tile = (long)blockIdx.x * 4 + wave; tile < ntile; tile += (long)gridDim.x * 4) {
     const long p0 = tile * 32;
     // dlogits of the tile: softmax backward per (pixel, sub-head); padding couts and pixels beyond M are zero
-    for (int e = lane; e < 32 * (CH_KP - S * k); e += 64)
-      sL[(e % 32) * CH_LDL + S * k + e / 32] = 0.f;
-    CY_CH_KQ_SWITCH(k, ch_dlogit_rows<KQ>(sL, CH_LDL, probs, dprobs, M, p0, S, k, invT, lane));
+    for (int e = lane; e < 32 * (CH_KP - K); e += 64)
+      sL[(e % 32) * CH_LDL + K + e / 32] = 0.f;
+    if constexpr (LINEAR) {
+      // the tile is one contiguous, 16-byte aligned run of 32 K floats: every lane requests its (up to 16) quads before
+      // the first one is used (a load -> LDS store loop pays one memory latency per iteration), then scatters them
+      // into the padded rows; element e = 4 (lane + 64 t) + j sits at (e / K, e % K), advanced by 256 per round
+      const long rows = M - p0 < 32 ? M - p0 : 32;
+      const int n = (int)rows * K;
+      const float* d = dprobs + (size_t)p0 * K;
+      f32x4 v[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int e0 = 4 * (lane + 64 * t);
+        if (e0 + 4 <= n) {
+          v[t] = *reinterpret_cast<const f32x4*>(d + e0);
+        } else {
+          v[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            if (e0 + j < n) v[t][j] = d[e0 + j];
+        }
+      }
+      const int d256 = 256 / K, r256 = 256 - d256 * K;
+      int px[4], co[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = 4 * lane + j;
+        px[j] = e / K;
+        co[j] = e - px[j] * K;
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (px[j] < 32) sL[px[j] * CH_LDL + co[j]] = v[t][j];
+          px[j] += d256, co[j] += r256;
+          if (co[j] >= K) co[j] -= K, ++px[j];
+        }
+      }
+    } else {
+      CY_CH_KQ_SWITCH(k, ch_dlogit_rows<KQ>(sL, CH_LDL, probs, dprobs, M, p0, S, k, invT, lane));
+    }
     if (need_dw) ch_stage_x<T>(x, sX, p0, M, C, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (need_dx) {  // dx[c][px] = sum_co W[co][c] dl[px][co]: rows = channels, columns = pixels
@@ -304,16 +358,16 @@ __global__ void __launch_bounds__(256)
 
 __global__ void __launch_bounds__(256)
     cluster_head_slab_reduce_kernel(const float* __restrict__ stage, float* __restrict__ dw, float* __restrict__ db,
-                                    int K, int C) {
+                                    int K, int C, int accumulate) {
   const int per = CH_KP * C + CH_KP;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < per; e += gridDim.x * 256) {
     float s = 0.f;
 #pragma unroll 8
     for (int q = 0; q < CH_RG; ++q) s += stage[(size_t)q * per + e];
     if (e < CH_KP * C) {
-      if (e / C < K) dw[e] = s;
-    } else if (e - CH_KP * C < K) {
-      db[e - CH_KP * C] = s;
+      if (e / C < K && dw) dw[e] = accumulate ? dw[e] + s : s;
+    } else if (e - CH_KP * C < K && db) {
+      db[e - CH_KP * C] = accumulate ? db[e - CH_KP * C] + s : s;
     }
   }
 }
@@ -349,11 +403,11 @@ static int ch_check(long M, int C, int K, int S, int k) {
   return CY_OK;
 }
 
-int cy_cluster_head_fwd(const void* x, const float* w, const float* b, float* probs, long M, int C, int K, int S,
-                        int k, float invT, int dtype, void* stream) {
-  if (!x || !w || !probs) return CY_ERR_ARG;
-  int rc = ch_check(M, C, K, S, k);
-  if (rc != CY_OK) return rc;
+}  // extern "C"
+
+template <bool LINEAR>
+static int ch_fwd_impl(const void* x, const float* w, const float* b, float* out, long M, int C, int K, int S, int k,
+                       float invT, int dtype, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int nw = ch_fwd_waves(C);
   long gb = ((M + 31) / 32 + nw - 1) / nw;
@@ -361,11 +415,11 @@ int cy_cluster_head_fwd(const void* x, const float* w, const float* b, float* pr
   const size_t smem = ch_fwd_smem(C, K);
 #define CY_CH_FWD(TT)                                                                                         \
   do {                                                                                                        \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cluster_head_fwd_kernel<TT>),                       \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cluster_head_fwd_kernel<TT, LINEAR>),               \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)            \
       return CY_ERR_LAUNCH;                                                                                   \
-    hipLaunchKernelGGL(cluster_head_fwd_kernel<TT>, dim3(grid), dim3(64 * nw), smem, st, (const TT*)x, w, b,  \
-                       probs, M, C, K, S, k, invT);                                                           \
+    hipLaunchKernelGGL((cluster_head_fwd_kernel<TT, LINEAR>), dim3(grid), dim3(64 * nw), smem, st, (const TT*)x, w, b, \
+                       out, M, C, K, S, k, invT);                                                             \
   } while (0)
   if (dtype == CY_BF16) CY_CH_FWD(bf16);
   else if (dtype == CY_F16) CY_CH_FWD(f16);
@@ -376,26 +430,37 @@ int cy_cluster_head_fwd(const void* x, const float* w, const float* b, float* pr
   return CY_OK;
 }
 
+extern "C" {
+
+int cy_cluster_head_fwd(const void* x, const float* w, const float* b, float* probs, long M, int C, int K, int S,
+                        int k, float invT, int dtype, void* stream) {
+  if (!x || !w || !probs) return CY_ERR_ARG;
+  int rc = ch_check(M, C, K, S, k);
+  if (rc != CY_OK) return rc;
+  return ch_fwd_impl<false>(x, w, b, probs, M, C, K, S, k, invT, dtype, stream);
+}
+
 size_t cy_cluster_head_bwd_ws_bytes(long M, int C) {
   return ((size_t)ch_blocks(M) * 4 + CH_RG) * ((size_t)CH_KP * C + CH_KP) * sizeof(float);
 }
 
-int cy_cluster_head_bwd(const void* x, const float* w, const float* probs, const float* dprobs, void* dx, float* dw,
-                        float* db, long M, int C, int K, int S, int k, float invT, int dtype, void* ws,
-                        size_t ws_bytes, void* stream) {
-  if (!x || !w || !probs || !dprobs) return CY_ERR_ARG;
-  int rc = ch_check(M, C, K, S, k);
-  if (rc != CY_OK) return rc;
-  const int need_dx = dx != nullptr, need_dw = dw != nullptr;
-  if (need_dw && (!db || !ws || ws_bytes < cy_cluster_head_bwd_ws_bytes(M, C))) return CY_ERR_WORKSPACE;
+}  // extern "C"
+
+template <bool LINEAR>
+static int ch_bwd_impl(const void* x, const float* w, const float* probs, const float* dprobs, void* dx, float* dw,
+                       float* db, int accumulate, long M, int C, int K, int S, int k, float invT, int dtype, void* ws,
+                       size_t ws_bytes, void* stream) {
+  int rc;
+  const int need_dx = dx != nullptr, need_dw = dw != nullptr || db != nullptr;
+  if (need_dw && (!ws || ws_bytes < cy_cluster_head_bwd_ws_bytes(M, C))) return CY_ERR_WORKSPACE;
   if (!need_dx && !need_dw) return CY_OK;
   hipStream_t st = (hipStream_t)stream;
   const int grid = ch_blocks(M);
   const size_t smem = ch_smem(C);
 #define CY_CH_BWD(TT)                                                                                          \
   do {                                                                                                         \
-    if ((rc = ch_set_smem(cluster_head_bwd_kernel<TT>, 64)) != CY_OK) return rc;                               \
-    hipLaunchKernelGGL(cluster_head_bwd_kernel<TT>, dim3(grid), dim3(256), smem, st, (const TT*)x, w, probs,   \
+    if ((rc = ch_set_smem(cluster_head_bwd_kernel<TT, LINEAR>, 64)) != CY_OK) return rc;                       \
+    hipLaunchKernelGGL((cluster_head_bwd_kernel<TT, LINEAR>), dim3(grid), dim3(256), smem, st, (const TT*)x, w, probs, \
                        dprobs, (TT*)dx, (float*)ws, M, C, K, S, k, invT, need_dx, need_dw);                    \
   } while (0)
   if (dtype == CY_BF16) CY_CH_BWD(bf16);
@@ -411,10 +476,35 @@ int cy_cluster_head_bwd(const void* x, const float* w, const float* probs, const
                        (const float*)ws, grid * 4, stage, per);
     CY_CHECK_LAUNCH();
     hipLaunchKernelGGL(cluster_head_slab_reduce_kernel, dim3(cy_cdiv(per, 256)), dim3(256), 0, st,
-                       (const float*)stage, dw, db, K, C);
+                       (const float*)stage, dw, db, K, C, accumulate);
     CY_CHECK_LAUNCH();
   }
   return CY_OK;
 }
 
+extern "C" {
+
+int cy_cluster_head_bwd(const void* x, const float* w, const float* probs, const float* dprobs, void* dx, float* dw,
+                        float* db, long M, int C, int K, int S, int k, float invT, int dtype, void* ws,
+                        size_t ws_bytes, void* stream) {
+  if (!x || !w || !probs || !dprobs) return CY_ERR_ARG;
+  int rc = ch_check(M, C, K, S, k);
+  if (rc != CY_OK) return rc;
+  if (dw && !db) return CY_ERR_WORKSPACE;
+  return ch_bwd_impl<false>(x, w, probs, dprobs, dx, dw, db, 0, M, C, K, S, k, invT, dtype, ws, ws_bytes, stream);
+}
+
 }  // extern "C"
+
+// ---- the wide 1x1 head (cy_head1x1_fwd / _bwd with 16 < K <= 128 outputs over 32 or 64 channels) on the kernels above:
+// called from cy_head_loss.hip, same shared object
+bool cy_head_wide_ok(int C, int K) { return (C == 32 || C == 64) && K > 16 && K <= CH_KP; }
+size_t cy_head_wide_bwd_ws_bytes(long M, int C) { return cy_cluster_head_bwd_ws_bytes(M, C); }
+int cy_head_wide_fwd(const void* x, const float* w, const float* b, float* logits, long M, int C, int K, int dtype,
+                     void* stream) {
+  return ch_fwd_impl<true>(x, w, b, logits, M, C, K, 1, K, 1.f, dtype, stream);
+}
+int cy_head_wide_bwd(const void* x, const float* w, const float* dlogits, void* dx, float* dw, float* db, int accumulate,
+                     long M, int C, int K, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  return ch_bwd_impl<true>(x, w, nullptr, dlogits, dx, dw, db, accumulate, M, C, K, 1, K, 1.f, dtype, ws, ws_bytes, stream);
+}

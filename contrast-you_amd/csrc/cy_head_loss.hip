@@ -8,6 +8,14 @@
 // All of it is HBM-streaming work over [pixels][K] f32 logits (K = classes).
 #include "cy_common.h"
 
+// the wide head on the matrix-core kernels of cy_cluster_head.hip (same shared object)
+bool cy_head_wide_ok(int C, int K);
+size_t cy_head_wide_bwd_ws_bytes(long M, int C);
+int cy_head_wide_fwd(const void* x, const float* w, const float* b, float* logits, long M, int C, int K, int dtype,
+                     void* stream);
+int cy_head_wide_bwd(const void* x, const float* w, const float* dlogits, void* dx, float* dw, float* db, int accumulate,
+                     long M, int C, int K, int dtype, void* ws, size_t ws_bytes, void* stream);
+
 namespace {
 
 constexpr int KMAX = 16;    // segmentation classes
@@ -441,6 +449,9 @@ int cy_head1x1_fwd(const void* x, const float* w, const float* b, float* logits,
   if (!x || !w || !logits || npix <= 0) return CY_ERR_ARG;
   if (C % 8 || K < 1 || K > KWIDE || (size_t)(K * C + K) * 4 > 60000) return CY_ERR_SHAPE;
   if (x_dtype != CY_BF16 && x_dtype != CY_F32 && x_dtype != CY_F16) return CY_ERR_DTYPE;
+  // stacked cluster sub-heads over 32 / 64 channels: f32 matrix cores, the logits tile written in contiguous runs
+  // (the VALU kernel below stores one float per lane at a 4 K-byte stride: 0.8 TB/s at K = 100)
+  if (cy_head_wide_ok(C, K)) return cy_head_wide_fwd(x, w, b, logits, npix, C, K, x_dtype, stream);
   hipStream_t st = (hipStream_t)stream;
   const int grid = loss_blocks(npix) * 2;
   const size_t smem = (size_t)(K * C + K) * sizeof(float);
@@ -471,6 +482,7 @@ int cy_head1x1_fwd(const void* x, const float* w, const float* b, float* logits,
 }
 
 size_t cy_head1x1_bwd_ws_bytes(long npix, int C, int K) {
+  if (cy_head_wide_ok(C, K)) return cy_head_wide_bwd_ws_bytes(npix, C);
   return (size_t)head_dw_blocks(npix) * (K * C + K) * sizeof(float);
 }
 
@@ -496,6 +508,8 @@ static int head1x1_bwd_impl(const void* x, const float* w, const float* dlogits,
   if (!x || !w || !dlogits || npix <= 0) return CY_ERR_ARG;
   if (C % 8 || K < 1 || K > KWIDE || (size_t)(K * C + K) * 4 > 60000) return CY_ERR_SHAPE;
   if (x_dtype != CY_BF16 && x_dtype != CY_F32 && x_dtype != CY_F16) return CY_ERR_DTYPE;
+  if (cy_head_wide_ok(C, K))
+    return cy_head_wide_bwd(x, w, dlogits, dx, dw, db, accumulate, npix, C, K, x_dtype, ws, ws_bytes, stream);
   hipStream_t st = (hipStream_t)stream;
   if (dx) {
     const long total = npix * (C / 8);
