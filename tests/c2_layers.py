@@ -39,7 +39,7 @@ def conv_kernel_name(plan: dict, dtype_tag: str = "DF16b", cin: int = 0, stats: 
                 + b(allt) + b(plan["one_per_cu"]) + "E")
     if plan["kernel"] == "conv3x3_flow_kernel":
         wgm, wgn = (4, 2) if plan["bn"] == 128 else ((4, 1) if plan["th"] in (16, 32) else (8, 1))
-        return ("conv3x3_flow_kernelI" + dtype_tag + i(plan["th"]) + i(plan["bn"]) + i(wgm) + i(wgn) + b(plan["tw"] == 16) + "E")
+        return ("conv3x3_flow_kernelI" + dtype_tag + i(plan["th"]) + i(plan["bn"]) + i(wgm) + i(wgn) + b(plan["tw"] == 16) + i(0) + "E")  # (MODE 0: the forward / plain data-gradient build)
     if plan["kernel"] == "conv3x3_stream_kernel":
         return ("conv3x3_stream_kernelI" + dtype_tag + i(cin // 32) + i(plan["bn"] // 32) + b(stats) + b(pro) + "E")
     wgm, wgn = ((1, 4) if (plan["th"], plan["tw"]) in ((8, 28), (16, 14)) else (2, 2)) if plan["bn"] == 128 else (4, 1)
