@@ -883,6 +883,90 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// The same on the matrix core (Cin = 1, Cout = 32, 16-bit storage, H % 8 == 0, W % 16 == 0): the VALU kernel above spends
+// 72 FMAs, nine LDS reads and a dependent 16-byte load per (pixel, 8 couts) and runs at 2.1 TB/s of dy (93 us of a C2 step,
+// 1.36 ms of a C5 step).  dW[co][tap] = sum_px dy[px][co] x[px + tap] is one 32x32x16 MFMA per 16 consecutive pixels of an
+// image row: rows = couts (dy, transposed through a 1 KB per-wave LDS tile with ds_read_b64_tr_b16 like the weight
+// gradient of the other layers), columns = taps (9 of 32 used), k = the 16 pixels; a tap's fragment is ONE aligned 16-byte
+// LDS read from the image rows, which are staged in the storage type three times (shifted by -1 / 0 / +1 columns).
+// A workgroup walks sub-blocks of eight image rows (ten staged); one partial per workgroup, the four waves summed in wave
+// order: bitwise reproducible.  The image is rounded to the storage type, as the forward kernel on the matrix core does.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    first_wgrad_mfma_kernel(const float* __restrict__ x, const T* __restrict__ dy, float* __restrict__ ws, int N, int H,
+                            int W, int spb) {
+  using M = Mma<T>;
+  constexpr int Cout = 32, SUBR = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* sdy = smem + wave * 1024;          // this wave's [16 px][64 B] tile
+  T* simg = reinterpret_cast<T*>(smem + 4096);      // [3 shifts][SUBR + 2 rows][W]
+  const int h = lane >> 5, tap = lane & 31;
+  const int dh = tap < 9 ? tap / 3 - 1 : 0, dw = tap < 9 ? tap % 3 - 1 : 0;
+  // per-lane constants of the transposed dy fragment (WFrag, wgrad12 kernels)
+  const int q = (lane & 15) >> 2, p4 = lane & 3, gsel = (lane >> 4) & 1;
+  const unsigned char* arow = sdy + (8 * h + q) * 64 + (16 * gsel + 4 * p4) * 2;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int NH = N * H, nsub = NH / SUBR;
+  const int gpr = W / 16;  // pixel groups per image row
+  const int sb0 = (int)blockIdx.x * spb, sb1 = sb0 + spb < nsub ? sb0 + spb : nsub;
+  for (int sb = sb0; sb < sb1; ++sb) {
+    const int r0 = sb * SUBR;  // first global row (n * H + h) of the sub-block; its rows belong to one image
+    __syncthreads();           // (the previous sub-block's image is no longer read)
+    for (int r = wave; r < SUBR + 2; r += 4) {
+      const int g = r0 - 1 + r;
+      const bool rok = g >= 0 && g < NH;
+      const float* xr = x + (size_t)(rok ? g : 0) * W;
+      for (int c = lane; c < W; c += 64) {
+        const float v0 = (rok && c >= 1) ? xr[c - 1] : 0.f, v1 = rok ? xr[c] : 0.f, v2 = (rok && c + 1 < W) ? xr[c + 1] : 0.f;
+        simg[(0 * (SUBR + 2) + r) * W + c] = from_f32<T>(v0);
+        simg[(1 * (SUBR + 2) + r) * W + c] = from_f32<T>(v1);
+        simg[(2 * (SUBR + 2) + r) * W + c] = from_f32<T>(v2);
+      }
+    }
+    __syncthreads();
+    const int ngr = SUBR * gpr;
+    const T* dyb = dy + (size_t)r0 * W * Cout;
+    u32x4 d = {0u, 0u, 0u, 0u};
+    if (wave < ngr) d = ld16(dyb + (size_t)wave * 16 * Cout + lane * 8);
+    for (int gi = wave; gi < ngr; gi += 4) {
+      const int rr = gi / gpr, w0 = (gi - rr * gpr) * 16;
+      const int hq = (r0 + rr) % H;
+      st16(sdy + lane * 16, d);
+      // (the next group's rows in flight; three groups ahead measured the same: a launch at C2's sizes is its fixed costs)
+      if (gi + 4 < ngr) d = ld16(dyb + (size_t)(gi + 4) * 16 * Cout + lane * 8);
+      __builtin_amdgcn_wave_barrier();
+      const typename M::Frag af = WFrag<T>::load(arow, arow + 4 * 64);
+      typename M::Frag bf;
+      {
+        const bool on = tap < 9 && hq + dh >= 0 && hq + dh < H;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (on) v = *reinterpret_cast<const u32x4*>(simg + ((dw + 1) * (SUBR + 2) + rr + 1 + dh) * W + w0 + 8 * h);
+        bf.v = __builtin_bit_cast(decltype(bf.v), v);
+      }
+      M::mma(af, bf, acc);
+      __builtin_amdgcn_wave_barrier();  // (the tile is rewritten by the next group)
+    }
+  }
+  // the workgroup's partial: waves 0..3 summed in wave order, then ws[block][co][tap]
+  __syncthreads();
+  float* sred = reinterpret_cast<float*>(smem);  // [4 waves][16 regs][64 lanes] = 16 KB (aliases the tiles and the image)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sred[(wave * 16 + i) * 64 + lane] = acc[i];
+  __syncthreads();
+  for (int e = tid; e < Cout * 9; e += 256) {
+    const int co = e / 9, t = e - co * 9;
+    const int l = t + 32 * ((co >> 2) & 1), v = 4 * (co >> 3) + (co & 3);  // D[co][t]: lane t + 32 (co/4 % 2), register 4 (co/8) + co % 4
+    float sum = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) sum += sred[(wv * 16 + v) * 64 + l];
+    ws[((size_t)blockIdx.x * Cout + co) * 9 + t] = sum;
+  }
+}
+
 // dw[i] (+)= sum over the block partials: 4 outputs per workgroup, 64 slices each, fixed order
 __global__ void __launch_bounds__(256)
     first_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nblk,
@@ -900,6 +984,17 @@ __global__ void __launch_bounds__(256)
     for (int q = 0; q < 64; ++q) t += sr[q][el];
     dw[i] = accumulate ? dw[i] + t : t;
   }
+}
+
+// workgroups of first_wgrad_mfma_kernel (sub-blocks of eight rows, contiguous ranges of them), or 0 where it does not apply
+int first_wgrad_mfma_blocks(int N, int Cin, int H, int W, int Cout, int dtype) {
+  static const bool enabled = [] {
+    const char* e = getenv("CY_FIRST_WGRAD_MFMA");
+    return !(e && e[0] == '0');
+  }();
+  if (!enabled || Cin != 1 || Cout != 32 || (dtype != CY_BF16 && dtype != CY_F16) || H % 8 || W % 16 || W > 2048) return 0;
+  const long nsub = (long)N * H / 8;
+  return (int)(nsub < 1024 ? nsub : 1024);
 }
 
 int first_wgrad_blocks(long npix, int W) {
@@ -1046,7 +1141,10 @@ int cy_conv3x3_wgrad_pair(const cy_conv_desc* d, const void* src1, const void* s
 }
 
 size_t cy_conv3x3_first_wgrad_ws_bytes(int N, int Cin, int H, int W, int Cout) {
-  return (size_t)first_wgrad_blocks((long)N * H * W, W) * Cout * Cin * 9 * sizeof(float);
+  long nb = first_wgrad_blocks((long)N * H * W, W);
+  const long nm = first_wgrad_mfma_blocks(N, Cin, H, W, Cout, CY_BF16);  // (either kernel's partials fit)
+  if (nm > nb) nb = nm;
+  return (size_t)nb * Cout * Cin * 9 * sizeof(float);
 }
 
 int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int accumulate, int N, int Cin,
@@ -1056,8 +1154,23 @@ int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int accumu
   if (Cin < 1 || Cin > 4 || Cout % 8 || Cout > 64 || 256 % (Cout / 8)) return CY_ERR_SHAPE;
   if ((long)N * H * W >= (1L << 31)) return CY_ERR_SHAPE;
   if (ws_bytes < cy_conv3x3_first_wgrad_ws_bytes(N, Cin, H, W, Cout)) return CY_ERR_WORKSPACE;
-  const int nblk = first_wgrad_blocks((long)N * H * W, W);
   hipStream_t st = (hipStream_t)stream;
+  if (const int nm = first_wgrad_mfma_blocks(N, Cin, H, W, Cout, dy_dtype)) {
+    const int nsub = N * H / 8, spb = (nsub + nm - 1) / nm;
+    size_t smem = 4096 + (size_t)3 * 10 * W * 2;
+    if (smem < 16384) smem = 16384;  // (the four waves' accumulators pass through it at the end)
+    if (dy_dtype == CY_BF16)
+      hipLaunchKernelGGL(first_wgrad_mfma_kernel<bf16>, dim3(nm), dim3(256), smem, st, x, (const bf16*)dy, (float*)ws, N, H, W, spb);
+    else
+      hipLaunchKernelGGL(first_wgrad_mfma_kernel<f16>, dim3(nm), dim3(256), smem, st, x, (const f16*)dy, (float*)ws, N, H, W, spb);
+    CY_CHECK_LAUNCH();
+    const int total = Cout * 9;
+    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(cy_cdiv(total, 4)), dim3(256), 0, st, (const float*)ws, dw, nm, total,
+                       accumulate);
+    CY_CHECK_LAUNCH();
+    return CY_OK;
+  }
+  const int nblk = first_wgrad_blocks((long)N * H * W, W);
   const long per = ((long)N * H * W + nblk - 1) / nblk;
   const size_t smem = (size_t)(per / W + 4) * (W + 2) * sizeof(float);
   if (nblk < 0 || smem > 96 * 1024) return CY_ERR_SHAPE;

@@ -65,6 +65,8 @@ def first_layer(out):
     y, part = ops.conv_first_fwd(x, w, DT)
     out["first_fwd"] = y.float().cpu()
     out["first_stats"] = part.double().sum(0).float().cpu()
+    dy = nhwc(torch.randn(2, 32, 64, 64, generator=g))
+    out["first_wgrad"] = ops.conv_first_wgrad(x, dy).cpu()
 
 
 if __name__ == "__main__":

@@ -198,6 +198,28 @@ def test_first_conv_fwd_wgrad(cin, cout, dtype):
     assert_close(dw, w.grad, WTOL[dtype], "first conv wgrad")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W", [(3, 24, 48), (2, 224, 224), (5, 8, 16), (1, 40, 2048)])
+def test_first_conv_wgrad_on_the_matrix_core(N, H, W, dtype):
+    """first_wgrad_mfma_kernel (Cin 1, Cout 32, 16-bit storage, H % 8 == 0, W % 16 == 0): rows = couts, columns = taps,
+    k = 16 consecutive pixels; the image is rounded to the storage type like the forward kernel's.  Against torch's CPU
+    convolution on the rounded image (exact products, f32 sums: 1e-4 of the maximum), and bit-identical over launches;
+    image-border rows / columns, sub-block borders and several sub-blocks per workgroup are in these geometries."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N * H + W)
+    x = torch.rand(N, 1, H, W, generator=g)
+    w = (rnd(32, 1, 3, 3, gen=g) / 3).requires_grad_(True)
+    dy = rnd(N, 32, H, W, gen=g).to(dtype).float()
+    (F.conv2d(x.to(dtype).float(), w, None, 1, 1) * dy).sum().backward()
+    dw = ops.conv_first_wgrad(x.to(DEV), nhwc(dy, dtype))
+    assert_close(dw, w.grad, 1e-4, "first conv wgrad (matrix core)")
+    dw2 = ops.conv_first_wgrad(x.to(DEV), nhwc(dy, dtype))
+    assert torch.equal(dw, dw2)
+    sink = torch.ones(32, 1, 3, 3, device=DEV)
+    ops.conv_first_wgrad(x.to(DEV), nhwc(dy, dtype), out=sink)
+    assert_close(sink - 1, w.grad, 1e-4, "accumulating form")
+
+
 def test_first_conv_at_pretraining_batch_size():
     """BASELINE config 5 runs the first layer on 512 slices per launch: more image rows per workgroup than the
     LDS image of the input holds unless the grid grows with the batch (it did not at first: CY_ERR_SHAPE in

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 REPO = Path(__file__).resolve().parents[1]
 
 SWITCHES = [
-    {"CY_FLOW": "0"}, {"CY_STREAM": "0"}, {"CY_CONV_PLANE": "0"}, {"CY_FIRST_MFMA": "0"}, {"CY_PLANE_XCD": "0"},
+    {"CY_FLOW": "0"}, {"CY_STREAM": "0"}, {"CY_CONV_PLANE": "0"}, {"CY_FIRST_MFMA": "0"}, {"CY_FIRST_WGRAD_MFMA": "0"}, {"CY_PLANE_XCD": "0"},
     {"CY_WGRAD_SPEC": "0"}, {"CY_WGRAD_DMA": "0"}, {"CY_WGRAD_BLK": "0"},
     {"CY_PAIR_WGRAD": "0"}, {"CY_POOL_BN_FUSE": "0"}, {"CY_BN_ACC": "0"}, {"CY_BN_FOLD_IN_KERNEL": "0"},
     {"CY_DGRAD_BN": "1"}, {"CY_DGRAD_DZ": "1"}, {"CY_ASYNC_WGRAD": "0"}, {"CY_TWO_STREAM": "0"},
