@@ -17,9 +17,12 @@
 namespace {
 
 constexpr int CH_KP = 128;          // couts, padded
-// pitch of a logits tile row (floats): the real K, made odd -- K = 100 instead of the padded 128 lets eight waves'
-// tiles fit the LDS next to the weights (C = 32), i.e. two waves per SIMD instead of one
-__host__ __device__ inline int ch_ldl(int K) { return K | 1; }
+// pitch of a logits tile row (floats): the smallest p >= K with p % 8 == 4 -- K = 100 instead of the padded 128 lets eight
+// waves' tiles fit the LDS next to the weights (C = 32), i.e. two waves per SIMD instead of one; rows are 16-byte
+// aligned, so the epilogue, the softmax rows and the linear mode's output move the tile in 16-byte LDS accesses (it went
+// through LDS one float at a time with the odd pitch of rounds 2-3), and eight consecutive rows start in the eight
+// 16-byte bank groups
+__host__ __device__ inline int ch_ldl(int K) { return ((K + 3) & ~7) + 4; }
 constexpr int CH_LDL = CH_KP + 1;   // backward: padded couts take part in the products
 
 template <typename T> __device__ __forceinline__ void ch_load8(const T* p, float* f) {
@@ -69,8 +72,16 @@ __device__ __forceinline__ void ch_softmax_rows(const float* sL, int ldl, float*
     if (p0 + px >= M) continue;
     const float* lr = sL + px * ldl + s * k;
     float v[KQ];
+    if ((k & 3) == 0) {  // (rows and sub-head offsets are multiples of four floats)
 #pragma unroll
-    for (int j = 0; j < KQ; ++j) v[j] = lr[j];  // (columns beyond k: the next sub-head's / padding, masked below)
+      for (int q = 0; q < KQ / 4; ++q) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(lr + 4 * q);
+        v[4 * q] = t4[0], v[4 * q + 1] = t4[1], v[4 * q + 2] = t4[2], v[4 * q + 3] = t4[3];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) v[j] = lr[j];  // (columns beyond k: the next sub-head's / padding, masked below)
+    }
     float m = v[0];
 #pragma unroll
     for (int j = 1; j < KQ; ++j) m = (j < KQ - 4 || j < k) ? fmaxf(m, v[j]) : m;
@@ -150,7 +161,7 @@ template <typename T, bool LINEAR = false>
 __global__ void __launch_bounds__(512)
     cluster_head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                             float* __restrict__ probs, long M, int C, int K, int S, int k, float invT) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   float* sW = sm;                                   // [128][C + 1]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -179,23 +190,39 @@ __global__ void __launch_bounds__(512)
       for (int nb = 0; nb < 4; ++nb)
         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(sW[(nb * 32 + i) * (C + 1) + ks + kk], bv, acc[nb], 0, 0, 0);
     }
+    const int K4 = (K + 3) & ~3;  // (<= ldl: a quad that starts below K4 lies inside the row; columns >= K are never read)
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int co = nb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
-        if (co < K) sL[i * ldl + co] = acc[nb][reg] + sBias[co];
+      for (int g = 0; g < 4; ++g) {  // registers 4g .. 4g+3 = four consecutive couts
+        const int co0 = nb * 32 + 8 * g + 4 * kk;
+        if (co0 < K4) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + co0);
+          *reinterpret_cast<f32x4*>(sL + i * ldl + co0) =
+              f32x4{acc[nb][4 * g] + b4[0], acc[nb][4 * g + 1] + b4[1], acc[nb][4 * g + 2] + b4[2], acc[nb][4 * g + 3] + b4[3]};
+        }
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if constexpr (LINEAR) {
       const long rows = M - p0 < 32 ? M - p0 : 32;
       float* o = probs + (size_t)p0 * K;
-      int px = 0, co = lane;  // element e = px * K + co of the tile, e = lane, lane + 64, ...
-      while (co >= K) co -= K, ++px;
-      for (int e = lane; e < (int)rows * K; e += 64) {
-        o[e] = sL[px * ldl + co];
-        co += 64;
+      if ((K & 3) == 0) {  // quads: 16-byte LDS reads, 16-byte stores (the tile starts at a multiple of 32 K floats)
+        const int qpr = K >> 2, nq = (int)rows * qpr;
+        int px = 0, cq = lane;
+        while (cq >= qpr) cq -= qpr, ++px;
+        for (int e = lane; e < nq; e += 64) {
+          *reinterpret_cast<f32x4*>(o + 4 * e) = *reinterpret_cast<const f32x4*>(sL + px * ldl + 4 * cq);
+          cq += 64;
+          while (cq >= qpr) cq -= qpr, ++px;
+        }
+      } else {
+        int px = 0, co = lane;  // element e = px * K + co of the tile, e = lane, lane + 64, ...
         while (co >= K) co -= K, ++px;
+        for (int e = lane; e < (int)rows * K; e += 64) {
+          o[e] = sL[px * ldl + co];
+          co += 64;
+          while (co >= K) co -= K, ++px;
+        }
       }
     } else {
       CY_CH_KQ_SWITCH(k, ch_softmax_rows<KQ>(sL, ldl, probs, M, p0, S, k, invT, lane));
@@ -378,10 +405,12 @@ inline int ch_blocks(long M) {
   if (nb < 1) nb = 1;
   return (int)nb;
 }
-inline int ch_fwd_waves(int C) { return C <= 32 ? 8 : 4; }
-inline size_t ch_fwd_smem(int C, int K) {
-  return ((size_t)CH_KP * (C + 1) + ch_fwd_waves(C) * (32 * (C + 1) + 32 * ch_ldl(K)) + CH_KP) * sizeof(float);
+inline size_t ch_fwd_smem_w(int C, int K, int nw) {
+  return ((size_t)CH_KP * (C + 1) + nw * (32 * (C + 1) + 32 * ch_ldl(K)) + CH_KP) * sizeof(float);
 }
+// eight waves where their tiles fit the 160 KB next to the weights (C = 32 up to K = 108), four otherwise
+inline int ch_fwd_waves(int C, int K) { return ch_fwd_smem_w(C, K, 8) <= 160 * 1024 ? 8 : 4; }
+inline size_t ch_fwd_smem(int C, int K) { return ch_fwd_smem_w(C, K, ch_fwd_waves(C, K)); }
 inline size_t ch_smem(int C) { return ((size_t)CH_KP * (C + 1) + 4 * (32 * (C + 1) + 32 * CH_LDL) + CH_KP) * sizeof(float); }
 
 template <typename K_>
@@ -409,7 +438,7 @@ template <bool LINEAR>
 static int ch_fwd_impl(const void* x, const float* w, const float* b, float* out, long M, int C, int K, int S, int k,
                        float invT, int dtype, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  const int nw = ch_fwd_waves(C);
+  const int nw = ch_fwd_waves(C, K);
   long gb = ((M + 31) / 32 + nw - 1) / nw;
   const int grid = (int)(gb > 256 ? 256 : gb);  // one block per CU (LDS): grid-stride over the pixel tiles
   const size_t smem = ch_fwd_smem(C, K);
