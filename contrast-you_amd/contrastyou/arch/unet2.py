@@ -15,8 +15,10 @@ memory, views, `cat`, the residual adds and dtype casts at the block borders.  U
 SemiSupervisedEpocher + InfoNCE hot path (it has no `until=` / `arch_elements`,
 semi_seg/hooks/infonce.py:98 cannot attach to it): these kernels are sized for correctness and
 full-chip launches, not tuned per shape.  Module and parameter names are the reference's
-(checkpoints interchange); time embeddings are not supported (the segmentation configs never enable
-them).
+(checkpoints interchange).  `with_time_emb=True` (round 4): `SinusoidalPosEmb`, the two small MLPs
+(`time_mlp`, every `ResnetBlock.mlp`) and the `x * (scale + 1) + shift` modulation between GroupNorm and
+SiLU run on HIP kernels as well (cy_sinusoidal_emb, cy_linear_*, cy_act_*, cy_gn_silu_mod_*); like the
+reference, `forward(x, time)` then needs a `time` tensor of shape [B].
 """
 from __future__ import annotations
 
@@ -26,7 +28,7 @@ import torch
 from torch import Tensor, nn
 
 from cyhip import ops
-from cyhip.functions import Conv3x3Fn, GNSiLUFn, compute_dtype_for
+from cyhip.functions import ActFn, Conv3x3Fn, GNSiLUFn, GNSiLUModFn, LinearFn, compute_dtype_for
 from cyhip.glue import AttentionFn, ChanLayerNormFn, Conv2dFn, ConvTranspose2dFn, LinearAttentionFn
 
 __all__ = ["Block", "UNet2"]
@@ -44,8 +46,6 @@ class Block(nn.Module):
         self.compute_dtype: Optional[torch.dtype] = None
 
     def forward(self, x: Tensor, scale_shift=None) -> Tensor:
-        if scale_shift is not None:
-            raise NotImplementedError("time-embedding scale/shift is not used by the segmentation path")
         ops.require_gpu(x)
         dt = compute_dtype_for(x, self.compute_dtype)
         w = self.proj.weight
@@ -55,6 +55,10 @@ class Block(nn.Module):
             w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, pad))
         x = ops.to_nhwc(x if x.dtype == dt else x.to(dt))
         y = Conv3x3Fn.apply(x, w)
+        if scale_shift is not None:  # (scale, shift) of the time embedding, [B, C] or [B, C, 1, 1] (unet2.py:216-220)
+            scale, shift = (t.reshape(t.shape[0], -1) for t in scale_shift)
+            return GNSiLUModFn.apply(y, self.proj.bias, self.norm.weight, self.norm.bias, scale, shift,
+                                     self.norm.num_groups, self.norm.eps)
         return GNSiLUFn.apply(y, self.proj.bias, self.norm.weight, self.norm.bias, self.norm.num_groups,
                               self.norm.eps)
 
@@ -139,20 +143,39 @@ class _Attention(nn.Module):
         return self.to_out(AttentionFn.apply(self.to_qkv(x), self.heads, self.dim_head, self.scale))
 
 
+class _SinusoidalPosEmb(nn.Module):
+    """[B] -> [B, dim]: sin / cos of time * exp(-i log(10000) / (dim/2 - 1)) (unet2.py:161-173)"""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, t: Tensor) -> Tensor:
+        return ops.sinusoidal_emb(t, self.dim)
+
+
+def _linear(lin: nn.Linear, x: Tensor) -> Tensor:
+    return LinearFn.apply(x, lin.weight, lin.bias, 0, 0.0)
+
+
 class ResnetBlock(nn.Module):
-    """Block -> Block + (1x1 conv | identity) shortcut (unet2.py:227-243, without the time-embedding MLP)"""
+    """Block -> Block + (1x1 conv | identity) shortcut (unet2.py:227-243); with `time_emb_dim` the block owns
+    `mlp` = SiLU -> Linear(time_emb_dim, 2 dim_out), whose output modulates the first Block"""
 
     def __init__(self, dim, dim_out, *, time_emb_dim=None, groups=8):
         super().__init__()
-        if time_emb_dim is not None:
-            raise NotImplementedError("time embeddings are not used by the segmentation path")
-        self.mlp = None
+        self.mlp = (nn.Sequential(nn.SiLU(), nn.Linear(time_emb_dim, dim_out * 2))
+                    if time_emb_dim is not None else None)  # (parameter holders: forward runs cy_act_* / cy_linear_*)
         self.block1 = Block(dim, dim_out, groups=groups)
         self.block2 = Block(dim_out, dim_out, groups=groups)
         self.res_conv = _Conv2d(dim, dim_out, 1) if dim != dim_out else nn.Identity()
 
     def forward(self, x, time_emb=None):
-        h = self.block2(self.block1(x))
+        scale_shift = None
+        if self.mlp is not None and time_emb is not None:
+            e = _linear(self.mlp[1], ActFn.apply(time_emb, ops.ACT_SILU))
+            scale_shift = e.chunk(2, dim=1)
+        h = self.block2(self.block1(x, scale_shift=scale_shift))
         return h + self.res_conv(x).to(h.dtype)
 
 
@@ -160,31 +183,34 @@ class UNet2(nn.Module):
     def __init__(self, init_dim=None, num_classes=None, dim_mults=(1, 2, 4, 8), input_dim=3, dim=16,
                  with_time_emb=False, resnet_block_groups=8, learned_variance=False, **kwargs):
         super().__init__()
-        if with_time_emb:
-            raise NotImplementedError("time embeddings are not used by the segmentation path")
         self.channels = input_dim
         init_dim = init_dim if init_dim is not None else dim // 3 * 2
         self.init_conv = _Conv2d(input_dim, init_dim, 7, padding=3)
         dims = [init_dim] + [dim * m for m in dim_mults]
         in_out = list(zip(dims[:-1], dims[1:]))
-        self.time_mlp = None
+        if with_time_emb:  # (unet2.py:51-58)
+            td = dim * 4
+            self.time_mlp = nn.Sequential(_SinusoidalPosEmb(dim), nn.Linear(dim, td), nn.GELU(), nn.Linear(td, td))
+        else:
+            td = None
+            self.time_mlp = None
         g = resnet_block_groups
         n_res = len(in_out)
         self.downs, self.ups = nn.ModuleList([]), nn.ModuleList([])
         for i, (cin, cout) in enumerate(in_out):
             last = i >= n_res - 1
             self.downs.append(nn.ModuleList([
-                ResnetBlock(cin, cout, groups=g), ResnetBlock(cout, cout, groups=g),
+                ResnetBlock(cin, cout, time_emb_dim=td, groups=g), ResnetBlock(cout, cout, time_emb_dim=td, groups=g),
                 _Residual(_PreNorm(cout, _LinearAttention(cout))),
                 nn.Identity() if last else _Conv2d(cout, cout, 4, 2, 1)]))
         mid = dims[-1]
-        self.mid_block1 = ResnetBlock(mid, mid, groups=g)
+        self.mid_block1 = ResnetBlock(mid, mid, time_emb_dim=td, groups=g)
         self.mid_attn = _Residual(_PreNorm(mid, _Attention(mid)))
-        self.mid_block2 = ResnetBlock(mid, mid, groups=g)
+        self.mid_block2 = ResnetBlock(mid, mid, time_emb_dim=td, groups=g)
         for i, (cin, cout) in enumerate(reversed(in_out[1:])):
             last = i >= n_res - 1
             self.ups.append(nn.ModuleList([
-                ResnetBlock(cout * 2, cin, groups=g), ResnetBlock(cin, cin, groups=g),
+                ResnetBlock(cout * 2, cin, time_emb_dim=td, groups=g), ResnetBlock(cin, cin, time_emb_dim=td, groups=g),
                 _Residual(_PreNorm(cin, _LinearAttention(cin))),
                 nn.Identity() if last else _ConvTranspose2d(cin, cin, 4, 2, 1)]))
         self.out_dim = num_classes if num_classes is not None else input_dim * (2 if learned_variance else 1)
@@ -205,19 +231,26 @@ class UNet2(nn.Module):
 
     def forward(self, x, time=None):
         ops.require_gpu(x)
-        return self._forward(x)  # (the glue computes in f32 whatever the blocks' storage type is)
+        t = None
+        if self.time_mlp is not None:
+            if time is None:  # (the reference fails inside SinusoidalPosEmb here: unet2.py:104,166-171)
+                raise TypeError("UNet2(with_time_emb=True).forward needs `time` ([B] tensor)")
+            ops.require_gpu(time)
+            m = self.time_mlp
+            t = _linear(m[3], ActFn.apply(_linear(m[1], m[0](time)), ops.ACT_GELU))
+        return self._forward(x, t)  # (the glue computes in f32 whatever the blocks' storage type is)
 
-    def _forward(self, x):
+    def _forward(self, x, t=None):
         x = self.init_conv(x)
         skips = []
         for block1, block2, attn, down in self.downs:
-            x = attn(block2(block1(x)))
+            x = attn(block2(block1(x, t), t))
             skips.append(x)
             x = down(x)
-        x = self.mid_block2(self.mid_attn(self.mid_block1(x)))
+        x = self.mid_block2(self.mid_attn(self.mid_block1(x, t)), t)
         for block1, block2, attn, up in self.ups:
-            x = up(attn(block2(block1(torch.cat((x, skips.pop()), dim=1)))))
-        return self.final_conv(x)
+            x = up(attn(block2(block1(torch.cat((x, skips.pop()), dim=1), t), t)))
+        return self.final_conv(x)  # (final_conv's ResnetBlock has no time MLP: unet2.py:93-95)
 
     def switch_grad(self, **kwargs):
         from contextlib import nullcontext

@@ -1164,7 +1164,7 @@ int first_conv_blocks(long npix, int Cout, int W) {
 // ---------------------------------------------------------------------------
 extern "C" {
 
-int cy_abi_version(void) { return 11; }
+int cy_abi_version(void) { return 12; }
 const char* cy_build_arch(void) { return "gfx950"; }
 
 unsigned long long cy_stream_capture_id(void* stream) {

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256)
     gn_stats_finalize_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                              const float* __restrict__ gamma, const float* __restrict__ beta,
                              float* __restrict__ mean_rstd, float* __restrict__ xcoef, int N, int C, int G, int HW,
-                             float eps) {
+                             float eps, const float* __restrict__ mod_s, const float* __restrict__ mod_t) {
   __shared__ double s1s[256], s2s[256];
   const int n = blockIdx.x / G, g = blockIdx.x - n * G, cg = C / G;
   const int tid = threadIdx.x;
@@ -147,9 +147,17 @@ __global__ void __launch_bounds__(256)
   }
   for (int cl = tid; cl < cg; cl += 256) {
     const int c = g * cg + cl;
-    const float a = gamma[c] * frstd;
+    // time-embedding modulation (ResnetBlock, arch/unet2.py:216-220: v * (scale + 1) + shift after the norm) = a
+    // per-(image, channel) affine: gamma' = gamma (1 + s), beta' = beta (1 + s) + t
+    float gm = gamma[c], bt = beta[c];
+    if (mod_s) {
+      const float s1 = 1.f + mod_s[(size_t)n * C + c];
+      gm *= s1;
+      bt = fmaf(bt, s1, mod_t[(size_t)n * C + c]);
+    }
+    const float a = gm * frstd;
     xcoef[((size_t)n * 2 + 0) * C + c] = a;
-    xcoef[((size_t)n * 2 + 1) * C + c] = fmaf((bias ? bias[c] : 0.f) - fmean, a, beta[c]);
+    xcoef[((size_t)n * 2 + 1) * C + c] = fmaf((bias ? bias[c] : 0.f) - fmean, a, bt);
   }
 }
 
@@ -187,15 +195,22 @@ __global__ void __launch_bounds__(256)
 // fetching five scalars per element
 __global__ void __launch_bounds__(256)
     gn_bwd_coef_kernel(const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
-                       const float* __restrict__ mean_rstd, float* __restrict__ xt, int N, int C, int G) {
+                       const float* __restrict__ mean_rstd, float* __restrict__ xt, int N, int C, int G,
+                       const float* __restrict__ mod_s, const float* __restrict__ mod_t) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= N * C) return;
   const int n = e / C, c = e - n * C;
   const float* mr = mean_rstd + 2 * ((size_t)n * G + c / (C / G));
   const float rstd = mr[1], bh = ((bias ? bias[c] : 0.f) - mr[0]) * rstd;
   float* t = xt + (size_t)n * 4 * C + c;
-  t[0] = gamma[c] * rstd;
-  t[C] = fmaf(gamma[c], bh, beta[c]);
+  float gm = gamma[c], bt = beta[c];
+  if (mod_s) {
+    const float s1 = 1.f + mod_s[e];
+    gm *= s1;
+    bt = fmaf(bt, s1, mod_t[e]);
+  }
+  t[0] = gm * rstd;
+  t[C] = fmaf(gm, bh, bt);
   t[2 * C] = rstd;
   t[3 * C] = bh;
 }
@@ -225,7 +240,7 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(64)
     gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                            const float* __restrict__ mean_rstd, float* __restrict__ coef,
-                           float* __restrict__ pgrad, int N, int C, int G, int HW) {
+                           float* __restrict__ pgrad, int N, int C, int G, int HW, const float* __restrict__ mod_s) {
   __shared__ double sA[64], sB[64];
   __shared__ double sa[2048 / 8], sb[2048 / 8], sx[2048 / 8];  // per-channel sums (cg <= 256)
   const int n = blockIdx.x / G, g = blockIdx.x - n * G, cg = C / G;
@@ -241,8 +256,9 @@ __global__ void __launch_bounds__(64)
       x += (double)p[2 * C + c];
     }
     sa[cl] = a, sb[cl] = b, sx[cl] = x;
-    tA += (double)gamma[c] * a;
-    tB += (double)gamma[c] * b;
+    const double gme = (double)(mod_s ? gamma[c] * (1.f + mod_s[(size_t)n * C + c]) : gamma[c]);  // (the effective gamma)
+    tA += gme * a;
+    tB += gme * b;
   }
   sA[tid] = tA, sB[tid] = tB;
   __syncthreads();
@@ -256,25 +272,36 @@ __global__ void __launch_bounds__(64)
   for (int cl = tid; cl < cg; cl += 64) {
     const int c = g * cg + cl;
     float* k = coef + (size_t)n * 3 * C + c;  // [n][k0 | k1 | k2][C]
+    const double gme = (double)(mod_s ? gamma[c] * (1.f + mod_s[(size_t)n * C + c]) : gamma[c]);
     k[0] = (float)(-rstd * m1);
-    k[C] = (float)(rstd * (double)gamma[c]);
+    k[C] = (float)(rstd * gme);
     k[2 * C] = (float)(-rstd * m2);
     float* pg = pgrad + ((size_t)n * C + c) * 3;
-    pg[0] = (float)sb[cl];                                                       // dgamma_n
-    pg[1] = (float)sa[cl];                                                       // dbeta_n
-    pg[2] = (float)(rstd * ((double)gamma[c] * sa[cl] - HW * m1 - m2 * sx[cl]));  // dbias_n
+    pg[0] = (float)sb[cl];                                                       // dgamma_n (of the effective gamma)
+    pg[1] = (float)sa[cl];                                                       // dbeta_n  (of the effective beta)
+    pg[2] = (float)(rstd * (gme * sa[cl] - HW * m1 - m2 * sx[cl]));               // dbias_n
   }
 }
 
 __global__ void __launch_bounds__(256)
     gn_param_grad_kernel(const float* __restrict__ pgrad, float* __restrict__ dgamma,
                          float* __restrict__ dbeta, float* __restrict__ dbias, int N, int C,
-                         int accumulate) {
+                         int accumulate, const float* __restrict__ mod_s, const float* __restrict__ gamma,
+                         const float* __restrict__ beta, float* __restrict__ dmod_s, float* __restrict__ dmod_t) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   double s[3] = {0.0, 0.0, 0.0};
-  for (int n = 0; n < N; ++n)
-    for (int v = 0; v < 3; ++v) s[v] += (double)pgrad[((size_t)n * C + c) * 3 + v];
+  for (int n = 0; n < N; ++n) {
+    // with the modulation v = (gamma x^ + beta)(1 + s) + t: dgamma = sum_n (1 + s) dgamma'_n, dbeta likewise,
+    // ds_n = gamma dgamma'_n + beta dbeta'_n, dt_n = dbeta'_n
+    const float* pg = pgrad + ((size_t)n * C + c) * 3;
+    const double w = mod_s ? 1.0 + (double)mod_s[(size_t)n * C + c] : 1.0;
+    s[0] += w * (double)pg[0];
+    s[1] += w * (double)pg[1];
+    s[2] += (double)pg[2];
+    if (dmod_s) dmod_s[(size_t)n * C + c] = gamma[c] * pg[0] + beta[c] * pg[1];
+    if (dmod_t) dmod_t[(size_t)n * C + c] = pg[1];
+  }
   float* dst[3] = {dgamma, dbeta, dbias};
   for (int v = 0; v < 3; ++v)
     if (dst[v]) dst[v][c] = accumulate ? dst[v][c] + (float)s[v] : (float)s[v];
@@ -348,9 +375,10 @@ size_t cy_gn_ws_bytes(int N, int C) {
   return ((size_t)N * GN_SPLIT * 3 * C + 10 * (size_t)N * C) * sizeof(float);
 }
 
-int cy_gn_silu_fwd(const void* y, int ldy, const float* bias, const float* gamma, const float* beta,
-                   void* out, int ldo, float* mean_rstd, int N, int HW, int C, int G, float eps,
-                   int dtype, void* ws, size_t ws_bytes, void* stream) {
+static int gn_silu_fwd_impl(const void* y, int ldy, const float* bias, const float* gamma, const float* beta,
+                            const float* mod_s, const float* mod_t, void* out, int ldo, float* mean_rstd, int N, int HW,
+                            int C, int G, float eps, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  if ((mod_s == nullptr) != (mod_t == nullptr)) return CY_ERR_ARG;
   if (!y || !gamma || !beta || !out || !mean_rstd || N <= 0 || HW <= 0) return CY_ERR_ARG;
   if (C % 8 || G <= 0 || C % G || ldy % 8 || ldo % 8 || ldy < C || ldo < C || C / G > 256 || C > 2048)
     return CY_ERR_SHAPE;
@@ -366,7 +394,7 @@ int cy_gn_silu_fwd(const void* y, int ldy, const float* bias, const float* gamma
                        ldy, bias, HW, C, part);
     CY_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(N * G), dim3(256), 0, st, (const float*)part, bias, gamma, beta,
-                       mean_rstd, xcoef, N, C, G, HW, eps);
+                       mean_rstd, xcoef, N, C, G, HW, eps, mod_s, mod_t);
     CY_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_silu_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, ldy,
                        (const float*)xcoef, (bf16*)out, ldo, N, HW, C);
@@ -375,7 +403,7 @@ int cy_gn_silu_fwd(const void* y, int ldy, const float* bias, const float* gamma
                        ldy, bias, HW, C, part);
     CY_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(N * G), dim3(256), 0, st, (const float*)part, bias, gamma, beta,
-                       mean_rstd, xcoef, N, C, G, HW, eps);
+                       mean_rstd, xcoef, N, C, G, HW, eps, mod_s, mod_t);
     CY_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_silu_apply_kernel<f16>, dim3(grid), dim3(256), 0, st, (const f16*)y, ldy,
                        (const float*)xcoef, (f16*)out, ldo, N, HW, C);
@@ -384,7 +412,7 @@ int cy_gn_silu_fwd(const void* y, int ldy, const float* bias, const float* gamma
                        (const float*)y, ldy, bias, HW, C, part);
     CY_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(N * G), dim3(256), 0, st, (const float*)part, bias, gamma, beta,
-                       mean_rstd, xcoef, N, C, G, HW, eps);
+                       mean_rstd, xcoef, N, C, G, HW, eps, mod_s, mod_t);
     CY_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_silu_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y,
                        ldy, (const float*)xcoef, (float*)out, ldo, N, HW, C);
@@ -393,10 +421,27 @@ int cy_gn_silu_fwd(const void* y, int ldy, const float* bias, const float* gamma
   return CY_OK;
 }
 
-int cy_gn_silu_bwd(const void* y, int ldy, const void* dz, int ldd, const float* bias,
-                   const float* gamma, const float* beta, const float* mean_rstd, void* du, int ldu,
-                   float* dgamma, float* dbeta, float* dbias, int accumulate, int N, int HW, int C,
-                   int G, int dtype, void* ws, size_t ws_bytes, void* stream) {
+int cy_gn_silu_fwd(const void* y, int ldy, const float* bias, const float* gamma, const float* beta,
+                   void* out, int ldo, float* mean_rstd, int N, int HW, int C, int G, float eps,
+                   int dtype, void* ws, size_t ws_bytes, void* stream) {
+  return gn_silu_fwd_impl(y, ldy, bias, gamma, beta, nullptr, nullptr, out, ldo, mean_rstd, N, HW, C, G, eps, dtype, ws,
+                          ws_bytes, stream);
+}
+
+int cy_gn_silu_mod_fwd(const void* y, int ldy, const float* bias, const float* gamma, const float* beta,
+                       const float* mod_scale, const float* mod_shift, void* out, int ldo, float* mean_rstd, int N,
+                       int HW, int C, int G, float eps, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  if (!mod_scale || !mod_shift) return CY_ERR_ARG;
+  return gn_silu_fwd_impl(y, ldy, bias, gamma, beta, mod_scale, mod_shift, out, ldo, mean_rstd, N, HW, C, G, eps, dtype,
+                          ws, ws_bytes, stream);
+}
+
+static int gn_silu_bwd_impl(const void* y, int ldy, const void* dz, int ldd, const float* bias,
+                            const float* gamma, const float* beta, const float* mod_s, const float* mod_t,
+                            const float* mean_rstd, void* du, int ldu, float* dgamma, float* dbeta, float* dbias,
+                            float* dmod_s, float* dmod_t, int accumulate, int N, int HW, int C, int G, int dtype,
+                            void* ws, size_t ws_bytes, void* stream) {
+  if ((mod_s == nullptr) != (mod_t == nullptr) || (!mod_s && (dmod_s || dmod_t))) return CY_ERR_ARG;
   if (!y || !dz || !gamma || !beta || !mean_rstd || !du || N <= 0 || HW <= 0) return CY_ERR_ARG;
   if (C % 8 || G <= 0 || C % G || ldy % 8 || ldd % 8 || ldu % 8 || ldy < C || ldd < C || ldu < C ||
       C / G > 256 || C > 2048)
@@ -411,7 +456,7 @@ int cy_gn_silu_bwd(const void* y, int ldy, const void* dz, int ldd, const float*
   const size_t smem = reduce_smem(C, 3);
   const int grid = grid_for((long)N * HW * (C / 8));
   hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(cy_cdiv((long)N * C, 256)), dim3(256), 0, st, bias, gamma, beta,
-                     mean_rstd, xt, N, C, G);
+                     mean_rstd, xt, N, C, G, mod_s, mod_t);
   CY_CHECK_LAUNCH();
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16>, dim3(GN_SPLIT, N), dim3(256), smem, st,
@@ -424,11 +469,11 @@ int cy_gn_silu_bwd(const void* y, int ldy, const void* dz, int ldd, const float*
                        (const float*)y, ldy, (const float*)dz, ldd, (const float*)xt, HW, C, part);
   CY_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N * G), dim3(64), 0, st, (const float*)part, gamma,
-                     mean_rstd, coef, pgrad, N, C, G, HW);
+                     mean_rstd, coef, pgrad, N, C, G, HW, mod_s);
   CY_CHECK_LAUNCH();
-  if (dgamma || dbeta || dbias) {
+  if (dgamma || dbeta || dbias || dmod_s || dmod_t) {
     hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cy_cdiv(C, 256)), dim3(256), 0, st,
-                       (const float*)pgrad, dgamma, dbeta, dbias, N, C, accumulate);
+                       (const float*)pgrad, dgamma, dbeta, dbias, N, C, accumulate, mod_s, gamma, beta, dmod_s, dmod_t);
     CY_CHECK_LAUNCH();
   }
   if (dtype == CY_BF16)
@@ -442,6 +487,24 @@ int cy_gn_silu_bwd(const void* y, int ldy, const void* dz, int ldd, const float*
                        (const float*)dz, ldd, (const float*)xt, (const float*)coef, (float*)du, ldu, N, HW, C);
   CY_CHECK_LAUNCH();
   return CY_OK;
+}
+
+int cy_gn_silu_bwd(const void* y, int ldy, const void* dz, int ldd, const float* bias,
+                   const float* gamma, const float* beta, const float* mean_rstd, void* du, int ldu,
+                   float* dgamma, float* dbeta, float* dbias, int accumulate, int N, int HW, int C,
+                   int G, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  return gn_silu_bwd_impl(y, ldy, dz, ldd, bias, gamma, beta, nullptr, nullptr, mean_rstd, du, ldu, dgamma, dbeta, dbias,
+                          nullptr, nullptr, accumulate, N, HW, C, G, dtype, ws, ws_bytes, stream);
+}
+
+int cy_gn_silu_mod_bwd(const void* y, int ldy, const void* dz, int ldd, const float* bias, const float* gamma,
+                       const float* beta, const float* mod_scale, const float* mod_shift, const float* mean_rstd,
+                       void* du, int ldu, float* dgamma, float* dbeta, float* dbias, float* dmod_scale,
+                       float* dmod_shift, int accumulate, int N, int HW, int C, int G, int dtype, void* ws,
+                       size_t ws_bytes, void* stream) {
+  if (!mod_scale || !mod_shift) return CY_ERR_ARG;
+  return gn_silu_bwd_impl(y, ldy, dz, ldd, bias, gamma, beta, mod_scale, mod_shift, mean_rstd, du, ldu, dgamma, dbeta,
+                          dbias, dmod_scale, dmod_shift, accumulate, N, HW, C, G, dtype, ws, ws_bytes, stream);
 }
 
 int cy_bilinear_fwd(const void* x, void* out, int N, int H, int W, int C, int h, int w, int dtype,

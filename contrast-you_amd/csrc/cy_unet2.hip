@@ -401,9 +401,69 @@ inline int grid_for(long total) {
 
 inline MatL to_l(const cy_mat_layout* l) { return MatL{l->rs, l->cs, l->s1, l->s2}; }
 
+// ---- the time embedding of UNet2 (arch/unet2.py:51-58,161-173,230-231): a [B, dim] table and two tiny MLPs ----------
+// out[b][i] = sin(t_b e_i), out[b][half + i] = cos(t_b e_i), e_i = exp(-i log(10000) / (half - 1))   (SinusoidalPosEmb)
+__global__ void __launch_bounds__(256) sinusoidal_emb_kernel(const float* __restrict__ t, float* __restrict__ out, int B, int dim) {
+  const int half = dim / 2;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * half) return;
+  const int b = e / half, i = e - b * half;
+  const float f = expf((float)i * -(logf(10000.f) / (float)(half - 1)));
+  const float a = t[b] * f;
+  out[(size_t)b * dim + i] = sinf(a);
+  out[(size_t)b * dim + half + i] = cosf(a);
+}
+
+// kind 0: SiLU (x sigmoid(x)), kind 1: GELU (exact: x Phi(x), nn.GELU() default)
+__device__ __forceinline__ float act_f(float x, int kind) {
+  if (kind == 0) return x / (1.f + expf(-x));
+  return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float act_df(float x, int kind) {
+  if (kind == 0) {
+    const float s = 1.f / (1.f + expf(-x));
+    return s * (1.f + x * (1.f - s));
+  }
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * expf(-0.5f * x * x);
+}
+__global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int kind) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) y[i] = act_f(x[i], kind);
+}
+__global__ void __launch_bounds__(256)
+    act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n, int kind) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) dx[i] = dy[i] * act_df(x[i], kind);
+}
+
 }  // namespace
 
 extern "C" {
+
+int cy_sinusoidal_emb(const float* time, float* out, int B, int dim, void* stream) {
+  if (!time || !out || B <= 0) return CY_ERR_ARG;
+  if (dim < 4 || dim % 2) return CY_ERR_SHAPE;
+  hipLaunchKernelGGL(sinusoidal_emb_kernel, dim3(cy_cdiv(B * (dim / 2), 256)), dim3(256), 0, (hipStream_t)stream, time, out, B, dim);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_act_fwd(const float* x, float* y, long n, int kind, void* stream) {
+  if (!x || !y || n <= 0) return CY_ERR_ARG;
+  if (kind != 0 && kind != 1) return CY_ERR_SHAPE;
+  long b = (n + 255) / 256;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3((int)(b > 4096 ? 4096 : b)), dim3(256), 0, (hipStream_t)stream, x, y, n, kind);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
+int cy_act_bwd(const float* x, const float* dy, float* dx, long n, int kind, void* stream) {
+  if (!x || !dy || !dx || n <= 0) return CY_ERR_ARG;
+  if (kind != 0 && kind != 1) return CY_ERR_SHAPE;
+  long b = (n + 255) / 256;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((int)(b > 4096 ? 4096 : b)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, kind);
+  CY_CHECK_LAUNCH();
+  return CY_OK;
+}
+
 
 size_t cy_gemm_strided_ws_bytes(int M, int N, int nbatch, int ksplit) {
   return ksplit > 1 ? (size_t)nbatch * ksplit * M * N * sizeof(float) : 0;

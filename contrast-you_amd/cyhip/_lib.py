@@ -11,7 +11,7 @@ from pathlib import Path
 
 CY_F32, CY_BF16, CY_F16 = 0, 1, 2
 CY_SRC_DIRECT, CY_SRC_POOL2, CY_SRC_UP2 = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _ERRORS = {-1: "CY_ERR_ARG (bad/NULL argument)", -2: "CY_ERR_SHAPE (unsupported shape)",
            -3: "CY_ERR_DTYPE (unsupported dtype)", -4: "CY_ERR_LAUNCH (HIP launch failed)",
@@ -220,6 +220,10 @@ _SIGS = {
                                c_int, _P, c_size_t, _P]),
     "cy_gn_silu_bwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int,
                                c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "cy_gn_silu_mod_fwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_float,
+                                   c_int, _P, c_size_t, _P]),
+    "cy_gn_silu_mod_bwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int,
+                                   c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "cy_bilinear_fwd": (c_int, [_P, _P] + [c_int] * 7 + [_P]),
     "cy_gemm_strided_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "cy_gemm_strided": (c_int, [_P, _PML, _P, _PML, _P, _PML, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
@@ -238,6 +242,9 @@ _SIGS = {
     "cy_col_softmax_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cy_row_softmax_fwd": (c_int, [_P, c_long, c_int, _P]),
     "cy_row_softmax_bwd": (c_int, [_P, _P, c_long, c_int, _P]),
+    "cy_sinusoidal_emb": (c_int, [_P, _P, c_int, c_int, _P]),
+    "cy_act_fwd": (c_int, [_P, _P, c_long, c_int, _P]),
+    "cy_act_bwd": (c_int, [_P, _P, _P, c_long, c_int, _P]),
 }
 
 # functions whose int return is a count / size, not a status

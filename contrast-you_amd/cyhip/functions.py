@@ -979,6 +979,46 @@ class GNSiLUFn(torch.autograd.Function):
         return du, dbias, dg, dbt, None, None
 
 
+class GNSiLUModFn(torch.autograd.Function):
+    """GroupNorm(G, C)(y + bias) * (scale + 1) + shift -> SiLU: `Block.forward(x, scale_shift)` of the reference's
+    time-embedded ResnetBlock (arch/unet2.py:208-224,240-246); scale / shift are [N, C] (f32)"""
+
+    @staticmethod
+    def forward(ctx, y: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, scale: Tensor, shift: Tensor,
+                groups: int, eps: float):
+        y = ops.to_nhwc(y)
+        b = None if bias is None else bias.detach().float().contiguous()
+        gm, bt = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        ms, mt = scale.detach().float().contiguous(), shift.detach().float().contiguous()
+        out, mr = ops.gn_silu_mod_fwd(y, b, gm, bt, ms, mt, groups, eps)
+        ctx.save_for_backward(y, b, gm, bt, ms, mt, mr)
+        ctx.groups = groups
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        y, b, gm, bt, ms, mt, mr = ctx.saved_tensors
+        g = ops.to_nhwc(g if g.dtype == y.dtype else g.to(y.dtype))
+        du, dg, dbt, dbias, dms, dmt = ops.gn_silu_mod_bwd(y, g, b, gm, bt, ms, mt, mr, ctx.groups)
+        return du, dbias, dg, dbt, dms, dmt, None, None
+
+
+class ActFn(torch.autograd.Function):
+    """elementwise SiLU (kind 0) / exact GELU (kind 1) on a small f32 tensor (UNet2's time-embedding MLPs)"""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, kind: int):
+        x = x.float().contiguous()
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return ops.act_fwd(x, kind)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (x,) = ctx.saved_tensors
+        return ops.act_bwd(x, g.float().contiguous(), ctx.kind), None
+
+
 class Conv3x3Fn(torch.autograd.Function):
     """bias-free 3x3 convolution (stride 1, padding 1) on the implicit-GEMM kernels; NHWC in/out.
     Used by the GroupNorm block, whose conv bias is folded into the normalisation kernels."""

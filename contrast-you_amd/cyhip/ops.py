@@ -1721,6 +1721,64 @@ def gn_silu_bwd(y: Tensor, dz: Tensor, bias: Optional[Tensor], gamma: Tensor, be
     return du, dg, dbt, dbias
 
 
+def gn_silu_mod_fwd(y: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, mod_s: Tensor, mod_t: Tensor,
+                    groups: int, eps: float):
+    """gn_silu_fwd with the time-embedding modulation (x * (scale + 1) + shift between the norm and SiLU,
+    contrastyou/arch/unet2.py:216-220); mod_s / mod_t: f32 [N, C]"""
+    require_gpu(y, gamma, beta, mod_s, mod_t)
+    N, Cc, H, W = y.shape
+    out = empty_nhwc(N, Cc, H, W, y.dtype, y.device)
+    mr = _f32(N * groups * 2, y.device)
+    nbytes = _lib.load().cy_gn_ws_bytes(N, Cc)
+    ws = _ws(nbytes, y.device)
+    _lib.call("cy_gn_silu_mod_fwd", y.data_ptr(), Cc, _ptr(bias), gamma.data_ptr(), beta.data_ptr(), mod_s.data_ptr(),
+              mod_t.data_ptr(), out.data_ptr(), Cc, mr.data_ptr(), N, H * W, Cc, groups, eps, dtype_code(y.dtype),
+              ws.data_ptr(), nbytes, _stream())
+    return out, mr
+
+
+def gn_silu_mod_bwd(y: Tensor, dz: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, mod_s: Tensor,
+                    mod_t: Tensor, mr: Tensor, groups: int):
+    N, Cc, H, W = y.shape
+    du = empty_nhwc(N, Cc, H, W, y.dtype, y.device)
+    dg, dbt = _f32(Cc, y.device), _f32(Cc, y.device)
+    dbias = _f32(Cc, y.device) if bias is not None else None
+    dms, dmt = _f32(N * Cc, y.device).view(N, Cc), _f32(N * Cc, y.device).view(N, Cc)
+    nbytes = _lib.load().cy_gn_ws_bytes(N, Cc)
+    ws = _ws(nbytes, y.device)
+    _lib.call("cy_gn_silu_mod_bwd", y.data_ptr(), Cc, dz.data_ptr(), Cc, _ptr(bias), gamma.data_ptr(), beta.data_ptr(),
+              mod_s.data_ptr(), mod_t.data_ptr(), mr.data_ptr(), du.data_ptr(), Cc, dg.data_ptr(), dbt.data_ptr(),
+              _ptr(dbias), dms.data_ptr(), dmt.data_ptr(), 0, N, H * W, Cc, groups, dtype_code(y.dtype), ws.data_ptr(),
+              nbytes, _stream())
+    return du, dg, dbt, dbias, dms, dmt
+
+
+ACT_SILU, ACT_GELU = 0, 1
+
+
+def act_fwd(x: Tensor, kind: int) -> Tensor:
+    """elementwise SiLU / exact GELU of a small f32 tensor (the time-embedding MLPs of UNet2)"""
+    require_gpu(x)
+    y = torch.empty_like(x)
+    _lib.call("cy_act_fwd", x.data_ptr(), y.data_ptr(), x.numel(), kind, _stream())
+    return y
+
+
+def act_bwd(x: Tensor, dy: Tensor, kind: int) -> Tensor:
+    dx = torch.empty_like(x)
+    _lib.call("cy_act_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), kind, _stream())
+    return dx
+
+
+def sinusoidal_emb(time: Tensor, dim: int) -> Tensor:
+    """SinusoidalPosEmb(dim)(time) (contrastyou/arch/unet2.py:161-173): [B] -> [B, dim]"""
+    require_gpu(time)
+    t = time.detach().float().contiguous()
+    out = _f32(t.numel() * dim, t.device).view(t.numel(), dim)
+    _lib.call("cy_sinusoidal_emb", t.data_ptr(), out.data_ptr(), t.numel(), dim, _stream())
+    return out
+
+
 def bilinear_fwd(x: Tensor, size: Tuple[int, int]) -> Tensor:
     require_gpu(x)
     x = to_nhwc(x)

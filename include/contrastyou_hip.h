@@ -644,6 +644,17 @@ int cy_gn_silu_bwd(const void* y, int ldy, const void* dz, int ldd, const float*
                    const float* gamma, const float* beta, const float* mean_rstd, void* du, int ldu,
                    float* dgamma, float* dbeta, float* dbias, int accumulate, int N, int HW, int C,
                    int G, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* The same with the time-embedding modulation of ResnetBlock / Block (contrastyou/arch/unet2.py:216-220,240-246):
+ * out = SiLU(GroupNorm(y + bias) * (mod_scale[n][c] + 1) + mod_shift[n][c]); mod_* are f32 [N][C].  Backward also gives
+ * dmod_scale / dmod_shift [N][C] (NULL to skip). */
+int cy_gn_silu_mod_fwd(const void* y, int ldy, const float* bias, const float* gamma, const float* beta,
+                       const float* mod_scale, const float* mod_shift, void* out, int ldo, float* mean_rstd, int N,
+                       int HW, int C, int G, float eps, int dtype, void* ws, size_t ws_bytes, void* stream);
+int cy_gn_silu_mod_bwd(const void* y, int ldy, const void* dz, int ldd, const float* bias, const float* gamma,
+                       const float* beta, const float* mod_scale, const float* mod_shift, const float* mean_rstd,
+                       void* du, int ldu, float* dgamma, float* dbeta, float* dbias, float* dmod_scale,
+                       float* dmod_shift, int accumulate, int N, int HW, int C, int G, int dtype, void* ws,
+                       size_t ws_bytes, void* stream);
 /* F.interpolate(x, size=(h,w), mode="bilinear", align_corners=False) on an NHWC
  * tensor (semi_seg/hooks/cc.py:132, ccblock.py:300). */
 int cy_bilinear_fwd(const void* x, void* out, int N, int H, int W, int C, int h, int w, int dtype,
@@ -705,6 +716,11 @@ int cy_col_softmax_bwd(const float* y, const float* dy, const float* t, float* d
 /* softmax of every row of x [rows][n], in place; backward: dp <- p * (dp - sum_j p * dp) */
 int cy_row_softmax_fwd(float* x, long rows, int n, void* stream);
 int cy_row_softmax_bwd(const float* p, float* dp, long rows, int n, void* stream);
+/* UNet2's time embedding (contrastyou/arch/unet2.py:51-58,161-173,230-231): SinusoidalPosEmb(dim) of time [B] ->
+ * out [B][dim] (sin half, cos half); elementwise SiLU (kind 0) / exact GELU (kind 1) of the embedding MLPs, f32 */
+int cy_sinusoidal_emb(const float* time, float* out, int B, int dim, void* stream);
+int cy_act_fwd(const float* x, float* y, long n, int kind, void* stream);
+int cy_act_bwd(const float* x, const float* dy, float* dx, long n, int kind, void* stream);
 
 #ifdef __cplusplus
 }

@@ -367,8 +367,39 @@ def gen_round4(scratch):
     np.savez_compressed(OUT / "round4.npz", **out)
 
 
+def gen_round4_unet2_time(scratch):
+    """UNet2(with_time_emb=True) (contrastyou/arch/unet2.py:51-58,101-119,161-173,227-246) -> round4_unet2_time.npz:
+    the reference's own state dict, outputs and a sample of parameter gradients for an image batch and a time vector"""
+    from contrastyou.arch.unet2 import UNet2
+
+    g = torch.Generator().manual_seed(4242)
+    out = {}
+    torch.manual_seed(987)
+    net = UNet2(input_dim=1, num_classes=4, dim=8, with_time_emb=True)
+    for k, v in net.state_dict().items():
+        out[f"sd_{k}"] = npy(v)
+    x = torch.rand(2, 1, 32, 32, generator=g)
+    t = torch.tensor([3.0, 11.0])
+    y = net(x, t)
+    (y * torch.linspace(-1, 1, y.numel()).view_as(y)).sum().backward()
+    out["x"], out["time"], out["y"] = npy(x), npy(t), npy(y)
+    params = dict(net.named_parameters())
+    for name in ("init_conv.weight", "time_mlp.1.weight", "time_mlp.3.bias", "downs.0.0.mlp.1.weight",
+                 "downs.0.0.block1.norm.weight", "downs.0.0.block1.norm.bias", "downs.0.0.block1.proj.bias",
+                 "downs.2.1.mlp.1.bias", "mid_block1.mlp.1.weight", "mid_block2.block1.proj.weight",
+                 "ups.1.1.mlp.1.weight", "ups.2.0.block1.norm.weight", "final_conv.1.bias"):
+        out[f"grad_{name}"] = npy(params[name].grad)
+    np.savez_compressed(OUT / "round4_unet2_time.npz", **out)
+
+
 def main():
     sys.path.insert(0, str(REPO))
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "round4t":
+        scratch = setup_reference()
+        gen_round4_unet2_time(scratch)
+        shutil.rmtree(scratch, ignore_errors=True)
+        print("wrote round4_unet2_time.npz")
+        return
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "round4":
         scratch = setup_reference()
         gen_round4(scratch)
@@ -501,6 +532,7 @@ def main():
     gen_round2(scratch)
     gen_round3(scratch)
     gen_round4(scratch)
+    gen_round4_unet2_time(scratch)
     shutil.rmtree(scratch, ignore_errors=True)
     print("wrote", sorted(p.name for p in OUT.glob("*.npz")))
 
