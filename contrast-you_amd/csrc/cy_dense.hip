@@ -411,8 +411,8 @@ int cy_dense_proj_fwd(const void* x, const float* w1, const float* b1, const int
   hipStream_t st = (hipStream_t)stream;
   if (dpm_applicable(dtype, C, hid, slope)) {
     if (dtype == CY_BF16)
-      return dpm_launch_fwd<bf16>((const bf16*)x, w1, b1, bins, nb, hpool, H, W, ldx, hid, sh, sw, slope, st);
-    return dpm_launch_fwd<f16>((const f16*)x, w1, b1, bins, nb, hpool, H, W, ldx, hid, sh, sw, slope, st);
+      return dpm_launch_fwd<bf16>((const bf16*)x, w1, b1, bins, nb, hpool, H, W, ldx, C, hid, sh, sw, slope, st);
+    return dpm_launch_fwd<f16>((const f16*)x, w1, b1, bins, nb, hpool, H, W, ldx, C, hid, sh, sw, slope, st);
   }
   if (dtype == CY_BF16)
     hipLaunchKernelGGL(dense_proj_fwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)x, w1,
@@ -451,9 +451,9 @@ int cy_dense_proj_bwd(const void* x, const float* w1, const float* b1, const int
   if (dpm_applicable(dtype, C, hid, slope)) {
     if (dtype == CY_BF16)
       return dpm_launch_bwd<bf16>((const bf16*)x, w1, b1, bins, nb, dhpool, (bf16*)dx, dw1, db1, accumulate, N, H, W,
-                                  ldx, hid, sh, sw, slope, (float*)ws, st);
+                                  ldx, C, hid, sh, sw, slope, (float*)ws, st);
     return dpm_launch_bwd<f16>((const f16*)x, w1, b1, bins, nb, dhpool, (f16*)dx, dw1, db1, accumulate, N, H, W, ldx,
-                               hid, sh, sw, slope, (float*)ws, st);
+                               C, hid, sh, sw, slope, (float*)ws, st);
   }
   const int G = dp_bwd_blocks(nb);
   const size_t slot = (size_t)hid * C + hid;

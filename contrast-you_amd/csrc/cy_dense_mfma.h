@@ -1,6 +1,11 @@
-// Matrix-core forms of the dense projector (cy_dense.hip) for 16-bit feature maps with C = 32 channels and
-// 128 or 256 hidden units -- the geometry of the dense InfoNCE hook (Up_conv2 features,
-// config/hooks/infonce_dense.yaml; contrastyou/projectors/heads.py:31-41,99-123).
+// Matrix-core forms of the dense projector (cy_dense.hip) for 16-bit feature maps with C = 32, 64 or 128 channels and
+// 128 or 256 hidden units -- the geometry of the dense InfoNCE hook (Up_conv2 features at max_channel 512,
+// config/hooks/infonce_dense.yaml; Up_conv3 / Up_conv4 = 64 / 128 channels, the former in the pre-training scripts;
+// contrastyou/projectors/heads.py:31-41,99-123).  The kernels were written for C = 32; with CB = C / 32 channel
+// blocks the pre-activations accumulate over the blocks (rows and the W1 image carry a block index) and the backward
+// kernels' second product (dW1, dx) is done for ONE selected block per launch (`cbs`): CB launches, each recomputing
+// the cheap pre-activations, instead of the VALU kernels' 9-15 ms.  (C = 256 would need 192 registers of rows in
+// flight: it stays on the VALU kernels.)
 //
 // No workgroup-level cooperation: a WAVE owns a job (a bin, or a cell of the bin partition) and walks its
 // pixels 32 at a time.  The 1x1 convolution of a block of 32 pixels is 2 x (hid/32) MFMAs whose operands need no
@@ -114,27 +119,30 @@ __device__ __forceinline__ DpJob dpm_cell_job(int idx, int sh, int sw, int H, in
 }
 
 // A fragments (both k-steps) of pixel row `blk*32 + r` of the job; rows past the job's last pixel read as zero
-template <typename T>
+template <typename T, int CB>
 __device__ __forceinline__ void dpm_load_rows(const T* __restrict__ x, const DpJob& J, long pix0, float inv_bw,
-                                              int W, int ldx, int blk, int r, int h, u32x4 (&f)[2]) {
+                                              int W, int ldx, int blk, int r, int h, u32x4 (&f)[CB][2]) {
   const int q = blk * 32 + r;
   const bool ok = q < J.npx;
   const int qc = ok ? q : 0;
   const int qr = (int)(((float)qc + 0.5f) * inv_bw), qcol = qc - qr * J.bw;
   const T* p = x + (pix0 + (long)qr * W + qcol) * ldx + 8 * h;
-  f[0] = ld16(p);
-  f[1] = ld16(p + 16);
-  if (!ok) f[0] = f[1] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    f[cb][0] = ld16(p + 32 * cb);
+    f[cb][1] = ld16(p + 32 * cb + 16);
+    if (!ok) f[cb][0] = f[cb][1] = u32x4{0u, 0u, 0u, 0u};
+  }
 }
 
 // B fragments of W1 (f32 [hid][32], rounded to T): column = hidden unit o, k = channel 16*ks + 8h + i
 template <typename T>
-__device__ __forceinline__ void dpm_load_w(const float* __restrict__ w1, int o, int h, DpFrag<T> (&wf)[2]) {
+__device__ __forceinline__ void dpm_load_w(const float* __restrict__ w1, int C, int cb, int o, int h, DpFrag<T> (&wf)[2]) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     float f[8];
-    const f32x4 a = *reinterpret_cast<const f32x4*>(w1 + (size_t)o * 32 + ks * 16 + 8 * h);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(w1 + (size_t)o * 32 + ks * 16 + 8 * h + 4);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w1 + (size_t)o * C + cb * 32 + ks * 16 + 8 * h);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(w1 + (size_t)o * C + cb * 32 + ks * 16 + 8 * h + 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) f[i] = a[i], f[4 + i] = b[i];
     wf[ks] = dpm_frag<T>(Chunk<T>::pack(f));
@@ -218,38 +226,43 @@ __device__ __forceinline__ float dpm_rec_coef(const float* __restrict__ dhpool, 
   return (d0 * R.inv[0] + d1 * R.inv[1]) + (d2 * R.inv[2] + d3 * R.inv[3]);
 }
 
-template <typename T>
+template <typename T, int CB>
 __device__ __forceinline__ void dpm_rec_rows(const T* __restrict__ x, const DpRec& R, int W, int ldx, int blk, int r,
-                                             int h, u32x4 (&f)[2]) {
+                                             int h, u32x4 (&f)[CB][2]) {
   const int q = blk * 32 + r;
   const bool ok = q < R.npx;
   const int qc = ok ? q : 0;
   const int qr = (int)(((float)qc + 0.5f) * R.inv_bw), qcol = qc - qr * R.bw;
   const T* p = x + (R.pix0 + (long)qr * W + qcol) * ldx + 8 * h;
-  f[0] = ld16(p);
-  f[1] = ld16(p + 16);
-  if (!ok) f[0] = f[1] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    f[cb][0] = ld16(p + 32 * cb);
+    f[cb][1] = ld16(p + 32 * cb + 16);
+    if (!ok) f[cb][0] = f[cb][1] = u32x4{0u, 0u, 0u, 0u};
+  }
 }
 
 // W1 rounded to T as an LDS image [hid][32] (64-byte rows, dpm_xoff swizzle): the backward kernels read their B
 // fragments from it instead of pinning 4 registers per (32 units, k-step)
 __device__ __forceinline__ int dpm_xoff(int row, int slot);
-template <typename T>
+// (CB channel blocks: one such image per block, 256 * 64 bytes apart)
+template <typename T, int CB>
 __device__ __forceinline__ void dpm_stage_w(const float* __restrict__ w1, int hid, unsigned char* sw1) {
-  for (int idx = threadIdx.x; idx < hid * 4; idx += 256) {
-    const int row = idx >> 2, slot = idx & 3;
+  for (int idx = threadIdx.x; idx < CB * hid * 4; idx += 256) {
+    const int cb = idx / (hid * 4), rem = idx - cb * hid * 4;
+    const int row = rem >> 2, slot = rem & 3;
     float f[8];
-    const f32x4 a = *reinterpret_cast<const f32x4*>(w1 + (size_t)row * 32 + slot * 8);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(w1 + (size_t)row * 32 + slot * 8 + 4);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w1 + (size_t)row * (32 * CB) + cb * 32 + slot * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(w1 + (size_t)row * (32 * CB) + cb * 32 + slot * 8 + 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) f[i] = a[i], f[4 + i] = b[i];
-    st16(sw1 + dpm_xoff(row, slot), Chunk<T>::pack(f));
+    st16(sw1 + cb * (256 * 64) + dpm_xoff(row, slot), Chunk<T>::pack(f));
   }
 }
 
 // ------------------------------------------------------------------------------------------------ forward
 // hpool[bin][o] = mean over the bin's pixels of lrelu(W1 x + b1).  NHB 32-unit blocks of hidden units per wave.
-template <typename T, int NHB>
+template <typename T, int NHB, int CB>
 __global__ void __launch_bounds__(256, 2)
     dense_proj_mfma_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
                                const int32_t* __restrict__ bins, int nb, float* __restrict__ hpool, int H, int W,
@@ -262,11 +275,12 @@ __global__ void __launch_bounds__(256, 2)
   const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
   const int o0 = (gw % npass) * NHB * 32;
 
-  DpFrag<T> wf[NHB][2];
+  DpFrag<T> wf[NHB][CB][2];
   float bias[NHB], sbias[NHB], lbias[NHB];
 #pragma unroll
   for (int hb = 0; hb < NHB; ++hb) {
-    dpm_load_w<T>(w1, o0 + hb * 32 + r, h, wf[hb]);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) dpm_load_w<T>(w1, 32 * CB, cb, o0 + hb * 32 + r, h, wf[hb][cb]);
     bias[hb] = b1[o0 + hb * 32 + r];
     sbias[hb] = slope * bias[hb];
     lbias[hb] = fmaxf(bias[hb], sbias[hb]);
@@ -274,19 +288,19 @@ __global__ void __launch_bounds__(256, 2)
 
   const int stride = nw / npass;
   DpRun cur = dpm_run<false>(bins, gw / npass, nb, sh, sw, H, W, -1);
-  u32x4 f0[2], f1[2];
-  dpm_load_rows<T>(x, cur.J, cur.pix0, cur.inv_bw, W, ldx, 0, r, h, f0);
+  u32x4 f0[CB][2], f1[CB][2];
+  dpm_load_rows<T, CB>(x, cur.J, cur.pix0, cur.inv_bw, W, ldx, 0, r, h, f0);
   for (int b = gw / npass; b < nb; b += stride) {
     const DpRun nxt = dpm_run<false>(bins, b + stride, nb, sh, sw, H, W, -1);
-    u32x4 n0[2];
-    dpm_load_rows<T>(x, nxt.J, nxt.pix0, nxt.inv_bw, W, ldx, 0, r, h, n0);
+    u32x4 n0[CB][2];
+    dpm_load_rows<T, CB>(x, nxt.J, nxt.pix0, nxt.inv_bw, W, ldx, 0, r, h, n0);
     const DpJob& J = cur.J;
     const int nblk = cur.nblk;
     float sum[NHB];
 #pragma unroll
     for (int hb = 0; hb < NHB; ++hb) sum[hb] = 0.f;
 
-    auto block = [&](const u32x4 (&f)[2]) {
+    auto block = [&](const u32x4 (&f)[CB][2]) {
 #pragma unroll
       for (int hq = 0; hq < NHB / 2; ++hq) {  // two blocks of hidden units at a time: 32 accumulator registers live
         f32x16 acc[2];
@@ -295,9 +309,11 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;  // (a bias splat would pin 16 registers per block for the loop)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-          for (int k = 0; k < 2; ++k) M::mma(dpm_frag<T>(f[ks]), wf[2 * hq + k][ks], acc[k]);
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) M::mma(dpm_frag<T>(f[cb][ks]), wf[2 * hq + k][cb][ks], acc[k]);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -312,9 +328,9 @@ __global__ void __launch_bounds__(256, 2)
 
     // two register sets; every load is unconditional (a conditional one would turn the waits into vmcnt(0))
     for (int blk = 0; blk + 1 < nblk; blk += 2) {
-      dpm_load_rows<T>(x, J, cur.pix0, cur.inv_bw, W, ldx, blk + 1, r, h, f1);
+      dpm_load_rows<T, CB>(x, J, cur.pix0, cur.inv_bw, W, ldx, blk + 1, r, h, f1);
       block(f0);
-      dpm_load_rows<T>(x, J, cur.pix0, cur.inv_bw, W, ldx, min(blk + 2, nblk - 1), r, h, f0);
+      dpm_load_rows<T, CB>(x, J, cur.pix0, cur.inv_bw, W, ldx, min(blk + 2, nblk - 1), r, h, f0);
       block(f1);
     }
     if (nblk & 1) block(f0);
@@ -327,7 +343,8 @@ __global__ void __launch_bounds__(256, 2)
       if (h == 0) hpool[(size_t)b * hid + o0 + hb * 32 + r] = s * J.inv[0];
     }
     cur = nxt;
-    f0[0] = n0[0], f0[1] = n0[1];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) f0[cb][0] = n0[cb][0], f0[cb][1] = n0[cb][1];
   }
 }
 
@@ -339,16 +356,16 @@ __device__ __forceinline__ int dpm_goff(int row, int slot) { return row * 64 + (
 
 // dW1 / db1 partials: four 32-unit blocks of hidden units per workgroup (pass = blockIdx.x % (hid/128)),
 // each wave its own jobs; the workgroup adds its four waves through LDS and writes ONE partial.
-template <typename T, bool CELLS>
+template <typename T, bool CELLS, int CB>
 __global__ void __launch_bounds__(256, 2)
     dense_proj_mfma_dw_kernel(const T* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
                               const DpRec* __restrict__ recs, int njobs, const float* __restrict__ dhpool,
                               float* __restrict__ part, int H, int W, int ldx, int hid, int sh, int sw,
-                              float slope) {
+                              float slope, int cbs) {
   using M = Mma<T>;
   constexpr int HB = 4;
   __shared__ __attribute__((aligned(16))) float red[2 * DPM_PART];  // (the x tiles alias its head)
-  __shared__ __attribute__((aligned(16))) unsigned char sw1[256 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char sw1[CB * 256 * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -358,7 +375,7 @@ __global__ void __launch_bounds__(256, 2)
   const int slot = (blockIdx.x / npass) * 4 + wave, nslot = (gridDim.x / npass) * 4;
   unsigned char* sx = reinterpret_cast<unsigned char*>(red) + wave * 2048;
 
-  dpm_stage_w<T>(w1, hid, sw1);
+  dpm_stage_w<T, CB>(w1, hid, sw1);
   __syncthreads();
   float nbias[HB];
   int woff[2];  // fragment of (hidden unit o0 + r, k-step ks); + hb * 2048 bytes (the swizzle repeats every 16 rows)
@@ -396,23 +413,28 @@ __global__ void __launch_bounds__(256, 2)
   //  asserts run-to-run bit equality of dx, dW1 and db1 at 3-4 jobs per wave.)
   DpRec cur = dpm_rec(recs, slot, njobs, -1);
   float dpos[HB];
-  u32x4 f0[2], f1[2];
-  dpm_rec_rows<T>(x, cur, W, ldx, 0, r, h, f0);
+  u32x4 f0[CB][2], f1[CB][2];
+  dpm_rec_rows<T, CB>(x, cur, W, ldx, 0, r, h, f0);
   for (int job = slot; job < njobs; job += nslot) {
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) dpos[hb] = dpm_rec_coef(dhpool, cur, hid, o0 + hb * 32 + r);
     const DpRec nxt = dpm_rec(recs, job + nslot, njobs, -1);
-    u32x4 n0[2];
-    dpm_rec_rows<T>(x, nxt, W, ldx, 0, r, h, n0);
+    u32x4 n0[CB][2];
+    dpm_rec_rows<T, CB>(x, nxt, W, ldx, 0, r, h, n0);
     const DpRec& J = cur;
     const int nblk = cur.nblk;
     float dneg[HB];
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) dneg[hb] = slope * dpos[hb];
 
-    auto block = [&](const u32x4 (&f)[2]) {
-      st16(sx + dpm_xoff(r, h), f[0]);
-      st16(sx + dpm_xoff(r, 2 + h), f[1]);
+    auto block = [&](const u32x4 (&f)[CB][2]) {
+      // (the x tile of the second product: the selected channel block's 32 channels)
+      u32x4 s0 = f[0][0], s1 = f[0][1];
+#pragma unroll
+      for (int cb = 1; cb < CB; ++cb)
+        if (cbs == cb) s0 = f[cb][0], s1 = f[cb][1];
+      st16(sx + dpm_xoff(r, h), s0);
+      st16(sx + dpm_xoff(r, 2 + h), s1);
       __builtin_amdgcn_wave_barrier();
       DpFrag<T> xt[2];
 #pragma unroll
@@ -425,10 +447,12 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-          for (int k = 0; k < 2; ++k)
-            M::mma(dpm_frag<T>(f[ks]), dpm_frag<T>(ld16(sw1 + woff[ks] + (2 * hq + k) * 2048)), acc[k]);
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+              M::mma(dpm_frag<T>(f[cb][ks]), dpm_frag<T>(ld16(sw1 + cb * (256 * 64) + woff[ks] + (2 * hq + k) * 2048)), acc[k]);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int hb = 2 * hq + k;
@@ -448,9 +472,9 @@ __global__ void __launch_bounds__(256, 2)
     };
 
     for (int blk = 0; blk + 1 < nblk; blk += 2) {
-      dpm_rec_rows<T>(x, J, W, ldx, blk + 1, r, h, f1);
+      dpm_rec_rows<T, CB>(x, J, W, ldx, blk + 1, r, h, f1);
       block(f0);
-      dpm_rec_rows<T>(x, J, W, ldx, min(blk + 2, nblk - 1), r, h, f0);
+      dpm_rec_rows<T, CB>(x, J, W, ldx, min(blk + 2, nblk - 1), r, h, f0);
       block(f1);
     }
     if (nblk & 1) block(f0);
@@ -460,7 +484,8 @@ __global__ void __launch_bounds__(256, 2)
       db[hb] -= 0.5f * npad * (0.f > nbias[hb] ? dpos[hb] : dneg[hb]);
     }
     cur = nxt;
-    f0[0] = n0[0], f0[1] = n0[1];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) f0[cb][0] = n0[cb][0], f0[cb][1] = n0[cb][1];
   }
 
   // the workgroup's partial, in register order [e = hb*16 + reg | 64 + hb][lane]: (w0 + w2) + (w1 + w3)
@@ -498,7 +523,7 @@ __global__ void __launch_bounds__(256, 2)
 // dW1[o][c] / db1[o] <- sum over the workgroups of pass o/128, in workgroup order (bit-reproducible)
 __global__ void __launch_bounds__(256)
     dense_proj_mfma_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
-                                  int nwg, int npass, int accumulate) {
+                                  int nwg, int npass, int accumulate, int ldw, int coff) {
   __shared__ double sred[8][32];
   const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int E = blockIdx.x * 32 + el;  // element of [pass][68][64]
@@ -515,7 +540,7 @@ __global__ void __launch_bounds__(256)
   if (reg < 64) {
     const int hb = reg >> 4, i = reg & 15;
     const int o = pass * 128 + hb * 32 + r, c = (i & 3) + 8 * (i >> 2) + 4 * h;
-    if (dw) dw[(size_t)o * 32 + c] = accumulate ? dw[(size_t)o * 32 + c] + (float)s : (float)s;
+    if (dw) dw[(size_t)o * ldw + coff + c] = accumulate ? dw[(size_t)o * ldw + coff + c] + (float)s : (float)s;
   } else if (db && h == 0) {  // (both lane halves carry the unit's total)
     const int o = pass * 128 + (reg - 64) * 32 + r;
     db[o] = accumulate ? db[o] + (float)s : (float)s;
@@ -523,15 +548,15 @@ __global__ void __launch_bounds__(256)
 }
 
 // dx: all hidden units in one wave (NHB = hid/32 blocks, four at a time through the accumulators)
-template <typename T, int NHB, bool CELLS>
+template <typename T, int NHB, bool CELLS, int CB>
 __global__ void __launch_bounds__(256, 2)
     dense_proj_mfma_dx_kernel(const T* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
                               const DpRec* __restrict__ recs, int njobs, const float* __restrict__ dhpool,
                               T* __restrict__ dx, int H, int W, int ldx, int hid, int sh, int sw, float slope,
-                              int colour) {
+                              int colour, int cbs) {
   using M = Mma<T>;
   __shared__ __attribute__((aligned(16))) unsigned char sgall[4 * 128 * 64];  // per wave: g^T [128 units][32 pixels]
-  __shared__ __attribute__((aligned(16))) unsigned char sw1[256 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char sw1[CB * 256 * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -539,7 +564,7 @@ __global__ void __launch_bounds__(256, 2)
   const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
   unsigned char* sg = sgall + wave * (128 * 64);
 
-  dpm_stage_w<T>(w1, hid, sw1);  // pre-activations: B operand from LDS
+  dpm_stage_w<T, CB>(w1, hid, sw1);  // pre-activations: B operand from LDS
   __syncthreads();
   int woff[2];
 #pragma unroll
@@ -552,7 +577,7 @@ __global__ void __launch_bounds__(256, 2)
   for (int t = 0; t < NHB * 2; ++t) {
     float f[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = w1[(size_t)(16 * t + 8 * h + i) * 32 + r];
+    for (int i = 0; i < 8; ++i) f[i] = w1[(size_t)(16 * t + 8 * h + i) * (32 * CB) + cbs * 32 + r];  // (the selected block's channels)
     wt[t] = dpm_frag<T>(Chunk<T>::pack(f));
   }
   // transposed reads of the g tile: hidden units 16t + 8h + q (lo) / + 4 (hi), pixels 16*gsel + 4*p4 .. +3; the
@@ -569,18 +594,18 @@ __global__ void __launch_bounds__(256, 2)
   //  kernel's run-to-run differences with the coefficient loads in flight too, but the cause there is not understood)
   DpRec cur = dpm_rec(recs, gw, njobs, colour);
   float dpos[NHB];
-  u32x4 f0[2], f1[2];
-  dpm_rec_rows<T>(x, cur, W, ldx, 0, r, h, f0);
+  u32x4 f0[CB][2], f1[CB][2];
+  dpm_rec_rows<T, CB>(x, cur, W, ldx, 0, r, h, f0);
   for (int job = gw; job < njobs; job += nw) {
 #pragma unroll
     for (int hb = 0; hb < NHB; ++hb) dpos[hb] = dpm_rec_coef(dhpool, cur, hid, hb * 32 + r);
     const DpRec nxt = dpm_rec(recs, job + nw, njobs, colour);
-    u32x4 n0[2];
-    dpm_rec_rows<T>(x, nxt, W, ldx, 0, r, h, n0);
+    u32x4 n0[CB][2];
+    dpm_rec_rows<T, CB>(x, nxt, W, ldx, 0, r, h, n0);
     const DpRec& J = cur;
     const int nblk = cur.nblk;
 
-    auto block = [&](const u32x4 (&f)[2], int blk) {
+    auto block = [&](const u32x4 (&f)[CB][2], int blk) {
       f32x16 dxa;
 #pragma unroll
       for (int i = 0; i < 16; ++i) dxa[i] = 0.f;
@@ -594,10 +619,13 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks)
+          for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-              M::mma(dpm_frag<T>(f[ks]), dpm_frag<T>(ld16(sw1 + woff[ks] + (hq * 4 + hp * 2 + k) * 2048)), acc[k]);
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+              for (int k = 0; k < 2; ++k)
+                M::mma(dpm_frag<T>(f[cb][ks]),
+                       dpm_frag<T>(ld16(sw1 + cb * (256 * 64) + woff[ks] + (hq * 4 + hp * 2 + k) * 2048)), acc[k]);
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const float dp = dpos[hq * 4 + hp * 2 + k], dn = slope * dp, bs = nbias[hq * 4 + hp * 2 + k];
@@ -626,7 +654,7 @@ __global__ void __launch_bounds__(256, 2)
       const int q = blk * 32 + r;
       if (q < J.npx) {
         const int qr = (int)(((float)q + 0.5f) * J.inv_bw), qcol = q - qr * J.bw;
-        T* p = dx + (J.pix0 + (long)qr * W + qcol) * ldx + 4 * h;
+        T* p = dx + (J.pix0 + (long)qr * W + qcol) * ldx + cbs * 32 + 4 * h;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           T pk[4];
@@ -646,14 +674,15 @@ __global__ void __launch_bounds__(256, 2)
     };
 
     for (int blk = 0; blk + 1 < nblk; blk += 2) {
-      dpm_rec_rows<T>(x, J, W, ldx, blk + 1, r, h, f1);
+      dpm_rec_rows<T, CB>(x, J, W, ldx, blk + 1, r, h, f1);
       block(f0, blk);
-      dpm_rec_rows<T>(x, J, W, ldx, min(blk + 2, nblk - 1), r, h, f0);
+      dpm_rec_rows<T, CB>(x, J, W, ldx, min(blk + 2, nblk - 1), r, h, f0);
       block(f1, blk + 1);
     }
     if (nblk & 1) block(f0, nblk - 1);
     cur = nxt;
-    f0[0] = n0[0], f0[1] = n0[1];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) f0[cb][0] = n0[cb][0], f0[cb][1] = n0[cb][1];
   }
 }
 
@@ -666,22 +695,38 @@ inline bool dpm_enabled() {
 }
 
 inline bool dpm_applicable(int dtype, int C, int hid, float slope) {
-  return dpm_enabled() && (dtype == CY_BF16 || dtype == CY_F16) && C == 32 && (hid == 128 || hid == 256) &&
+  return dpm_enabled() && (dtype == CY_BF16 || dtype == CY_F16) && (C == 32 || C == 64 || C == 128) && (hid == 128 || hid == 256) &&
          slope <= 1.f;  // (the forward kernel forms lrelu as max(t, slope * t))
+}
+
+template <typename T, int CB>
+int dpm_launch_fwd_cb(const T* x, const float* w1, const float* b1, const int32_t* bins, int nb, float* hpool, int H,
+                      int W, int ldx, int hid, int sh, int sw, float slope, hipStream_t st) {
+  const int grid = nb < DPM_WGS * 4 ? cy_cdiv(nb, 4) : DPM_WGS;
+  // (32 hidden units x CB channel blocks x 2 k-steps of W1 fragments stay in registers: eight blocks of units per wave
+  //  for C = 32, four for C = 64 -- 128 registers either way; 256 units at C = 64 take two passes over the pixels)
+#define CY_DPM_FWD(NHB_)                                                                                                  \
+  hipLaunchKernelGGL((dense_proj_mfma_fwd_kernel<T, NHB_, CB>), dim3(grid), dim3(256), 0, st, x, w1, b1, bins, nb, hpool, H, \
+                     W, ldx, hid, sh, sw, slope)
+  if constexpr (CB >= 4) {  // (128 channels: two blocks of units per wave, 64 registers of W1 fragments next to 96 of rows)
+    CY_DPM_FWD(2);
+  } else if constexpr (CB == 2) {
+    CY_DPM_FWD(4);
+  } else {
+    if (hid == 256) CY_DPM_FWD(8);
+    else CY_DPM_FWD(4);
+  }
+#undef CY_DPM_FWD
+  CY_CHECK_LAUNCH();
+  return CY_OK;
 }
 
 template <typename T>
 int dpm_launch_fwd(const T* x, const float* w1, const float* b1, const int32_t* bins, int nb, float* hpool, int H,
-                   int W, int ldx, int hid, int sh, int sw, float slope, hipStream_t st) {
-  const int grid = nb < DPM_WGS * 4 ? cy_cdiv(nb, 4) : DPM_WGS;
-  if (hid == 256)
-    hipLaunchKernelGGL((dense_proj_mfma_fwd_kernel<T, 8>), dim3(grid), dim3(256), 0, st, x, w1, b1, bins, nb, hpool,
-                       H, W, ldx, hid, sh, sw, slope);
-  else
-    hipLaunchKernelGGL((dense_proj_mfma_fwd_kernel<T, 4>), dim3(grid), dim3(256), 0, st, x, w1, b1, bins, nb, hpool,
-                       H, W, ldx, hid, sh, sw, slope);
-  CY_CHECK_LAUNCH();
-  return CY_OK;
+                   int W, int ldx, int C, int hid, int sh, int sw, float slope, hipStream_t st) {
+  if (C == 128) return dpm_launch_fwd_cb<T, 4>(x, w1, b1, bins, nb, hpool, H, W, ldx, hid, sh, sw, slope, st);
+  if (C == 64) return dpm_launch_fwd_cb<T, 2>(x, w1, b1, bins, nb, hpool, H, W, ldx, hid, sh, sw, slope, st);
+  return dpm_launch_fwd_cb<T, 1>(x, w1, b1, bins, nb, hpool, H, W, ldx, hid, sh, sw, slope, st);
 }
 
 inline int dpm_dw_grid(int njobs, int npass) {
@@ -690,10 +735,10 @@ inline int dpm_dw_grid(int njobs, int npass) {
   return (per < cap ? per : cap) * npass;
 }
 
-template <typename T>
-int dpm_launch_bwd(const T* x, const float* w1, const float* b1, const int32_t* bins, int nb, const float* dhpool,
-                   T* dx, float* dw1, float* db1, int accumulate, int N, int H, int W, int ldx, int hid, int sh,
-                   int sw, float slope, float* ws, hipStream_t st) {
+template <typename T, int CB>
+int dpm_launch_bwd_cb(const T* x, const float* w1, const float* b1, const int32_t* bins, int nb, const float* dhpool,
+                      T* dx, float* dw1, float* db1, int accumulate, int N, int H, int W, int ldx, int hid, int sh,
+                      int sw, float slope, float* ws, hipStream_t st) {
   const bool cells = bins == nullptr;
   const int njobs = cells ? N * (2 * sh - 1) * (2 * sw - 1) : nb;
   const int npass = hid / 128;
@@ -701,42 +746,58 @@ int dpm_launch_bwd(const T* x, const float* w1, const float* b1, const int32_t* 
   hipLaunchKernelGGL(dpm_jobs_kernel, dim3(cy_cdiv(njobs, 256)), dim3(256), 0, st, bins, njobs, recs, cells ? 1 : 0, sh,
                      sw, H, W);
   CY_CHECK_LAUNCH();
-  if (dw1 || db1) {
-    const int grid = dpm_dw_grid(njobs, npass);
-    if (cells)
-      hipLaunchKernelGGL((dense_proj_mfma_dw_kernel<T, true>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs, njobs,
-                         dhpool, ws, H, W, ldx, hid, sh, sw, slope);
-    else
-      hipLaunchKernelGGL((dense_proj_mfma_dw_kernel<T, false>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs, njobs,
-                         dhpool, ws, H, W, ldx, hid, sh, sw, slope);
-    CY_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dense_proj_mfma_reduce_kernel, dim3(cy_cdiv((long)npass * DPM_PART, 32)), dim3(256), 0, st,
-                       (const float*)ws, dw1, db1, grid, npass, accumulate);
-    CY_CHECK_LAUNCH();
-  }
-  if (dx) {
-    const int grid = njobs < DPM_WGS * 4 ? cy_cdiv(njobs, 4) : DPM_WGS;
-    if (cells) {
-      if (hid == 256)
-        hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 8, true>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs,
-                           njobs, dhpool, dx, H, W, ldx, hid, sh, sw, slope, -1);
+  for (int cbs = 0; cbs < CB; ++cbs) {  // the second product for one block of 32 channels per launch
+    if (dw1 || (db1 && cbs == 0)) {
+      const int grid = dpm_dw_grid(njobs, npass);
+      if (cells)
+        hipLaunchKernelGGL((dense_proj_mfma_dw_kernel<T, true, CB>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs, njobs,
+                           dhpool, ws, H, W, ldx, hid, sh, sw, slope, cbs);
       else
-        hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 4, true>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs,
-                           njobs, dhpool, dx, H, W, ldx, hid, sh, sw, slope, -1);
+        hipLaunchKernelGGL((dense_proj_mfma_dw_kernel<T, false, CB>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs, njobs,
+                           dhpool, ws, H, W, ldx, hid, sh, sw, slope, cbs);
       CY_CHECK_LAUNCH();
-    } else {
-      for (int colour = 0; colour < 4; ++colour) {
+      hipLaunchKernelGGL(dense_proj_mfma_reduce_kernel, dim3(cy_cdiv((long)npass * DPM_PART, 32)), dim3(256), 0, st,
+                         (const float*)ws, dw1, cbs == 0 ? db1 : (float*)nullptr, grid, npass, accumulate, 32 * CB, 32 * cbs);
+      CY_CHECK_LAUNCH();
+    }
+    if (dx) {
+      const int grid = njobs < DPM_WGS * 4 ? cy_cdiv(njobs, 4) : DPM_WGS;
+      if (cells) {
         if (hid == 256)
-          hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 8, false>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs,
-                             njobs, dhpool, dx, H, W, ldx, hid, sh, sw, slope, colour);
+          hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 8, true, CB>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs,
+                             njobs, dhpool, dx, H, W, ldx, hid, sh, sw, slope, -1, cbs);
         else
-          hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 4, false>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs,
-                             njobs, dhpool, dx, H, W, ldx, hid, sh, sw, slope, colour);
+          hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 4, true, CB>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs,
+                             njobs, dhpool, dx, H, W, ldx, hid, sh, sw, slope, -1, cbs);
         CY_CHECK_LAUNCH();
+      } else {
+        for (int colour = 0; colour < 4; ++colour) {
+          if (hid == 256)
+            hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 8, false, CB>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs,
+                               njobs, dhpool, dx, H, W, ldx, hid, sh, sw, slope, colour, cbs);
+          else
+            hipLaunchKernelGGL((dense_proj_mfma_dx_kernel<T, 4, false, CB>), dim3(grid), dim3(256), 0, st, x, w1, b1, recs,
+                               njobs, dhpool, dx, H, W, ldx, hid, sh, sw, slope, colour, cbs);
+          CY_CHECK_LAUNCH();
+        }
       }
     }
   }
   return CY_OK;
+}
+
+template <typename T>
+int dpm_launch_bwd(const T* x, const float* w1, const float* b1, const int32_t* bins, int nb, const float* dhpool,
+                   T* dx, float* dw1, float* db1, int accumulate, int N, int H, int W, int ldx, int C, int hid, int sh,
+                   int sw, float slope, float* ws, hipStream_t st) {
+  if (C == 128)
+    return dpm_launch_bwd_cb<T, 4>(x, w1, b1, bins, nb, dhpool, dx, dw1, db1, accumulate, N, H, W, ldx, hid, sh, sw, slope,
+                                   ws, st);
+  if (C == 64)
+    return dpm_launch_bwd_cb<T, 2>(x, w1, b1, bins, nb, dhpool, dx, dw1, db1, accumulate, N, H, W, ldx, hid, sh, sw, slope,
+                                   ws, st);
+  return dpm_launch_bwd_cb<T, 1>(x, w1, b1, bins, nb, dhpool, dx, dw1, db1, accumulate, N, H, W, ldx, hid, sh, sw, slope, ws,
+                                 st);
 }
 
 }  // namespace
