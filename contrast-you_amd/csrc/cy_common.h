@@ -110,6 +110,10 @@ template <typename T> __device__ __forceinline__ float round_through(float v) {
 __device__ __forceinline__ u32x4 ld16(const void* p) {
   return *reinterpret_cast<const u32x4*>(p);
 }
+// streaming read: the line is not wanted in the caches after this use (the last reader of a large tensor)
+__device__ __forceinline__ u32x4 ld16_nt(const void* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+}
 __device__ __forceinline__ void st16(void* p, const u32x4& v) {
   *reinterpret_cast<u32x4*>(p) = v;
 }

@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""the dense projector over feature-map channel counts (the decoder taps of UNet(max_channel=512)), N = 32, 256 hidden units:
+    python tools/bench_dense_channels.py            (on the GPU box; times are host-paced events in ms -> us)"""
 import sys, torch
-sys.path.insert(0, "/root/repo/contrast-you_amd"); sys.path.insert(0, "/root/repo/tools")
+from pathlib import Path
+REPO = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(REPO / "contrast-you_amd")); sys.path.insert(0, str(REPO / "tools"))
 from cyhip import ops
 from bench_next import timed
 dev, dt = "cuda", torch.bfloat16
@@ -12,4 +17,4 @@ for (n, c, hw) in ((32, 32, 224), (32, 64, 112), (32, 128, 56), (32, 256, 28)):
     g = torch.randn(n * s * s, hid, device=dev)
     ms2 = timed(lambda: ops.dense_proj_bwd(x, w1, b1, (s, s), None, g, True, True), iters=3)
     xb = x.numel() * 2
-    print(f"C={c:3d} {hw}x{hw}: fwd {ms*1e3:7.1f} us ({xb/ms/1e9:6.1f} GB/s)  bwd {ms2*1e3:8.1f} us ({3*xb/ms2/1e9:6.1f} GB/s)")
+    print(f"C={c:3d} {hw}x{hw}: fwd {ms*1e3:7.1f} us ({xb/ms/1e9:5.2f} TB/s of x)  bwd {ms2*1e3:8.1f} us ({3*xb/ms2/1e9:5.2f} TB/s)")
