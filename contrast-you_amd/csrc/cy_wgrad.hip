@@ -1159,6 +1159,15 @@ int cy_conv3x3_first_wgrad(const float* x, const void* dy, float* dw, int accumu
     const int nsub = N * H / 8, spb = (nsub + nm - 1) / nm;
     size_t smem = 4096 + (size_t)3 * 10 * W * 2;
     if (smem < 16384) smem = 16384;  // (the four waves' accumulators pass through it at the end)
+    if (smem > 48 * 1024) {          // (wide images: W > 730)
+      static bool big_done = false;
+      if (!big_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(first_wgrad_mfma_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(first_wgrad_mfma_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+          return CY_ERR_LAUNCH;
+        big_done = true;
+      }
+    }
     if (dy_dtype == CY_BF16)
       hipLaunchKernelGGL(first_wgrad_mfma_kernel<bf16>, dim3(nm), dim3(256), smem, st, x, (const bf16*)dy, (float*)ws, N, H, W, spb);
     else
