@@ -30,18 +30,20 @@ __global__ void __launch_bounds__(256) k_reduce(const float* ws, float* out, int
 }
 
 // B
+template <int VARIANT>
 __global__ void __launch_bounds__(768) k_write_group_reduce(float* ws, float* part, unsigned* counter, unsigned* timeouts, int nblocks, int S) {
   const int wg = blockIdx.x, blk = wg % nblocks, sp = wg / nblocks;
   write_slab(ws + (size_t)wg * SLAB, wg);
-  __threadfence();  // release: this workgroup's slab is visible to the agent
+  if (VARIANT == 0) __threadfence();  // release by every thread: this workgroup's slab is visible to the agent
   __syncthreads();
   __shared__ int ok;
   if (threadIdx.x == 0) {
+    // (VARIANT 1: one release for the workgroup -- cumulative over the barrier -- and a slower poll)
     __hip_atomic_fetch_add(counter + blk, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     int good = 0;
     for (int it = 0; it < 4000000; ++it) {  // bounded: a wave that never sees its group must still drain
       if (__hip_atomic_load(counter + blk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)S) { good = 1; break; }
-      __builtin_amdgcn_s_sleep(4);
+      if (VARIANT == 0) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(64);
     }
     if (!good) atomicAdd(timeouts, 1u);
     ok = good;
@@ -87,7 +89,12 @@ int main() {
     });
     const float tb = timeit([&] {
       (void)hipMemsetAsync(counter, 0, 64 * 4, 0);
-      hipLaunchKernelGGL(k_write_group_reduce, dim3(256), dim3(768), 0, 0, ws, part, counter, timeouts, nblocks, S);
+      hipLaunchKernelGGL(k_write_group_reduce<0>, dim3(256), dim3(768), 0, 0, ws, part, counter, timeouts, nblocks, S);
+      hipLaunchKernelGGL(k_copy, dim3((int)((n4 + 255) / 256)), dim3(256), 0, 0, part, outB, n4);
+    });
+    const float tc = timeit([&] {
+      (void)hipMemsetAsync(counter, 0, 64 * 4, 0);
+      hipLaunchKernelGGL(k_write_group_reduce<1>, dim3(256), dim3(768), 0, 0, ws, part, counter, timeouts, nblocks, S);
       hipLaunchKernelGGL(k_copy, dim3((int)((n4 + 255) / 256)), dim3(256), 0, 0, part, outB, n4);
     });
     (void)hipDeviceSynchronize();
@@ -96,7 +103,7 @@ int main() {
     long bad = 0;
     for (long i = 0; i < n4 * 4; ++i) bad += a[i] != b[i];
     unsigned to = 0; (void)hipMemcpy(&to, timeouts, 4, hipMemcpyDeviceToHost);
-    printf("blocks %2d x splits %3d: A write + reduce %6.1f us | B write + group reduce + copy %6.1f us | mismatching floats %ld, timeouts %u\n", nblocks, S, ta, tb, bad, to);
+    printf("blocks %2d x splits %3d: A write + reduce %6.1f us | B write + group reduce + copy %6.1f us (one release per workgroup, slow poll: %6.1f) | mismatching floats %ld, timeouts %u\n", nblocks, S, ta, tb, tc, bad, to);
   }
   return 0;
 }
